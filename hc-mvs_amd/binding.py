@@ -1,0 +1,188 @@
+"""ctypes binding of libhcmvs_hip.so (the C-ABI of include/hcmvs_hip.h).
+
+Mirrors the reference's per-image interface (SceneDensify.h:63-70 DepthMapsData::EstimateDepthMap /
+FilterDepthMap / FuseDepthMaps) for tests and bench.py.  There is no CPU fallback: loading fails loudly
+when the library is missing, and creating a context fails when no gfx950 device is usable.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhcmvs_hip.so")
+
+OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_TIMEOUT, ERR_CAPACITY = range(6)
+
+
+class Params(C.Structure):
+    _fields_ = [("adapthalfwin", C.c_int32), ("n_estimation_iters", C.c_int32), ("it_external", C.c_int32),
+                ("n_external_iters", C.c_int32), ("propagate_halfwin", C.c_int32), ("propagate_step", C.c_int32),
+                ("n_random_iters", C.c_int32), ("ncc_threshold_keep", C.c_float), ("random_depth_ratio", C.c_float),
+                ("random_angle1_deg", C.c_float), ("random_angle2_deg", C.c_float),
+                ("random_smooth_depth", C.c_float), ("random_smooth_normal_deg", C.c_float),
+                ("random_smooth_bonus", C.c_float), ("photometric_flow", C.c_float), ("seed", C.c_uint32),
+                ("median_blur", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("evals", C.c_uint64), ("ms_score", C.c_float), ("ms_sweeps", C.c_float),
+                ("ms_sweep_avg", C.c_float), ("ms_end", C.c_float), ("ms_total", C.c_float),
+                ("n_sweeps", C.c_int32)]
+
+
+class HcmvsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("hcmvs error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+# every symbol include/hcmvs_hip.h declares
+SYMBOLS = ["hcmvs_default_params", "hcmvs_create", "hcmvs_destroy", "hcmvs_last_error", "hcmvs_set_stream",
+           "hcmvs_synchronize", "hcmvs_upload_view", "hcmvs_set_view_device", "hcmvs_release_view",
+           "hcmvs_get_gradient_map", "hcmvs_estimate", "hcmvs_estimate_device", "hcmvs_get_stats",
+           "hcmvs_splat_init"]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libhcmvs_hip.so is not built (run __graft_entry__.build() or make -C hc-mvs_amd/csrc); "
+                              "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, fp, u8p, dp = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_double)
+        u32p = C.POINTER(C.c_uint32)
+        L.hcmvs_default_params.argtypes = [C.POINTER(Params)]
+        L.hcmvs_default_params.restype = None
+        L.hcmvs_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.hcmvs_destroy.argtypes = [vp]
+        L.hcmvs_destroy.restype = None
+        L.hcmvs_last_error.argtypes = [vp]
+        L.hcmvs_last_error.restype = C.c_char_p
+        L.hcmvs_set_stream.argtypes = [vp, vp]
+        L.hcmvs_synchronize.argtypes = [vp]
+        L.hcmvs_upload_view.argtypes = [vp, C.c_uint32, C.c_int32, C.c_int32, fp, u8p, dp, dp, dp]
+        L.hcmvs_set_view_device.argtypes = [vp, C.c_uint32, C.c_int32, C.c_int32, vp, vp, dp, dp, dp]
+        L.hcmvs_release_view.argtypes = [vp, C.c_uint32]
+        L.hcmvs_get_gradient_map.argtypes = [vp, C.c_uint32, u8p]
+        L.hcmvs_estimate.argtypes = [vp, C.c_uint32, u32p, C.c_int32, C.POINTER(Params), C.c_float, C.c_float, fp, fp, fp]
+        L.hcmvs_estimate_device.argtypes = [vp, C.c_uint32, u32p, C.c_int32, C.POINTER(Params), C.c_float, C.c_float,
+                                            vp, vp, vp]
+        L.hcmvs_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.hcmvs_splat_init.argtypes = [vp, C.c_uint32, fp, C.c_int32, fp, fp, fp, fp]
+        _lib = L
+    return _lib
+
+
+def default_params(**kw):
+    p = Params()
+    lib().hcmvs_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _f(a):
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Context:
+    """One device context (hcmvs_ctx).  Host-buffer methods mirror DepthMapsData's per-image calls."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().hcmvs_create(device, C.byref(self._h))
+        if rc != OK:
+            raise HcmvsError(rc, "hcmvs_create failed (no usable gfx950 device?)")
+        self.shapes = {}
+
+    def close(self):
+        if self._h:
+            lib().hcmvs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise HcmvsError(rc, lib().hcmvs_last_error(self._h).decode())
+
+    def set_stream(self, stream_ptr):
+        self._chk(lib().hcmvs_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._chk(lib().hcmvs_synchronize(self._h))
+
+    def upload_view(self, vid, gray, K, R, Cc, bgr=None):
+        gray = np.ascontiguousarray(gray, np.float32)
+        h, w = gray.shape
+        Ka, Kp = _d(K); Ra, Rp = _d(R); Ca, Cp = _d(Cc)
+        bp = None
+        if bgr is not None:
+            bgr = np.ascontiguousarray(bgr, np.uint8)
+            bp = bgr.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._chk(lib().hcmvs_upload_view(self._h, vid, w, h, _f(gray), bp, Kp, Rp, Cp))
+        self.shapes[vid] = (h, w)
+
+    def set_view_device(self, vid, w, h, d_gray_ptr, K, R, Cc, d_bgr_ptr=None):
+        Ka, Kp = _d(K); Ra, Rp = _d(R); Ca, Cp = _d(Cc)
+        self._chk(lib().hcmvs_set_view_device(self._h, vid, w, h, C.c_void_p(d_gray_ptr),
+                                              C.c_void_p(d_bgr_ptr) if d_bgr_ptr else None, Kp, Rp, Cp))
+        self.shapes[vid] = (h, w)
+
+    def release_view(self, vid):
+        self._chk(lib().hcmvs_release_view(self._h, vid))
+        self.shapes.pop(vid, None)
+
+    def gradient_map(self, vid):
+        h, w = self.shapes[vid]
+        out = np.empty((h, w), np.uint8)
+        self._chk(lib().hcmvs_get_gradient_map(self._h, vid, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def splat_init(self, vid, points_xyz):
+        h, w = self.shapes[vid]
+        pts = np.ascontiguousarray(points_xyz, np.float32)
+        depth = np.zeros((h, w), np.float32); normal = np.zeros((h, w, 3), np.float32)
+        dmin = C.c_float(); dmax = C.c_float()
+        self._chk(lib().hcmvs_splat_init(self._h, vid, _f(pts), len(pts), _f(depth), _f(normal), C.byref(dmin),
+                                         C.byref(dmax)))
+        return depth, normal, dmin.value, dmax.value
+
+    def estimate(self, ref_id, src_ids, params, d_min, d_max, depth, normal, conf=None):
+        """EstimateDepthMap on host maps (copied); returns (depth, normal, conf)."""
+        h, w = self.shapes[ref_id]
+        d = np.ascontiguousarray(depth, np.float32).copy()
+        n = np.ascontiguousarray(normal, np.float32).copy()
+        c = np.zeros((h, w), np.float32) if conf is None else np.ascontiguousarray(conf, np.float32).copy()
+        assert d.shape == (h, w) and n.shape == (h, w, 3)
+        ids = (C.c_uint32 * len(src_ids))(*src_ids)
+        self._chk(lib().hcmvs_estimate(self._h, ref_id, ids, len(src_ids), C.byref(params), d_min, d_max, _f(d),
+                                       _f(n), _f(c)))
+        return d, n, c
+
+    def estimate_device(self, ref_id, src_ids, params, d_min, d_max, d_depth_ptr, d_normal_ptr, d_conf_ptr):
+        ids = (C.c_uint32 * len(src_ids))(*src_ids)
+        self._chk(lib().hcmvs_estimate_device(self._h, ref_id, ids, len(src_ids), C.byref(params), d_min, d_max,
+                                              C.c_void_p(d_depth_ptr), C.c_void_p(d_normal_ptr),
+                                              C.c_void_p(d_conf_ptr)))
+
+    def stats(self):
+        s = Stats()
+        self._chk(lib().hcmvs_get_stats(self._h, C.byref(s)))
+        return s

@@ -1,0 +1,459 @@
+/*
+ * hc-mvs_amd/csrc/hcmvs_api.cpp -- host side of the C-ABI declared in include/hcmvs_hip.h.
+ *
+ * Holds the per-device context (views resident in HBM, working maps, row-progress words), derives the
+ * per-call constants the way DepthEstimator's constructor does (DepthMap.cpp:386-439, DepthMap.h:412-444)
+ * and enqueues the kernels of pm_kernels.hip.  No compute happens on the host; without a usable HIP
+ * device every entry point fails.
+ */
+#include "../../include/hcmvs_hip.h"
+#include "pm_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace hcmvs;
+
+namespace {
+
+struct View {
+	int w = 0, h = 0;
+	float* gray = nullptr;   // device
+	uint8_t* bgr = nullptr;  // device or null
+	uint8_t* gra = nullptr;  // device gradient map (lazy)
+	bool owned = false;
+	double K[9], R[9], C[3];
+};
+
+} // namespace
+
+struct hcmvs_ctx {
+	int device = 0;
+	hipStream_t ownStream = nullptr;
+	hipStream_t stream = nullptr;
+	std::string err;
+	std::map<uint32_t, View> views;
+	// working buffers (grown on demand)
+	size_t capPixels = 0;
+	float4* dn = nullptr;
+	float* conf = nullptr;
+	float* tmpDepth = nullptr;
+	uint8_t* tmpU8 = nullptr;
+	// host-path staging
+	size_t capStage = 0;
+	float *sDepth = nullptr, *sNormal = nullptr, *sConf = nullptr;
+	DevView* dViews = nullptr;
+	DevView hViews[kMaxViews]; // host copy handed to hipMemcpyAsync (must outlive the call)
+	int32_t* sync = nullptr; // [ticket, error, pad..., progress rows]
+	size_t capSyncInts = 0;
+	unsigned long long* evals = nullptr;
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	int lastSweeps = 0;
+	bool haveStats = false;
+	int sweepLag = 2;
+};
+
+static int fail(hcmvs_ctx* c, int code, const char* fmt, ...) {
+	if (c) {
+		char buf[512];
+		va_list ap;
+		va_start(ap, fmt);
+		vsnprintf(buf, sizeof buf, fmt, ap);
+		va_end(ap);
+		c->err = buf;
+	}
+	return code;
+}
+#define HIPCHK(c, call)                                                                             \
+	do {                                                                                            \
+		hipError_t e_ = (call);                                                                     \
+		if (e_ != hipSuccess) return fail(c, HCMVS_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+	} while (0)
+
+static void mat3_mul(const double* a, const double* b, double* c) {
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j) {
+			double s = 0;
+			for (int k = 0; k < 3; ++k) s += a[i * 3 + k] * b[k * 3 + j];
+			c[i * 3 + j] = s;
+		}
+}
+static void mat3_mul_bt(const double* a, const double* b, double* c) {
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j) {
+			double s = 0;
+			for (int k = 0; k < 3; ++k) s += a[i * 3 + k] * b[j * 3 + k];
+			c[i * 3 + j] = s;
+		}
+}
+static void mat3_inv(const double* m, double* r) {
+	const double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+	                 m[2] * (m[3] * m[7] - m[4] * m[6]);
+	const double id = 1.0 / d;
+	r[0] = (m[4] * m[8] - m[5] * m[7]) * id;
+	r[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+	r[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+	r[3] = (m[5] * m[6] - m[3] * m[8]) * id;
+	r[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+	r[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+	r[6] = (m[3] * m[7] - m[4] * m[6]) * id;
+	r[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+	r[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+static inline float fd2r(float d) { return d * (3.14159274101257324f / 180.f); }
+
+extern "C" {
+
+void hcmvs_default_params(hcmvs_params* p) {
+	if (!p) return;
+	memset(p, 0, sizeof *p);
+	p->adapthalfwin = 5;           // DensifyPointCloud.cpp:163
+	p->n_estimation_iters = 1;
+	p->it_external = 0;
+	p->n_external_iters = 1;
+	p->propagate_halfwin = 1;
+	p->propagate_step = 4;
+	p->n_random_iters = 6;         // DepthMap.cpp:120
+	p->ncc_threshold_keep = 0.55f; // DepthMap.cpp:117
+	p->random_depth_ratio = 0.003f;
+	p->random_angle1_deg = 16.f;
+	p->random_angle2_deg = 10.f;
+	p->random_smooth_depth = 0.02f;
+	p->random_smooth_normal_deg = 13.f;
+	p->random_smooth_bonus = 0.93f;
+	p->photometric_flow = 0.f;
+	p->seed = 1234;
+	p->median_blur = 1;
+}
+
+int hcmvs_create(int device, hcmvs_ctx** out) {
+	if (!out) return HCMVS_ERR_INVALID;
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return HCMVS_ERR_NO_DEVICE;
+	if (hipSetDevice(device) != hipSuccess) return HCMVS_ERR_NO_DEVICE;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return HCMVS_ERR_NO_DEVICE;
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return HCMVS_ERR_NO_DEVICE; // kernels are built for gfx950 only
+	hcmvs_ctx* c = new hcmvs_ctx();
+	c->device = device;
+	if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { delete c; return HCMVS_ERR_NO_DEVICE; }
+	c->stream = c->ownStream;
+	for (auto& e : c->ev)
+		if (hipEventCreate(&e) != hipSuccess) { delete c; return HCMVS_ERR_NO_DEVICE; }
+	if (hipMalloc(&c->dViews, sizeof(DevView) * kMaxViews) != hipSuccess || hipMalloc(&c->evals, 8) != hipSuccess) {
+		delete c;
+		return HCMVS_ERR_NO_DEVICE;
+	}
+	const char* lag = getenv("HCMVS_SWEEP_LAG");
+	if (lag && atoi(lag) >= 1) c->sweepLag = atoi(lag);
+	*out = c;
+	return HCMVS_OK;
+}
+
+static void free_view(View& v) {
+	if (v.owned) { if (v.gray) (void)hipFree(v.gray); if (v.bgr) (void)hipFree(v.bgr); }
+	if (v.gra) (void)hipFree(v.gra);
+	v = View();
+}
+
+void hcmvs_destroy(hcmvs_ctx* c) {
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	for (auto& kv : c->views) free_view(kv.second);
+	for (void* p : {(void*)c->dn, (void*)c->conf, (void*)c->tmpDepth, (void*)c->tmpU8, (void*)c->sDepth, (void*)c->sNormal,
+	                (void*)c->sConf, (void*)c->dViews, (void*)c->sync, (void*)c->evals})
+		if (p) (void)hipFree(p);
+	for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+	if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+	delete c;
+}
+
+const char* hcmvs_last_error(const hcmvs_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int hcmvs_set_stream(hcmvs_ctx* c, void* stream) {
+	if (!c) return HCMVS_ERR_INVALID;
+	c->stream = stream ? (hipStream_t)stream : c->ownStream;
+	return HCMVS_OK;
+}
+int hcmvs_synchronize(hcmvs_ctx* c) {
+	if (!c) return HCMVS_ERR_INVALID;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return HCMVS_OK;
+}
+
+static int set_view(hcmvs_ctx* c, uint32_t id, int w, int h, const float* gray, const uint8_t* bgr, const double* K,
+                    const double* R, const double* C, bool copy) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!gray || !K || !R || !C || w < 2 * kHalfWindow + 2 || h < 2 * kHalfWindow + 2 || w > 32768 || h > 32768 || id >= 65536)
+		return fail(c, HCMVS_ERR_INVALID, "upload_view: bad arguments (id %u, %dx%d)", id, w, h);
+	HIPCHK(c, hipSetDevice(c->device));
+	auto it = c->views.find(id);
+	if (it != c->views.end()) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_view(it->second); }
+	View v;
+	v.w = w; v.h = h; v.owned = copy;
+	const size_t n = (size_t)w * h;
+	if (copy) {
+		HIPCHK(c, hipMalloc(&v.gray, n * sizeof(float)));
+		HIPCHK(c, hipMemcpyAsync(v.gray, gray, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+		if (bgr) {
+			HIPCHK(c, hipMalloc(&v.bgr, n * 3));
+			HIPCHK(c, hipMemcpyAsync(v.bgr, bgr, n * 3, hipMemcpyHostToDevice, c->stream));
+		}
+		HIPCHK(c, hipStreamSynchronize(c->stream)); // the caller may free its host buffers on return
+	} else {
+		v.gray = const_cast<float*>(gray);
+		v.bgr = const_cast<uint8_t*>(bgr);
+	}
+	memcpy(v.K, K, sizeof v.K); memcpy(v.R, R, sizeof v.R); memcpy(v.C, C, sizeof v.C);
+	c->views[id] = v;
+	return HCMVS_OK;
+}
+
+int hcmvs_upload_view(hcmvs_ctx* c, uint32_t id, int32_t w, int32_t h, const float* gray, const uint8_t* bgr,
+                      const double K[9], const double R[9], const double C[3]) {
+	return set_view(c, id, w, h, gray, bgr, K, R, C, true);
+}
+int hcmvs_set_view_device(hcmvs_ctx* c, uint32_t id, int32_t w, int32_t h, const float* gray, const uint8_t* bgr,
+                          const double K[9], const double R[9], const double C[3]) {
+	return set_view(c, id, w, h, gray, bgr, K, R, C, false);
+}
+int hcmvs_release_view(hcmvs_ctx* c, uint32_t id) {
+	if (!c) return HCMVS_ERR_INVALID;
+	auto it = c->views.find(id);
+	if (it == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "release_view: unknown view %u", id);
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	free_view(it->second);
+	c->views.erase(it);
+	return HCMVS_OK;
+}
+
+static int ensure_work(hcmvs_ctx* c, size_t n, int rows) {
+	if (n > c->capPixels) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		for (void* p : {(void*)c->dn, (void*)c->conf, (void*)c->tmpDepth, (void*)c->tmpU8}) if (p) (void)hipFree(p);
+		c->dn = nullptr; c->conf = nullptr; c->tmpDepth = nullptr; c->tmpU8 = nullptr; c->capPixels = 0;
+		HIPCHK(c, hipMalloc(&c->dn, n * sizeof(float4)));
+		HIPCHK(c, hipMalloc(&c->conf, n * sizeof(float)));
+		HIPCHK(c, hipMalloc(&c->tmpDepth, n * sizeof(float)));
+		HIPCHK(c, hipMalloc(&c->tmpU8, n));
+		c->capPixels = n;
+	}
+	const size_t ints = 16 + (size_t)rows * kProgressStride;
+	if (ints > c->capSyncInts) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		if (c->sync) (void)hipFree(c->sync);
+		c->sync = nullptr; c->capSyncInts = 0;
+		HIPCHK(c, hipMalloc(&c->sync, ints * sizeof(int32_t)));
+		c->capSyncInts = ints;
+	}
+	return HCMVS_OK;
+}
+
+// SceneDensify.cpp:581-595 InitGraMap, computed once per view on the device
+static int ensure_gradient(hcmvs_ctx* c, View& v) {
+	if (v.gra) return HCMVS_OK;
+	const int n = v.w * v.h;
+	int rc = ensure_work(c, (size_t)n, v.h);
+	if (rc) return rc;
+	HIPCHK(c, hipMalloc(&v.gra, (size_t)n));
+	if (v.bgr) launch_bgr_to_u8(v.bgr, c->tmpU8, n, c->stream);
+	else launch_gray_to_u8(v.gray, c->tmpU8, n, c->stream);
+	launch_gradient_map(c->tmpU8, v.gra, v.w, v.h, c->stream);
+	HIPCHK(c, hipGetLastError());
+	return HCMVS_OK;
+}
+
+int hcmvs_get_gradient_map(hcmvs_ctx* c, uint32_t id, uint8_t* out) {
+	if (!c || !out) return HCMVS_ERR_INVALID;
+	auto it = c->views.find(id);
+	if (it == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "get_gradient_map: unknown view %u", id);
+	HIPCHK(c, hipSetDevice(c->device));
+	int rc = ensure_gradient(c, it->second);
+	if (rc) return rc;
+	HIPCHK(c, hipMemcpyAsync(out, it->second.gra, (size_t)it->second.w * it->second.h, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return HCMVS_OK;
+}
+
+int hcmvs_estimate_device(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* src_ids, int32_t n_src, const hcmvs_params* p,
+                          float d_min, float d_max, float* d_depth, float* d_normal, float* d_conf) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!src_ids || !p || !d_depth || !d_normal || !d_conf) return fail(c, HCMVS_ERR_INVALID, "estimate: null argument");
+	if (n_src < 1 || n_src > HCMVS_MAX_VIEWS) return fail(c, HCMVS_ERR_INVALID, "estimate: n_src %d not in 1..%d", n_src, HCMVS_MAX_VIEWS);
+	if (p->adapthalfwin < 1 || p->adapthalfwin > kHalfWindow) return fail(c, HCMVS_ERR_INVALID, "estimate: adapthalfwin %d not in 1..7", p->adapthalfwin);
+	if (p->n_estimation_iters < 0 || p->n_random_iters < 0 || p->n_random_iters > 20)
+		return fail(c, HCMVS_ERR_INVALID, "estimate: bad iteration counts");
+	if (!(d_min > 0.f) || !(d_max > d_min)) return fail(c, HCMVS_ERR_INVALID, "estimate: bad depth range [%g,%g)", d_min, d_max);
+	auto rit = c->views.find(ref_id);
+	if (rit == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "estimate: unknown reference view %u", ref_id);
+	View& ref = rit->second;
+	HIPCHK(c, hipSetDevice(c->device));
+	int rc = ensure_work(c, (size_t)ref.w * ref.h, ref.h);
+	if (rc) return rc;
+	rc = ensure_gradient(c, ref);
+	if (rc) return rc;
+
+	// per-call constants: DepthMap.cpp:386-439, DepthMap.h:412-444
+	EstConst k;
+	memset(&k, 0, sizeof k);
+	k.W = ref.w; k.H = ref.h; k.V = n_src;
+	k.adapthalfwin = p->adapthalfwin; k.nRandomIters = p->n_random_iters; k.itExternal = p->it_external;
+	k.propHalfwin = p->propagate_halfwin; k.propStep = p->propagate_step;
+	k.ref = ref.gray; k.gra = ref.gra; k.views = c->dViews;
+	mat3_inv(ref.K, k.Hr);
+	k.fx = ref.K[0]; k.fy = ref.K[4]; k.cx = ref.K[2]; k.cy = ref.K[5];
+	DevView* hv = c->hViews;
+	memset(hv, 0, sizeof c->hViews);
+	for (int v = 0; v < n_src; ++v) {
+		auto sit = c->views.find(src_ids[v]);
+		if (sit == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "estimate: unknown source view %u", src_ids[v]);
+		const View& s = sit->second;
+		double KR[9], Hl[9];
+		mat3_mul(s.K, s.R, KR);
+		mat3_mul_bt(KR, ref.R, Hl);
+		const double dC[3] = {ref.C[0] - s.C[0], ref.C[1] - s.C[1], ref.C[2] - s.C[2]};
+		for (int i = 0; i < 3; ++i) hv[v].Hm[i] = KR[i * 3] * dC[0] + KR[i * 3 + 1] * dC[1] + KR[i * 3 + 2] * dC[2];
+		mat3_mul(Hl, k.Hr, hv[v].A);
+		hv[v].img = s.gray; hv[v].w = s.w; hv[v].h = s.h;
+	}
+	k.dMin = d_min; k.dMax = d_max; k.dMinSqr = sqrtf(d_min); k.dMaxSqr = sqrtf(d_max);
+	k.smoothBonusDepth = 1.f - p->random_smooth_bonus;
+	k.smoothBonusNormal = (1.f - p->random_smooth_bonus) * 0.96f;
+	k.smoothSigmaDepth = -1.f / (2.f * (p->random_smooth_depth * p->random_smooth_depth));
+	{ const float r = fd2r(p->random_smooth_normal_deg); k.smoothSigmaNormal = -1.f / (2.f * (r * r)); }
+	k.angle1Range = fd2r(p->random_angle1_deg);
+	k.angle2Range = fd2r(p->random_angle2_deg);
+	k.thConfSmall = p->ncc_threshold_keep * 0.2f;
+	k.thConfBig = p->ncc_threshold_keep * 0.4f;
+	k.thConfRand = p->ncc_threshold_keep * 0.9f;
+	k.thRobust = p->ncc_threshold_keep * 1.2f;
+	k.thKeep = p->ncc_threshold_keep;
+	k.depthRatio = p->random_depth_ratio;
+	k.pfScale = 1.f - p->photometric_flow;
+	k.seed = p->seed;
+	k.dn = c->dn; k.conf = c->conf;
+
+	hipStream_t s = c->stream;
+	// the previous call's copy of the view table must not be overwritten while in use: same stream => ordered
+	HIPCHK(c, hipMemcpyAsync(c->dViews, hv, sizeof(DevView) * n_src, hipMemcpyHostToDevice, s));
+	HIPCHK(c, hipMemsetAsync(c->evals, 0, 8, s));
+
+	HIPCHK(c, hipEventRecord(c->ev[0], s));
+	const float* depthIn = d_depth;
+	if (p->median_blur) { // SceneDensify.cpp:859
+		launch_median3(d_depth, c->tmpDepth, ref.w, ref.h, s);
+		depthIn = c->tmpDepth;
+	}
+	launch_score_pass(k, depthIn, d_normal, c->evals, s);
+	HIPCHK(c, hipEventRecord(c->ev[1], s));
+	const int rows = ref.h - 2 * kHalfWindow;
+	SweepSync sy;
+	sy.ticket = c->sync; sy.error = c->sync + 1; sy.progress = c->sync + 16; sy.evals = c->evals;
+	for (int iter = 0; iter < p->n_estimation_iters; ++iter) {
+		HIPCHK(c, hipMemsetAsync(c->sync, 0, (16 + (size_t)rows * kProgressStride) * sizeof(int32_t), s));
+		launch_sweep(k, sy, iter, c->sweepLag, s);
+	}
+	HIPCHK(c, hipEventRecord(c->ev[2], s));
+	launch_end_pass(k, p->it_external == p->n_external_iters - 1 ? 1 : 0, d_depth, d_normal, d_conf, s);
+	HIPCHK(c, hipEventRecord(c->ev[3], s));
+	HIPCHK(c, hipGetLastError());
+	c->lastSweeps = p->n_estimation_iters;
+	c->haveStats = true;
+	return HCMVS_OK;
+}
+
+int hcmvs_get_stats(hcmvs_ctx* c, hcmvs_stats* out) {
+	if (!c || !out) return HCMVS_ERR_INVALID;
+	memset(out, 0, sizeof *out);
+	if (!c->haveStats) return fail(c, HCMVS_ERR_INVALID, "get_stats: no estimate has run");
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	unsigned long long ev = 0;
+	HIPCHK(c, hipMemcpy(&ev, c->evals, 8, hipMemcpyDeviceToHost));
+	out->evals = ev;
+	HIPCHK(c, hipEventElapsedTime(&out->ms_score, c->ev[0], c->ev[1]));
+	HIPCHK(c, hipEventElapsedTime(&out->ms_sweeps, c->ev[1], c->ev[2]));
+	HIPCHK(c, hipEventElapsedTime(&out->ms_end, c->ev[2], c->ev[3]));
+	HIPCHK(c, hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[3]));
+	out->n_sweeps = c->lastSweeps;
+	out->ms_sweep_avg = c->lastSweeps > 0 ? out->ms_sweeps / (float)c->lastSweeps : 0.f;
+	int32_t flags[2] = {0, 0};
+	HIPCHK(c, hipMemcpy(flags, c->sync, sizeof flags, hipMemcpyDeviceToHost));
+	if (flags[1] != 0) return fail(c, HCMVS_ERR_TIMEOUT, "sweep worker timed out waiting for its predecessor row");
+	return HCMVS_OK;
+}
+
+int hcmvs_estimate(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* src_ids, int32_t n_src, const hcmvs_params* p, float d_min,
+                   float d_max, float* depth, float* normal, float* conf) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!depth || !normal || !conf) return fail(c, HCMVS_ERR_INVALID, "estimate: null map buffer");
+	auto rit = c->views.find(ref_id);
+	if (rit == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "estimate: unknown reference view %u", ref_id);
+	HIPCHK(c, hipSetDevice(c->device));
+	const size_t n = (size_t)rit->second.w * rit->second.h;
+	if (n > c->capStage) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		for (void* q : {(void*)c->sDepth, (void*)c->sNormal, (void*)c->sConf}) if (q) (void)hipFree(q);
+		c->sDepth = c->sNormal = c->sConf = nullptr; c->capStage = 0;
+		HIPCHK(c, hipMalloc(&c->sDepth, n * 4));
+		HIPCHK(c, hipMalloc(&c->sNormal, n * 12));
+		HIPCHK(c, hipMalloc(&c->sConf, n * 4));
+		c->capStage = n;
+	}
+	hipStream_t s = c->stream;
+	HIPCHK(c, hipMemcpyAsync(c->sDepth, depth, n * 4, hipMemcpyHostToDevice, s));
+	HIPCHK(c, hipMemcpyAsync(c->sNormal, normal, n * 12, hipMemcpyHostToDevice, s));
+	HIPCHK(c, hipMemcpyAsync(c->sConf, conf, n * 4, hipMemcpyHostToDevice, s));
+	int rc = hcmvs_estimate_device(c, ref_id, src_ids, n_src, p, d_min, d_max, c->sDepth, c->sNormal, c->sConf);
+	if (rc) return rc;
+	HIPCHK(c, hipMemcpyAsync(depth, c->sDepth, n * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipMemcpyAsync(normal, c->sNormal, n * 12, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipMemcpyAsync(conf, c->sConf, n * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipStreamSynchronize(s));
+	hcmvs_stats st;
+	return hcmvs_get_stats(c, &st); // surfaces a sweep timeout as an error
+}
+
+int hcmvs_splat_init(hcmvs_ctx* c, uint32_t id, const float* pts, int32_t n, float* depth, float* normal, float* d_min,
+                     float* d_max) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!pts || !depth || !normal || !d_min || !d_max || n < 1) return fail(c, HCMVS_ERR_INVALID, "splat_init: bad arguments");
+	auto it = c->views.find(id);
+	if (it == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "splat_init: unknown view %u", id);
+	const View& v = it->second;
+	const int W = v.w, H = v.h;
+	memset(depth, 0, sizeof(float) * (size_t)W * H);
+	float dmin = 3.402823466e+38f, dmax = 0.f;
+	for (int i = 0; i < n; ++i) { // SceneDensify.cpp:789-806
+		const double X[3] = {pts[3 * i] - v.C[0], pts[3 * i + 1] - v.C[1], pts[3 * i + 2] - v.C[2]};
+		double cam[3];
+		for (int r = 0; r < 3; ++r) cam[r] = v.R[r * 3] * X[0] + v.R[r * 3 + 1] * X[1] + v.R[r * 3 + 2] * X[2];
+		const int x = (int)std::floor(v.K[2] + v.K[0] * (cam[0] / cam[2]) + .5);
+		const int y = (int)std::floor(v.K[5] + v.K[4] * (cam[1] / cam[2]) + .5);
+		const float d = (float)cam[2];
+		const int sx = x - 2 > 0 ? x - 2 : 0, sy = y - 2 > 0 ? y - 2 : 0;
+		const int ex = x + 2 < W - 1 ? x + 2 : W - 1, ey = y + 2 < H - 1 ? y + 2 : H - 1;
+		for (int yy = sy; yy <= ey; ++yy)
+			for (int xx = sx; xx <= ex; ++xx) {
+				depth[yy * W + xx] = d;
+				float* nn = normal + 3 * ((size_t)yy * W + xx);
+				nn[0] = nn[1] = nn[2] = 0.f;
+			}
+		if (dmin > d) dmin = d;
+		if (dmax < d) dmax = d;
+	}
+	*d_min = dmin * 0.9f;
+	*d_max = dmax * 1.1f;
+	return HCMVS_OK;
+}
+
+} // extern "C"

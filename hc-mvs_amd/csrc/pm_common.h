@@ -1,0 +1,63 @@
+/*
+ * hc-mvs_amd/csrc/pm_common.h -- structures shared by the host API and the gfx950 kernels.
+ */
+#ifndef HCMVS_PM_COMMON_H
+#define HCMVS_PM_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hcmvs {
+
+constexpr int kHalfWindow = 7;      // nSizeHalfWindow, DepthMap.h:354 (fixed border, DepthMap.cpp:442-447)
+constexpr int kMaxViews = 16;
+constexpr int kMaxSlots = 32;       // neighbour slots of one pixel (cross pattern: 4 * ceil(halfwin/step))
+constexpr int kProgressStride = 16; // ints between the progress words of consecutive rows (64 B)
+
+// per source view constants, one lane group reads its own view's entry (DepthMap.h:412-444 ViewData)
+struct DevView {
+	const float* img;
+	int32_t w, h;
+	double A[9];  // Hl * Hr = Kj Rj Ri^T Ki^-1
+	double Hm[3]; // Kj Rj (Ci - Cj)
+};
+
+// uniform constants of one EstimateDepthMap call (DepthMap.cpp:386-439 DepthEstimator ctor)
+struct EstConst {
+	int32_t W, H, V;
+	int32_t adapthalfwin, nRandomIters, itExternal, propHalfwin, propStep;
+	const float* ref;
+	const uint8_t* gra;
+	const DevView* views;
+	double Hr[9];           // Ki^-1
+	double fx, fy, cx, cy;  // reference intrinsics (Camera.h:299-312)
+	float dMin, dMax, dMinSqr, dMaxSqr;
+	float smoothBonusDepth, smoothBonusNormal, smoothSigmaDepth, smoothSigmaNormal;
+	float angle1Range, angle2Range;
+	float thConfSmall, thConfBig, thConfRand, thRobust, thKeep;
+	float depthRatio, pfScale;
+	uint32_t seed;
+	// working state: (depth, nx, ny, nz) per pixel + score per pixel
+	float4* dn;
+	float* conf;
+};
+
+struct SweepSync {
+	int32_t* progress; // [rows * kProgressStride] pixels finished per logical row
+	int32_t* ticket;   // next logical row to hand out
+	int32_t* error;    // set non-zero when a worker times out
+	unsigned long long* evals;
+};
+
+// launch wrappers (pm_kernels.hip)
+void launch_gray_to_u8(const float* gray, uint8_t* out, int n, hipStream_t s);
+void launch_bgr_to_u8(const uint8_t* bgr, uint8_t* out, int n, hipStream_t s);
+void launch_gradient_map(const uint8_t* g8, uint8_t* gra, int W, int H, hipStream_t s);
+void launch_median3(const float* in, float* out, int W, int H, hipStream_t s);
+void launch_score_pass(const EstConst& c, const float* depthIn, const float* normalIn, unsigned long long* evals,
+                       hipStream_t s);
+void launch_sweep(const EstConst& c, const SweepSync& sync, int iter, int lag, hipStream_t s);
+void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s);
+
+} // namespace hcmvs
+#endif

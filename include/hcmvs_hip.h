@@ -1,0 +1,128 @@
+/*
+ * include/hcmvs_hip.h -- C-ABI of the MI355X-native PatchMatch densifier (libhcmvs_hip.so).
+ *
+ * The reference (Liaoyongjian1/HC-MVS, an OpenMVS v1.1.1 fork) has no FFI for this path: it is private
+ * C++ inside libMVS.  Each entry point below replaces one of its seams; paths are
+ * under /root/reference/frame_main/libs/MVS/:
+ *
+ *   hcmvs_upload_view / hcmvs_set_view_device
+ *        <- DepthMapsData::InitViews (SceneDensify.cpp:336-397): per view gray f32 image + camera
+ *   hcmvs_estimate / hcmvs_estimate_device
+ *        <- bool DepthMapsData::EstimateDepthMap(int it_external, IIndex idxImage)
+ *           (SceneDensify.h:63, SceneDensify.cpp:758-1072) with DepthEstimator (DepthMap.cpp:386-1738)
+ *   hcmvs_filter   <- bool DepthMapsData::FilterDepthMap(DepthData&, const IIndexArr&, bool bAdjust)
+ *                     (SceneDensify.h:69, SceneDensify.cpp:3006-3259)
+ *   hcmvs_fuse     <- void DepthMapsData::FuseDepthMaps(PointCloud&, bool, bool)
+ *                     (SceneDensify.h:70, SceneDensify.cpp:3265-3495)
+ *   hcmvs_params   <- the OPTDENSE::* globals (DepthMap.cpp:67-143) this path reads
+ *
+ * Conventions: plain pointers and sizes; caller owns every buffer; int status (0 = ok) instead of bool;
+ * no exceptions cross the boundary; hcmvs_last_error() gives the message of the last failure on a
+ * context.  One estimate may be in flight per context (the reference serialises EstimateDepthMap under
+ * a semaphore of count 1, SceneDensify.cpp:3895); contexts on different devices run concurrently.
+ * There is NO CPU fallback: every compute entry fails with HCMVS_ERR_NO_DEVICE when no gfx950 device is
+ * usable.
+ *
+ * Layouts: images/maps row-major; gray f32 in [0,1]; depth f32 (0 = invalid); normal 3 x f32 interleaved,
+ * camera space, unit, facing the camera; conf f32 (score in [0,2] between outer iterations, confidence in
+ * [0,1] after the last one); K, R 3x3 row-major f64, C 3 x f64, x_cam = R (X - C), pixel = K x_cam / z
+ * with pixel centres at integer coordinates (Camera.h:150-151).
+ */
+#ifndef HCMVS_HIP_H
+#define HCMVS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HCMVS_MAX_VIEWS 16 /* source views per estimate (reference cap nMaxViews = 12, DepthMap.cpp:73) */
+
+enum {
+	HCMVS_OK = 0,
+	HCMVS_ERR_NO_DEVICE = 1,   /* no usable gfx950 device / HIP runtime failure at create */
+	HCMVS_ERR_INVALID = 2,     /* bad argument (null pointer, unknown view id, size mismatch, V out of range) */
+	HCMVS_ERR_HIP = 3,         /* a HIP call failed */
+	HCMVS_ERR_TIMEOUT = 4,     /* a sweep worker gave up waiting on its predecessor row (never expected) */
+	HCMVS_ERR_CAPACITY = 5     /* output buffer too small (fuse) */
+};
+
+typedef struct hcmvs_ctx hcmvs_ctx;
+
+/* replaces the OPTDENSE globals read on this path; hcmvs_default_params() fills the reference defaults */
+typedef struct {
+	int32_t adapthalfwin;           /* --n-adapthalfwin 1..7, patch half window (DepthMap.cpp:455-461) */
+	int32_t n_estimation_iters;     /* --n-EstimationIters, inner sweeps (SceneDensify.cpp:949) */
+	int32_t it_external;            /* outer iteration index of this call (SceneDensify.cpp:758) */
+	int32_t n_external_iters;       /* --n-EstimationIters-external; the end pass runs on the last one */
+	int32_t propagate_halfwin;      /* --n-propagatehalfwin (DepthMap.cpp:1071), <= 7 */
+	int32_t propagate_step;         /* --n-propagatestep (DepthMap.cpp:1072), >= 1 */
+	int32_t n_random_iters;         /* nRandomIters (DepthMap.cpp:120) */
+	float ncc_threshold_keep;       /* fNCCThresholdKeep (DepthMap.cpp:117) */
+	float random_depth_ratio;       /* fRandomDepthRatio */
+	float random_angle1_deg;        /* fRandomAngle1Range */
+	float random_angle2_deg;        /* fRandomAngle2Range */
+	float random_smooth_depth;      /* fRandomSmoothDepth */
+	float random_smooth_normal_deg; /* fRandomSmoothNormal */
+	float random_smooth_bonus;      /* fRandomSmoothBonus */
+	float photometric_flow;         /* --n-photometric_flow: every score is scaled by (1-pf) (DepthMap.cpp:892) */
+	uint32_t seed;                  /* counter-based RNG seed; same seed => same maps on any schedule */
+	int32_t median_blur;            /* 1: 3x3 median on the depth map first (SceneDensify.cpp:859) */
+} hcmvs_params;
+
+typedef struct {
+	uint64_t evals;       /* ScorePixel evaluations of the last estimate (each covers all source views) */
+	float ms_score;       /* device time of the init-score pass (HIP events on the context's stream) */
+	float ms_sweeps;      /* device time of all propagate/refine sweeps */
+	float ms_sweep_avg;   /* average duration of one sweep kernel launch */
+	float ms_end;         /* device time of median/end/export kernels */
+	float ms_total;
+	int32_t n_sweeps;
+} hcmvs_stats;
+
+void hcmvs_default_params(hcmvs_params* p);
+
+/* device = HIP device ordinal.  Fails with HCMVS_ERR_NO_DEVICE when it is not a usable GPU. */
+int hcmvs_create(int device, hcmvs_ctx** out);
+void hcmvs_destroy(hcmvs_ctx* ctx);
+const char* hcmvs_last_error(const hcmvs_ctx* ctx);
+/* stream: a hipStream_t owned by the caller (NULL = the context's own stream).  All work is enqueued
+ * on it; the *_device entry points return without synchronising. */
+int hcmvs_set_stream(hcmvs_ctx* ctx, void* stream);
+int hcmvs_synchronize(hcmvs_ctx* ctx);
+
+/* register view `id` (any number < 65536): host buffers are copied to the device.  bgr (B,G,R u8) is
+ * optional: it feeds the gradient map exactly as the reference does (SceneDensify.cpp:586) and the fused
+ * colours; without it the gradient map is taken from round(gray*255). */
+int hcmvs_upload_view(hcmvs_ctx* ctx, uint32_t id, int32_t width, int32_t height, const float* gray,
+                      const uint8_t* bgr_or_null, const double K[9], const double R[9], const double C[3]);
+/* same, but gray/bgr already live in device memory and stay owned by the caller */
+int hcmvs_set_view_device(hcmvs_ctx* ctx, uint32_t id, int32_t width, int32_t height, const float* d_gray,
+                          const uint8_t* d_bgr_or_null, const double K[9], const double R[9], const double C[3]);
+int hcmvs_release_view(hcmvs_ctx* ctx, uint32_t id);
+/* copy the u8 gradient map of a view (SceneDensify.cpp:581-595 InitGraMap) to a host buffer of w*h bytes */
+int hcmvs_get_gradient_map(hcmvs_ctx* ctx, uint32_t id, uint8_t* out);
+
+/* One EstimateDepthMap call for reference view ref_id against src_ids[0..n_src): [median] -> init score
+ * -> n_estimation_iters sweeps -> end pass if it_external == n_external_iters-1.
+ * depth (w*h), normal (w*h*3), conf (w*h) are in/out HOST buffers: on entry the initial maps (zeros +
+ * splatted sparse depths at it_external 0, SceneDensify.cpp:783-808; the previous maps later).  Blocking. */
+int hcmvs_estimate(hcmvs_ctx* ctx, uint32_t ref_id, const uint32_t* src_ids, int32_t n_src,
+                   const hcmvs_params* params, float d_min, float d_max, float* depth, float* normal, float* conf);
+/* the same on DEVICE buffers, asynchronous on the context's stream */
+int hcmvs_estimate_device(hcmvs_ctx* ctx, uint32_t ref_id, const uint32_t* src_ids, int32_t n_src,
+                          const hcmvs_params* params, float d_min, float d_max, float* d_depth, float* d_normal,
+                          float* d_conf);
+/* synchronises, then reports counters/timings of the last estimate */
+int hcmvs_get_stats(hcmvs_ctx* ctx, hcmvs_stats* out);
+
+/* SceneDensify.cpp:783-808: splat n_points sparse world points (xyz f32) seen by view `id` as 5x5 blocks
+ * into host maps depth (w*h) / normal (w*h*3); returns the depth range (min*0.9, max*1.1). Host-side helper. */
+int hcmvs_splat_init(hcmvs_ctx* ctx, uint32_t id, const float* points_xyz, int32_t n_points, float* depth,
+                     float* normal, float* d_min, float* d_max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,180 @@
+/*
+ * oracle/hcmvs_oracle.h -- TEST INFRASTRUCTURE.  CPU restatement of the HC-MVS (OpenMVS v1.1.1 fork)
+ * PatchMatch depth-map estimation, geometric filter and fusion path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library; the
+ * product (hc-mvs_amd/, include/) never includes, links or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path and cannot be
+ * built in this environment (needs OpenCV, Eigen, Boost, CGAL), so this
+ * restatement is checked against hand-derived known-answer vectors only (tests/test_oracle_*.py).
+ *
+ * Citation shorthand (all under /root/reference/frame_main/libs/):
+ *   DM.cpp = MVS/DepthMap.cpp, DM.h = MVS/DepthMap.h, SD.cpp = MVS/SceneDensify.cpp,
+ *   Util.inl / Types.h / Types.inl / Random.h = Common/...
+ *
+ * "Defined subset" (SURVEY.md Appendix A): opticalflow=0, use-semantic=0, viewspread=0, nOptimize=0;
+ * photometric_flow is honoured as the plain (1-pf) scale it amounts to (DM.cpp:892,931).
+ */
+#ifndef HCMVS_ORACLE_H
+#define HCMVS_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HCOR_MAX_VIEWS 16
+#define HCOR_MAX_TAPS 64     /* nTexels, DM.h:358 */
+#define HCOR_HALF_WINDOW 7   /* nSizeHalfWindow, DM.h:354 */
+#define HCOR_MAX_NEIGHBORS 32
+
+enum { HCOR_ARITH_REFERENCE = 0, HCOR_ARITH_DEVICE = 1 };
+enum { HCOR_ORDER_ZIGZAG = 0, HCOR_ORDER_ROWS = 1 };
+
+/* one calibrated view: x_cam = R (X - C), pixel = K x_cam / z, pixel centres at integers (Camera.h) */
+typedef struct {
+	int width, height;
+	const float* gray;   /* H*W row-major, [0,1] (Types.inl:2354-2400 toGray) */
+	const uint8_t* bgr;  /* optional H*W*3 (B,G,R) working-resolution colour image, may be NULL */
+	double K[9], R[9], C[3];
+} hcor_view;
+
+/* replaces the OPTDENSE globals (DM.cpp:67-143) for this path */
+typedef struct {
+	int adapthalfwin;           /* --n-adapthalfwin, <= 7 (DM.cpp:455-461) */
+	int n_estimation_iters;     /* --n-EstimationIters: inner sweeps (SD.cpp:949) */
+	int it_external;            /* outer iteration this call is (SD.cpp:758) */
+	int n_external_iters;       /* --n-EstimationIters-external: pass C runs when it_external == n-1 */
+	int propagate_halfwin;      /* --n-propagatehalfwin (DM.cpp:1071) */
+	int propagate_step;         /* --n-propagatestep (DM.cpp:1072) */
+	int n_random_iters;         /* nRandomIters = 6 (DM.cpp:120) */
+	float ncc_threshold_keep;   /* fNCCThresholdKeep = 0.55 (DM.cpp:117) */
+	float random_depth_ratio;   /* fRandomDepthRatio = 0.003 */
+	float random_angle1_deg;    /* fRandomAngle1Range = 16 */
+	float random_angle2_deg;    /* fRandomAngle2Range = 10 */
+	float random_smooth_depth;  /* fRandomSmoothDepth = 0.02 */
+	float random_smooth_normal_deg; /* fRandomSmoothNormal = 13 */
+	float random_smooth_bonus;  /* fRandomSmoothBonus = 0.93 */
+	float photometric_flow;     /* --n-photometric_flow: scores scaled by (1-pf) (DM.cpp:892) */
+	uint32_t seed;              /* counter-based RNG seed (replaces mt19937, Random.h:102) */
+	int arith_mode;             /* HCOR_ARITH_* */
+	int order;                  /* HCOR_ORDER_*: pixel visiting order of the sweeps */
+	int n_threads;              /* zig-zag band height = max(64, 8*n_threads) (SD.cpp:835); ROWS order
+	                               uses n_threads OpenMP threads and gives the same result for any count */
+	int median_blur;            /* 1 = cv::medianBlur(depth,3) at the start of the call (SD.cpp:859) */
+} hcor_params;
+
+void hcor_default_params(hcor_params* p);
+
+/* ---- small pieces, exposed for known-answer tests ------------------------------------------- */
+
+/* DM.cpp:354-381 MapMatrix2ZigzagIdx (no mask). coords_xy: 2*w*h uint16 (x,y pairs). returns count */
+int hcor_zigzag_coords(int w, int h, int raw_stride, uint16_t* coords_xy);
+
+/* counter-based RNG: uniform u32 for (seed, pixel index, stream, counter) */
+uint32_t hcor_rand_u32(uint32_t seed, uint32_t pix, uint32_t stream, uint32_t ctr);
+
+/* OpenCV-compatible helpers restated from their published algorithms (OpenCV itself is absent):
+ * BGR->gray 8u fixed point, Sobel 3x3 (BORDER_REFLECT_101) + convertScaleAbs + addWeighted(.5,.5)
+ * (SD.cpp:581-595 InitGraMap) and 3x3 median with BORDER_REPLICATE (SD.cpp:859). */
+void hcor_bgr2gray_u8(const uint8_t* bgr, int w, int h, uint8_t* gray);
+void hcor_gray_f32_to_u8(const float* gray, int w, int h, uint8_t* out);
+void hcor_gradient_map(const uint8_t* gray, int w, int h, uint8_t* gra);
+void hcor_median3(const float* in, int w, int h, float* out);
+
+/* SD.cpp:783-808: splat sparse points (world XYZ, n of them) as 5x5 blocks; returns dMin/dMax */
+void hcor_splat_init(const hcor_view* ref, const float* points_xyz, int n_points, float* depth,
+                     float* normal, float* d_min, float* d_max);
+
+/* portable math entry points (tests compare them with libm) */
+float hcor_pm_expf(float x);
+float hcor_pm_sinf(float x);
+float hcor_pm_cosf(float x);
+float hcor_pm_acosf(float x);
+float hcor_pm_atan2f(float y, float x);
+
+/* DM.cpp:450-519 FillPixelPatch for pixel (x,y): fills weight[n], temp_weight[n] (n = (a+1)^2 taps),
+ * returns the number of taps; *sum_weights, *norm_sq0 as cached by the reference.  n_src only selects the
+ * device-mode summation layout (segments per view) */
+int hcor_fill_patch(const hcor_view* ref, const uint8_t* gra, const hcor_params* p, int n_src, int x, int y,
+                    float* weight, float* temp_weight, float* sum_weights, float* norm_sq0);
+
+/* DM.cpp:522-616 + 890-893 ScorePixelImage for one source view, no smoothness neighbours */
+float hcor_score_view(const hcor_view* ref, const hcor_view* src, const uint8_t* gra,
+                      const hcor_params* p, int x, int y, float depth, const float normal[3]);
+
+/* DM.cpp:987-1046 ScorePixel over all views, no smoothness neighbours */
+float hcor_score_pixel(const hcor_view* ref, const hcor_view* srcs, int n_src, const uint8_t* gra,
+                       const hcor_params* p, int x, int y, float depth, const float normal[3]);
+
+/* Util.inl:614-626 */
+void hcor_normal2dir(const float n[3], float p[2], int arith_mode);
+void hcor_dir2normal(const float p[2], float n[3], int arith_mode);
+/* DM.h:629-634 CorrectNormal for the pixel ray X0 = ((x-cx)/fx,(y-cy)/fy,1) */
+void hcor_correct_normal(const hcor_view* ref, int x, int y, float n[3], int arith_mode);
+/* DM.cpp:1671-1726 InterpolatePixel: depth at (x,y) of the plane through neighbour (nx,ny,depth,normal) */
+float hcor_interpolate_pixel(const hcor_view* ref, int x, int y, int nx, int ny, float depth,
+                             const float normal[3], float d_min, float d_max);
+
+/* ---- the path -------------------------------------------------------------------------------- */
+
+/* SD.cpp:758-1072 EstimateDepthMap for one reference view (defined subset).
+ * depth/normal/conf: H*W, H*W*3, H*W in/out.  gra: H*W gradient map (SD.cpp:581-595).
+ * Runs: [median blur] -> pass A (SD.cpp:649-675) -> n_estimation_iters sweeps (SD.cpp:677-686,
+ * DM.cpp:1050-1501) -> pass C when it_external == n_external_iters-1 (SD.cpp:688-744).
+ * eval_count (optional): receives the number of ScorePixel evaluations performed. */
+int hcor_estimate(const hcor_view* ref, const hcor_view* srcs, int n_src, const uint8_t* gra,
+                  const hcor_params* p, float d_min, float d_max, float* depth, float* normal,
+                  float* conf, uint64_t* eval_count);
+
+/* the three passes individually (same arguments), for per-pass parity tests */
+void hcor_pass_score(const hcor_view* ref, const hcor_view* srcs, int n_src, const uint8_t* gra,
+                     const hcor_params* p, float d_min, float d_max, float* depth, float* normal,
+                     float* conf, uint64_t* eval_count);
+void hcor_pass_sweep(const hcor_view* ref, const hcor_view* srcs, int n_src, const uint8_t* gra,
+                     const hcor_params* p, int iter, float d_min, float d_max, float* depth,
+                     float* normal, float* conf, uint64_t* eval_count);
+void hcor_pass_end(const hcor_params* p, int w, int h, float* depth, float* normal, float* conf);
+
+/* ---- filter and fuse (hcmvs_fuse.c) ----------------------------------------------------------- */
+
+typedef struct {
+	int width, height;
+	double K[9], R[9], C[3];
+	float* depth;        /* H*W, mutated by fusion (SD.cpp:3448-3449) */
+	const float* normal; /* H*W*3 camera space, may be NULL */
+	const float* conf;   /* H*W */
+	const uint8_t* bgr;  /* H*W*3 or NULL */
+	float d_min, d_max;
+	int n_neighbors;
+	const uint32_t* neighbors; /* image ids, decreasing importance */
+} hcor_depthmap;
+
+/* SD.cpp:3006-3259 FilterDepthMap(bAdjust).  neighbor_ids index into maps[].  out_depth/out_conf: H*W.
+ * returns 0 if too few neighbours (SD.cpp:3016-3019), 1 otherwise; n_discarded and n_processed as logged */
+int hcor_filter_depthmap(const hcor_depthmap* maps, uint32_t ref_id, const uint32_t* neighbor_ids,
+                         int n_neighbors, int adjust, int n_min_views, int n_min_views_adjust,
+                         float depth_diff_threshold, float* out_depth, float* out_conf,
+                         uint64_t* n_processed, uint64_t* n_discarded);
+
+typedef struct {
+	uint64_t n_points, capacity;
+	float* xyz;       /* capacity*3 */
+	float* normal;    /* capacity*3 or NULL */
+	uint8_t* bgr;     /* capacity*3 or NULL (stored B,G,R like Interface.h:369) */
+	uint32_t* n_views;/* capacity: number of views merged into each point */
+	uint64_t n_depths;/* valid depths visited (SD.cpp:3359) */
+} hcor_cloud;
+
+/* SD.cpp:3265-3495 FuseDepthMaps.  order: image ids sorted by #neighbours descending (SD.cpp:3302;
+ * ties broken by ascending id here -- std::sort leaves them unspecified).  returns 0 ok, 1 = capacity */
+int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, int n_order,
+                        int n_min_views_fuse, float depth_diff_threshold, float normal_diff_deg,
+                        float depthweight, float normalweight, hcor_cloud* cloud);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

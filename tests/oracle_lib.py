@@ -1,0 +1,152 @@
+"""ctypes binding of the CPU oracle (oracle/libhcmvs_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libhcmvs_oracle.so")
+
+ARITH_REFERENCE, ARITH_DEVICE = 0, 1
+ORDER_ZIGZAG, ORDER_ROWS = 0, 1
+
+
+class View(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("gray", C.POINTER(C.c_float)),
+                ("bgr", C.POINTER(C.c_uint8)), ("K", C.c_double * 9), ("R", C.c_double * 9), ("C", C.c_double * 3)]
+
+
+class Params(C.Structure):
+    _fields_ = [("adapthalfwin", C.c_int), ("n_estimation_iters", C.c_int), ("it_external", C.c_int),
+                ("n_external_iters", C.c_int), ("propagate_halfwin", C.c_int), ("propagate_step", C.c_int),
+                ("n_random_iters", C.c_int), ("ncc_threshold_keep", C.c_float), ("random_depth_ratio", C.c_float),
+                ("random_angle1_deg", C.c_float), ("random_angle2_deg", C.c_float),
+                ("random_smooth_depth", C.c_float), ("random_smooth_normal_deg", C.c_float),
+                ("random_smooth_bonus", C.c_float), ("photometric_flow", C.c_float), ("seed", C.c_uint32),
+                ("arith_mode", C.c_int), ("order", C.c_int), ("n_threads", C.c_int), ("median_blur", C.c_int)]
+
+
+_lib = None
+
+
+def build():
+    if not os.path.exists(LIB_PATH) or any(
+            os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
+            for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "libhcmvs_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        L = _lib
+        fp = C.POINTER(C.c_float); u8p = C.POINTER(C.c_uint8)
+        L.hcor_default_params.argtypes = [C.POINTER(Params)]
+        L.hcor_zigzag_coords.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16)]
+        L.hcor_zigzag_coords.restype = C.c_int
+        L.hcor_rand_u32.argtypes = [C.c_uint32] * 4
+        L.hcor_rand_u32.restype = C.c_uint32
+        for n in ("expf", "sinf", "cosf", "acosf"):
+            f = getattr(L, "hcor_pm_" + n); f.argtypes = [C.c_float]; f.restype = C.c_float
+        L.hcor_pm_atan2f.argtypes = [C.c_float, C.c_float]; L.hcor_pm_atan2f.restype = C.c_float
+        L.hcor_bgr2gray_u8.argtypes = [u8p, C.c_int, C.c_int, u8p]
+        L.hcor_gray_f32_to_u8.argtypes = [fp, C.c_int, C.c_int, u8p]
+        L.hcor_gradient_map.argtypes = [u8p, C.c_int, C.c_int, u8p]
+        L.hcor_median3.argtypes = [fp, C.c_int, C.c_int, fp]
+        L.hcor_splat_init.argtypes = [C.POINTER(View), fp, C.c_int, fp, fp, fp, fp]
+        L.hcor_fill_patch.argtypes = [C.POINTER(View), u8p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, fp, fp, fp, fp]
+        L.hcor_fill_patch.restype = C.c_int
+        L.hcor_score_view.argtypes = [C.POINTER(View), C.POINTER(View), u8p, C.POINTER(Params), C.c_int, C.c_int,
+                                      C.c_float, fp]
+        L.hcor_score_view.restype = C.c_float
+        L.hcor_score_pixel.argtypes = [C.POINTER(View), C.POINTER(View), C.c_int, u8p, C.POINTER(Params), C.c_int,
+                                       C.c_int, C.c_float, fp]
+        L.hcor_score_pixel.restype = C.c_float
+        L.hcor_normal2dir.argtypes = [fp, fp, C.c_int]
+        L.hcor_dir2normal.argtypes = [fp, fp, C.c_int]
+        L.hcor_correct_normal.argtypes = [C.POINTER(View), C.c_int, C.c_int, fp, C.c_int]
+        L.hcor_interpolate_pixel.argtypes = [C.POINTER(View), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fp,
+                                             C.c_float, C.c_float]
+        L.hcor_interpolate_pixel.restype = C.c_float
+        est_args = [C.POINTER(View), C.POINTER(View), C.c_int, u8p, C.POINTER(Params), C.c_float, C.c_float, fp, fp,
+                    fp, C.POINTER(C.c_uint64)]
+        L.hcor_estimate.argtypes = est_args; L.hcor_estimate.restype = C.c_int
+        L.hcor_pass_score.argtypes = est_args
+        L.hcor_pass_sweep.argtypes = est_args[:5] + [C.c_int] + est_args[5:]
+        L.hcor_pass_end.argtypes = [C.POINTER(Params), C.c_int, C.c_int, fp, fp, fp]
+    return _lib
+
+
+def fptr(a):
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def u8ptr(a):
+    assert a.dtype == np.uint8 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def default_params(**kw):
+    p = Params()
+    lib().hcor_default_params(C.byref(p))
+    for k, v in kw.items():
+        assert hasattr(p, k), k
+        setattr(p, k, v)
+    return p
+
+
+def make_view(v):
+    """v: dict with gray (h,w) f32, K,R (3,3), C (3).  Keeps references alive on the struct."""
+    s = View()
+    g = np.ascontiguousarray(v["gray"], np.float32)
+    s.width, s.height = g.shape[1], g.shape[0]
+    s.gray = fptr(g)
+    s._keep = [g]
+    if v.get("bgr") is not None:
+        b = np.ascontiguousarray(v["bgr"], np.uint8); s.bgr = u8ptr(b); s._keep.append(b)
+    s.K[:] = list(np.asarray(v["K"], np.float64).ravel())
+    s.R[:] = list(np.asarray(v["R"], np.float64).ravel())
+    s.C[:] = list(np.asarray(v["C"], np.float64).ravel())
+    return s
+
+
+def make_view_array(vs):
+    arr = (View * len(vs))()
+    keep = []
+    for i, v in enumerate(vs):
+        s = make_view(v)
+        keep.append(s._keep)
+        C.memmove(C.byref(arr[i]), C.byref(s), C.sizeof(View))
+    arr._keep = keep
+    return arr
+
+
+def gradient_map(gray_f32):
+    L = lib()
+    h, w = gray_f32.shape
+    g8 = np.empty((h, w), np.uint8); gra = np.empty((h, w), np.uint8)
+    L.hcor_gray_f32_to_u8(fptr(np.ascontiguousarray(gray_f32)), w, h, u8ptr(g8))
+    L.hcor_gradient_map(u8ptr(g8), w, h, u8ptr(gra))
+    return gra
+
+
+def estimate(views, params, d_min, d_max, depth, normal, gra=None, passes="all", iter_index=0):
+    """Runs the oracle on views[0] (ref) vs views[1:].  depth (h,w), normal (h,w,3) are copied.
+    Returns depth, normal, conf, evals."""
+    L = lib()
+    ref = make_view(views[0]); srcs = make_view_array(views[1:])
+    h, w = views[0]["gray"].shape
+    if gra is None:
+        gra = gradient_map(views[0]["gray"])
+    d = np.ascontiguousarray(depth, np.float32).copy()
+    n = np.ascontiguousarray(normal, np.float32).copy()
+    c = np.zeros((h, w), np.float32)
+    ev = C.c_uint64(0)
+    rc = L.hcor_estimate(C.byref(ref), srcs, len(views) - 1, u8ptr(gra), C.byref(params), d_min, d_max, fptr(d),
+                         fptr(n), fptr(c), C.byref(ev))
+    assert rc == 0
+    return d, n, c, ev.value

@@ -1,0 +1,116 @@
+"""GPU parity of the estimation path (pass A, sweeps, end pass) against the CPU oracle, through the C-ABI.
+
+The oracle runs in its device-association arithmetic (same IEEE operation sequence as the kernels), so the
+comparison is BIT-EXACT for every map, including all data-dependent control flow (propagation decisions,
+random refinement, the two-best-views selection) and the cross-wave hand-off protocol of the sweeps.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+binding = importlib.import_module("hc-mvs_amd.binding")
+synth = importlib.import_module("hc-mvs_amd.synth")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = binding.Context(0)
+    yield c
+    c.close()
+
+
+def _scene(w, h, f, n_src, seed, n_pts=80):
+    views = synth.make_views(w, h, f, n_src, seed=seed)
+    pts = synth.sparse_points(views, n_pts)
+    return views, pts
+
+
+def _upload(ctx, views):
+    for i, v in enumerate(views):
+        ctx.upload_view(i, v["gray"], v["K"], v["R"], v["C"])
+
+
+def _params(**kw):
+    pg = binding.default_params(**kw)
+    po = O.default_params(arith_mode=O.ARITH_DEVICE, order=O.ORDER_ROWS, n_threads=8, **kw)
+    return pg, po
+
+
+def _compare(got, want):
+    names = ("depth", "normal", "conf")
+    for g, w, n in zip(got, want, names):
+        if not np.array_equal(g, w):
+            bad = np.argwhere(g != w)
+            raise AssertionError("%s differs at %d elements, first %s: gpu %r oracle %r" %
+                                 (n, len(bad), bad[0], g[tuple(bad[0])], w[tuple(bad[0])]))
+
+
+def test_gradient_map_matches_oracle(ctx):
+    views, _ = _scene(96, 72, 90.0, 1, seed=4)
+    _upload(ctx, views)
+    assert np.array_equal(ctx.gradient_map(0), O.gradient_map(views[0]["gray"]))
+
+
+@pytest.mark.parametrize("n_src,ahw", [(1, 6), (2, 5), (3, 6), (4, 7), (5, 6), (8, 6), (8, 7), (9, 5)])
+def test_estimate_bit_exact(ctx, n_src, ahw):
+    views, pts = _scene(112, 88, 100.0, n_src, seed=10 + n_src)
+    _upload(ctx, views)
+    d0, n0, dmin, dmax = ctx.splat_init(0, pts)
+    pg, po = _params(adapthalfwin=ahw, n_estimation_iters=3, seed=77 + n_src)
+    got = ctx.estimate(0, list(range(1, n_src + 1)), pg, dmin, dmax, d0, n0)
+    st = ctx.stats()
+    do, no, co, ev = O.estimate(views, po, dmin, dmax, d0, n0)
+    assert st.evals == ev
+    _compare(got, (do, no, co))
+    assert (got[0] > 0).mean() > 0.3
+
+
+def test_outer_iterations_cross_pattern(ctx):
+    """it_external >= 1 uses the cross propagation pattern (DepthMap.cpp:1064-1274) and no end pass until
+    the last outer iteration; maps are handed from one call to the next."""
+    views, pts = _scene(120, 96, 110.0, 3, seed=21)
+    _upload(ctx, views)
+    d0, n0, dmin, dmax = ctx.splat_init(0, pts)
+    g = (d0, n0, None)
+    o = (d0, n0, None)
+    for it in range(3):
+        pg, po = _params(adapthalfwin=6, n_estimation_iters=2, it_external=it, n_external_iters=3,
+                         propagate_halfwin=5, propagate_step=2)
+        g = ctx.estimate(0, [1, 2, 3], pg, dmin, dmax, g[0], g[1], g[2])
+        od, on, oc, _ = O.estimate(views, po, dmin, dmax, o[0], o[1])
+        o = (od, on, oc)
+        _compare(g, o)
+    assert (g[0] > 0).mean() > 0.3
+
+
+def test_host_and_device_paths_agree(ctx):
+    torch = pytest.importorskip("torch")
+    views, pts = _scene(96, 80, 90.0, 2, seed=5)
+    _upload(ctx, views)
+    d0, n0, dmin, dmax = ctx.splat_init(0, pts)
+    pg, _ = _params(adapthalfwin=6, n_estimation_iters=2)
+    want = ctx.estimate(0, [1, 2], pg, dmin, dmax, d0, n0)
+    dev = torch.device("cuda:0")
+    td = torch.from_numpy(d0).to(dev); tn = torch.from_numpy(n0).to(dev); tc = torch.zeros_like(td)
+    torch.cuda.synchronize()
+    ctx.estimate_device(0, [1, 2], pg, dmin, dmax, td.data_ptr(), tn.data_ptr(), tc.data_ptr())
+    ctx.synchronize()
+    _compare((td.cpu().numpy(), tn.cpu().numpy(), tc.cpu().numpy()), want)
+
+
+def test_errors_are_reported(ctx):
+    views, pts = _scene(96, 80, 90.0, 1, seed=6)
+    _upload(ctx, views)
+    d0, n0, dmin, dmax = ctx.splat_init(0, pts)
+    pg, _ = _params()
+    with pytest.raises(binding.HcmvsError) as e:
+        ctx.estimate(0, [99], pg, dmin, dmax, d0, n0)
+    assert e.value.code == binding.ERR_INVALID and "99" in str(e.value)
+    pg.adapthalfwin = 9
+    with pytest.raises(binding.HcmvsError):
+        ctx.estimate(0, [1], pg, dmin, dmax, d0, n0)
