@@ -26,7 +26,7 @@ class Params(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("evals", C.c_uint64), ("ms_score", C.c_float), ("ms_sweeps", C.c_float),
+    _fields_ = [("evals", C.c_uint64), ("evals_issued", C.c_uint64), ("tap_evals", C.c_uint64), ("ms_score", C.c_float), ("ms_sweeps", C.c_float),
                 ("ms_sweep_avg", C.c_float), ("ms_end", C.c_float), ("ms_total", C.c_float),
                 ("n_sweeps", C.c_int32)]
 
@@ -52,6 +52,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libhcmvs_hip.so is not built (run __graft_entry__.build() or make -C hc-mvs_amd/csrc); "
                               "there is no CPU fallback")
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; two HIP runtimes in one process cannot both
+        # open the device.  Importing torch first makes the loader resolve our NEEDED libamdhip64.so.7 to the
+        # copy that is already mapped, so the process holds exactly one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, fp, u8p, dp = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_double)
         u32p = C.POINTER(C.c_uint32)

@@ -55,7 +55,8 @@ struct hcmvs_ctx {
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	int lastSweeps = 0;
 	bool haveStats = false;
-	int sweepLag = 2;
+	int sweepLag = 1;
+	int wavesPerRow = 2;
 };
 
 static int fail(hcmvs_ctx* c, int code, const char* fmt, ...) {
@@ -107,6 +108,10 @@ static void mat3_inv(const double* m, double* r) {
 }
 static inline float fd2r(float d) { return d * (3.14159274101257324f / 180.f); }
 
+#ifdef HCMVS_STAMPS
+namespace hcmvs { void debug_read_stamps(unsigned long long* out, int reset); }
+#endif
+
 extern "C" {
 
 void hcmvs_default_params(hcmvs_params* p) {
@@ -146,12 +151,14 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 	c->stream = c->ownStream;
 	for (auto& e : c->ev)
 		if (hipEventCreate(&e) != hipSuccess) { delete c; return HCMVS_ERR_NO_DEVICE; }
-	if (hipMalloc(&c->dViews, sizeof(DevView) * kMaxViews) != hipSuccess || hipMalloc(&c->evals, 8) != hipSuccess) {
+	if (hipMalloc(&c->dViews, sizeof(DevView) * kMaxViews) != hipSuccess || hipMalloc(&c->evals, 32) != hipSuccess) {
 		delete c;
 		return HCMVS_ERR_NO_DEVICE;
 	}
 	const char* lag = getenv("HCMVS_SWEEP_LAG");
 	if (lag && atoi(lag) >= 1) c->sweepLag = atoi(lag);
+	const char* wpr = getenv("HCMVS_WAVES_PER_ROW"); // tuning knob: 1, 2, 3, 4, 6 or 8 waves cooperate on one image row
+	if (wpr && (atoi(wpr) == 1 || atoi(wpr) == 2 || atoi(wpr) == 3 || atoi(wpr) == 4 || atoi(wpr) == 6 || atoi(wpr) == 8)) c->wavesPerRow = atoi(wpr);
 	*out = c;
 	return HCMVS_OK;
 }
@@ -309,8 +316,10 @@ int hcmvs_estimate_device(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* src_ids
 	k.adapthalfwin = p->adapthalfwin; k.nRandomIters = p->n_random_iters; k.itExternal = p->it_external;
 	k.propHalfwin = p->propagate_halfwin; k.propStep = p->propagate_step;
 	k.ref = ref.gray; k.gra = ref.gra; k.views = c->dViews;
-	mat3_inv(ref.K, k.Hr);
-	k.fx = ref.K[0]; k.fy = ref.K[4]; k.cx = ref.K[2]; k.cy = ref.K[5];
+	double Hr[9];
+	mat3_inv(ref.K, Hr);
+	for (int i = 0; i < 9; ++i) k.Hr[i] = (float)Hr[i];
+	k.ifx = 1.0 / ref.K[0]; k.ify = 1.0 / ref.K[4]; k.cx = ref.K[2]; k.cy = ref.K[5];
 	DevView* hv = c->hViews;
 	memset(hv, 0, sizeof c->hViews);
 	for (int v = 0; v < n_src; ++v) {
@@ -321,8 +330,10 @@ int hcmvs_estimate_device(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* src_ids
 		mat3_mul(s.K, s.R, KR);
 		mat3_mul_bt(KR, ref.R, Hl);
 		const double dC[3] = {ref.C[0] - s.C[0], ref.C[1] - s.C[1], ref.C[2] - s.C[2]};
-		for (int i = 0; i < 3; ++i) hv[v].Hm[i] = KR[i * 3] * dC[0] + KR[i * 3 + 1] * dC[1] + KR[i * 3 + 2] * dC[2];
-		mat3_mul(Hl, k.Hr, hv[v].A);
+		double A[9];
+		for (int i = 0; i < 3; ++i) hv[v].Hm[i] = (float)(KR[i * 3] * dC[0] + KR[i * 3 + 1] * dC[1] + KR[i * 3 + 2] * dC[2]);
+		mat3_mul(Hl, Hr, A);
+		for (int i = 0; i < 9; ++i) hv[v].A[i] = (float)A[i];
 		hv[v].img = s.gray; hv[v].w = s.w; hv[v].h = s.h;
 	}
 	k.dMin = d_min; k.dMax = d_max; k.dMinSqr = sqrtf(d_min); k.dMaxSqr = sqrtf(d_max);
@@ -345,7 +356,7 @@ int hcmvs_estimate_device(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* src_ids
 	hipStream_t s = c->stream;
 	// the previous call's copy of the view table must not be overwritten while in use: same stream => ordered
 	HIPCHK(c, hipMemcpyAsync(c->dViews, hv, sizeof(DevView) * n_src, hipMemcpyHostToDevice, s));
-	HIPCHK(c, hipMemsetAsync(c->evals, 0, 8, s));
+	HIPCHK(c, hipMemsetAsync(c->evals, 0, 32, s));
 
 	HIPCHK(c, hipEventRecord(c->ev[0], s));
 	const float* depthIn = d_depth;
@@ -360,7 +371,7 @@ int hcmvs_estimate_device(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* src_ids
 	sy.ticket = c->sync; sy.error = c->sync + 1; sy.progress = c->sync + 16; sy.evals = c->evals;
 	for (int iter = 0; iter < p->n_estimation_iters; ++iter) {
 		HIPCHK(c, hipMemsetAsync(c->sync, 0, (16 + (size_t)rows * kProgressStride) * sizeof(int32_t), s));
-		launch_sweep(k, sy, iter, c->sweepLag, s);
+		launch_sweep(k, sy, iter, c->sweepLag, c->wavesPerRow, s);
 	}
 	HIPCHK(c, hipEventRecord(c->ev[2], s));
 	launch_end_pass(k, p->it_external == p->n_external_iters - 1 ? 1 : 0, d_depth, d_normal, d_conf, s);
@@ -377,9 +388,11 @@ int hcmvs_get_stats(hcmvs_ctx* c, hcmvs_stats* out) {
 	if (!c->haveStats) return fail(c, HCMVS_ERR_INVALID, "get_stats: no estimate has run");
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
-	unsigned long long ev = 0;
-	HIPCHK(c, hipMemcpy(&ev, c->evals, 8, hipMemcpyDeviceToHost));
-	out->evals = ev;
+	unsigned long long ev[4] = {0, 0, 0, 0};
+	HIPCHK(c, hipMemcpy(ev, c->evals, 32, hipMemcpyDeviceToHost));
+	out->evals = ev[0];
+	out->evals_issued = ev[1];
+	out->tap_evals = ev[2];
 	HIPCHK(c, hipEventElapsedTime(&out->ms_score, c->ev[0], c->ev[1]));
 	HIPCHK(c, hipEventElapsedTime(&out->ms_sweeps, c->ev[1], c->ev[2]));
 	HIPCHK(c, hipEventElapsedTime(&out->ms_end, c->ev[2], c->ev[3]));
@@ -455,5 +468,15 @@ int hcmvs_splat_init(hcmvs_ctx* c, uint32_t id, const float* pts, int32_t n, flo
 	*d_max = dmax * 1.1f;
 	return HCMVS_OK;
 }
+
+#ifdef HCMVS_STAMPS
+// diagnostic build only: per-phase cycle totals of the sweep workers (not part of the public header)
+int hcmvs_debug_stamps(hcmvs_ctx* c, unsigned long long* out, int reset) {
+	if (!c || !out) return HCMVS_ERR_INVALID;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	hcmvs::debug_read_stamps(out, reset);
+	return HCMVS_OK;
+}
+#endif
 
 } // extern "C"

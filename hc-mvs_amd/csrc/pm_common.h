@@ -18,8 +18,8 @@ constexpr int kProgressStride = 16; // ints between the progress words of consec
 struct DevView {
 	const float* img;
 	int32_t w, h;
-	double A[9];  // Hl * Hr = Kj Rj Ri^T Ki^-1
-	double Hm[3]; // Kj Rj (Ci - Cj)
+	float A[9];  // Hl * Hr = Kj Rj Ri^T Ki^-1 (computed in double on the host, held as float)
+	float Hm[3]; // Kj Rj (Ci - Cj)
 };
 
 // uniform constants of one EstimateDepthMap call (DepthMap.cpp:386-439 DepthEstimator ctor)
@@ -29,8 +29,8 @@ struct EstConst {
 	const float* ref;
 	const uint8_t* gra;
 	const DevView* views;
-	double Hr[9];           // Ki^-1
-	double fx, fy, cx, cy;  // reference intrinsics (Camera.h:299-312)
+	float Hr[9];            // Ki^-1 (double on the host, held as float)
+	double cx, cy, ifx, ify; // reference principal point and 1/focal (Camera.h:299-312)
 	float dMin, dMax, dMinSqr, dMaxSqr;
 	float smoothBonusDepth, smoothBonusNormal, smoothSigmaDepth, smoothSigmaNormal;
 	float angle1Range, angle2Range;
@@ -46,7 +46,7 @@ struct SweepSync {
 	int32_t* progress; // [rows * kProgressStride] pixels finished per logical row
 	int32_t* ticket;   // next logical row to hand out
 	int32_t* error;    // set non-zero when a worker times out
-	unsigned long long* evals;
+	unsigned long long* evals;  // [0] ScorePixel calls of the sequential algorithm, [1] evaluations issued (incl. speculative), [2] patch taps of [0]
 };
 
 // launch wrappers (pm_kernels.hip)
@@ -56,7 +56,7 @@ void launch_gradient_map(const uint8_t* g8, uint8_t* gra, int W, int H, hipStrea
 void launch_median3(const float* in, float* out, int W, int H, hipStream_t s);
 void launch_score_pass(const EstConst& c, const float* depthIn, const float* normalIn, unsigned long long* evals,
                        hipStream_t s);
-void launch_sweep(const EstConst& c, const SweepSync& sync, int iter, int lag, hipStream_t s);
+void launch_sweep(const EstConst& c, const SweepSync& sync, int iter, int lag, int wavesPerRow, hipStream_t s);
 void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s);
 
 } // namespace hcmvs

@@ -32,6 +32,22 @@
 namespace hcmvs {
 
 #define HC_SQ(x) ((x) * (x))
+
+// diagnostic build only (-DHCMVS_STAMPS): per-phase cycle accounting of wave 0 of every row worker
+#ifdef HCMVS_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; }
+#define STAMP_ARGS , unsigned long long& st_last, unsigned long long (&st_acc)[12]
+#define STAMP_PASS , st_last, st_acc
+#define STAMP_FLUSH if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[i_], st_acc[i_]); }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_ARGS
+#define STAMP_PASS
+#define STAMP_FLUSH
+#endif
 #define HC_SCOPE __HIP_MEMORY_SCOPE_AGENT
 
 // ------------------------------------------------------------------------------------------------------
@@ -41,13 +57,15 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
 	h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
 	return h;
 }
-// counter-based RNG keyed by (seed, pixel, pass, draw): replaces the per-thread mt19937 (Random.h:102)
-__device__ __forceinline__ float rand_unit(uint32_t seed, uint32_t pix, uint32_t stream, uint32_t ctr) {
+// counter-based RNG keyed by (seed, pixel, pass, draw): replaces the per-thread mt19937 (Random.h:102).
+// rand_key() hashes the per-pixel part once; rand_unit() finishes one draw.
+__device__ __forceinline__ uint32_t rand_key(uint32_t seed, uint32_t pix, uint32_t stream) {
 	uint32_t h = fmix32(seed ^ 0x9e3779b9u);
 	h = fmix32(h ^ (pix * 0x9e3779b1u));
-	h = fmix32(h ^ (stream * 0x85ebca77u));
-	h = fmix32(h ^ (ctr * 0xc2b2ae3du));
-	return (float)h / 4294967296.0f; // (float)max() == 2^32 (Random.h:113-115)
+	return fmix32(h ^ (stream * 0x85ebca77u));
+}
+__device__ __forceinline__ float rand_unit(uint32_t key, uint32_t ctr) {
+	return (float)fmix32(key ^ (ctr * 0xc2b2ae3du)) / 4294967296.0f; // (float)max() == 2^32 (Random.h:113-115)
 }
 __device__ __forceinline__ float fd2r(float d) { return d * (3.14159274101257324f / 180.f); } // Types.h:566
 
@@ -82,24 +100,53 @@ __device__ __forceinline__ float rlf(float v, int lane) { // value of a (wave-un
 }
 __device__ __forceinline__ int rli(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-template <int S>
-__device__ __forceinline__ float group_sum(float v) { // xor butterfly inside a view group
-#pragma unroll
-	for (int step = 1; step < S; step <<= 1) v = v + __shfl_xor(v, step, 64);
-	return v;
+// value of lane (l ^ STEP).  Steps 1,2 are quad permutes; 4 and 8 use the DPP half-row / row mirrors, which
+// coincide with the xor partner's VALUE because the butterflies below make every 4- resp. 8-lane block
+// uniform before those steps; 16 is a swizzle inside 32 lanes; 32 goes through the LDS crossbar.
+template <int STEP>
+__device__ __forceinline__ float lane_xor(float v) {
+	if (STEP == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)); // quad_perm [1,0,3,2]
+	if (STEP == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)); // quad_perm [2,3,0,1]
+	if (STEP == 4) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)); // row_half_mirror
+	if (STEP == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)); // row_mirror
+	if (STEP == 16) return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));                    // xor 0x10
+	return __shfl_xor(v, 32, 64);
+}
+template <int S, int STEP = 1>
+__device__ __forceinline__ float group_sum(float v) { // xor butterfly inside a view group of S lanes
+	if constexpr (STEP < S) {
+		v = v + lane_xor<STEP>(v);
+		return group_sum<S, STEP * 2>(v);
+	} else {
+		return v;
+	}
+}
+// two smallest of the per-group scores, butterfly across the view groups (every group is uniform inside)
+template <int STEP>
+__device__ __forceinline__ void min2_across(float& m1, float& m2) {
+	if constexpr (STEP < 64) {
+		const float o1 = lane_xor<STEP>(m1), o2 = lane_xor<STEP>(m2);
+		const float lo = fminf(m1, o1), hi = fmaxf(m1, o1);
+		m2 = fminf(hi, fminf(m2, o2));
+		m1 = lo;
+		min2_across<STEP * 2>(m1, m2);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------------
 // per-lane context
 
+typedef const __attribute__((address_space(1))) float* gcfptr; // global-address-space loads, not flat
+
 template <int S>
 struct LaneCtx {
 	static constexpr int MAXM = 64 / S; // taps per lane
 	int lane, view, seg;
-	bool vact;           // lane's view group exists
-	const float* img;    // my source view
-	int iw, ih;
-	double A[9], Hm[3];
+	bool vact;        // lane's view group exists
+	gcfptr img;       // my source view
+	int iw;
+	float wmax, hmax; // inside-with-border-1 limits of my view
+	float A[9], Hm[3];
 	unsigned long long groupMask;
 };
 
@@ -109,8 +156,9 @@ __device__ __forceinline__ void lane_init(const EstConst& c, LaneCtx<S>& L) {
 	L.view = L.lane / S;
 	L.seg = L.lane % S;
 	L.vact = L.view < c.V;
-	const DevView* dv = &c.views[L.vact ? L.view : 0];
-	L.img = dv->img; L.iw = dv->w; L.ih = dv->h;
+	const DevView* dv = &c.views[L.vact ? L.view : 0]; // idle groups mirror view 0 (results masked)
+	L.img = (gcfptr)dv->img; L.iw = dv->w;
+	L.wmax = (float)(dv->w - 2); L.hmax = (float)(dv->h - 2);
 #pragma unroll
 	for (int i = 0; i < 9; ++i) L.A[i] = dv->A[i];
 #pragma unroll
@@ -121,65 +169,111 @@ __device__ __forceinline__ void lane_init(const EstConst& c, LaneCtx<S>& L) {
 template <int S>
 struct Patch { // DepthMap.h:202-212 WeightedPatchFix, spread over the lanes of a group
 	static constexpr int MAXM = 64 / S;
-	float w[MAXM], tw[MAXM], px[MAXM], py[MAXM];
-	int ntaps;
+	float w[MAXM], tw[MAXM];
 	float sumW, normSq0;
+	int x, y, a;
 };
 
-// DepthMap.cpp:450-519 FillPixelPatch + DepthMap.h:537-548 GetWeight
+// everything one pixel reads from memory; the sweep loads it one pixel ahead (software pipeline)
 template <int S>
-__device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& L, int x, int y, Patch<S>& P) {
-	constexpr int MAXM = 64 / S;
-	const int W = c.W;
-	const float tx = (float)c.gra[y * W + x];
-	const int a = tx > 100.f ? 5 : c.adapthalfwin;
+struct PixIn {
+	static constexpr int MAXM = 64 / S;
+	float I[MAXM];  // reference-image taps of this lane (DepthMap.cpp:486-494)
+	float center;   // I0(x,y)
+	float tx;       // gradient-map value of (x,y) (DepthMap.cpp:455)
+	float4 cur;     // previous estimate of (x,y): depth, normal
+	float curConf;
+	// neighbour slot held by this lane (slot k lives in lane k)
+	int nx, ny;
+	bool slot, sprop;
+	int back;       // > 0: the slot is `back` columns behind me in my own row -> comes from the row ring
+	bool isUp;      // the slot lies in an earlier logical row -> needs that row's progress hand-off
+	bool loaded;    // payload below is valid
+	float4 ndn;
+	float nconf;
+};
+
+__device__ __forceinline__ int patch_halfwin(const EstConst& c, float tx) { return tx > 100.f ? 5 : c.adapthalfwin; } // DepthMap.cpp:455-461
+
+// Tap handled by segment `seg` at step m.  A segment owns ONE patch column and walks down its rows
+// (S = 8: all rows; 16/32/64: a half / quarter / single row run; S = 4: two columns), so (a) the lanes of a
+// view group read the same source-image row in each load instruction -- a handful of cache lines per
+// wave-instruction instead of 64 -- and (b) a lane's warped position is affine in m.
+// Row/column indices past the patch clamp to the last one (those taps get zero weight).
+template <int S>
+__device__ __forceinline__ bool tap_offset(int a, int seg, int m, int& i, int& j) {
 	const int nside = a + 1;
-	const int ntaps = nside * nside;
-	const int magic = (1024 + nside - 1) / nside; // (k*magic)>>10 == k/nside for k < 64, nside 2..8
-	P.ntaps = ntaps;
-	const float colCenter = c.ref[y * W + x];
+	int row, col;
+	if constexpr (S >= 8) {
+		constexpr int RH = 64 / S; // rows per segment
+		col = seg & 7;
+		row = (seg >> 3) * RH + m;
+	} else {
+		col = seg * 2 + (m >> 3);
+		row = m & 7;
+	}
+	const bool valid = row < nside && col < nside;
+	row = row < nside ? row : nside - 1;
+	col = col < nside ? col : nside - 1;
+	i = -a + 2 * row; j = -a + 2 * col;
+	return valid;
+}
+
+template <int S>
+__device__ __forceinline__ void load_patch_inputs(const EstConst& c, const LaneCtx<S>& L, int x, int y, PixIn<S>& in) {
+	constexpr int MAXM = 64 / S;
+	gcfptr ref = (gcfptr)c.ref;
+	const int a = patch_halfwin(c, in.tx);
+	in.center = ref[y * c.W + x];
+#pragma unroll
+	for (int m = 0; m < MAXM; ++m) {
+		int i, j;
+		tap_offset<S>(a, L.seg, m, i, j);
+		in.I[m] = ref[__mul24(y + i, c.W) + (x + j)];
+	}
+}
+
+// DepthMap.cpp:450-519 FillPixelPatch + DepthMap.h:537-548 GetWeight.
+// Lanes whose tap index is past the patch repeat the last tap with zero weights: they add exactly +0.
+template <int S>
+__device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& L, int x, int y, const PixIn<S>& in, Patch<S>& P) {
+	constexpr int MAXM = 64 / S;
+	const int a = patch_halfwin(c, in.tx);
 	const float sigmaColor = -1.f / (2.f * HC_SQ(0.2f));
 	const float sigmaSpatial = -1.f / (2.f * (float)HC_SQ(a));
-	float I[MAXM];
 	float sa = 0.f, sb = 0.f;
 #pragma unroll
 	for (int m = 0; m < MAXM; ++m) {
-		const int k = m * S + L.seg;
-		I[m] = 0.f; P.w[m] = 0.f; P.tw[m] = 0.f; P.px[m] = 0.f; P.py[m] = 0.f;
-		if (k < ntaps) {
-			const int ti = (k * magic) >> 10, tj = k - ti * nside;
-			const int i = -a + 2 * ti, j = -a + 2 * tj;
-			P.px[m] = (float)(x + j);
-			P.py[m] = (float)(y + i);
-			I[m] = c.ref[(y + i) * W + (x + j)];
-			const float wColor = HC_SQ(I[m] - colCenter) * sigmaColor;
-			const float wSpatial = (float)(HC_SQ(j) + HC_SQ(i)) * sigmaSpatial;
-			P.w[m] = pm_expf(wColor + wSpatial);
-			sa = fmaf(I[m], P.w[m], sa);
-			sb = sb + P.w[m];
-		}
+		int i, j;
+		const bool valid = tap_offset<S>(a, L.seg, m, i, j);
+		const float wColor = HC_SQ(in.I[m] - in.center) * sigmaColor;
+		const float wSpatial = (float)(HC_SQ(j) + HC_SQ(i)) * sigmaSpatial;
+		const float w = pm_expf(wColor + wSpatial);
+		P.w[m] = valid ? w : 0.f;
+		sa = fmaf(in.I[m], P.w[m], sa);
+		sb = sb + P.w[m];
 	}
 	const float swi = group_sum<S>(sa), sw = group_sum<S>(sb);
 	const float tm = swi / sw;
 	sa = 0.f;
 #pragma unroll
 	for (int m = 0; m < MAXM; ++m) {
-		const int k = m * S + L.seg;
-		if (k < ntaps) {
-			const float t = I[m] - tm;
-			P.tw[m] = P.w[m] * t;
-			sa = fmaf(P.tw[m], t, sa);
-		}
+		const float t = in.I[m] - tm;
+		P.tw[m] = P.w[m] * t;
+		sa = fmaf(P.tw[m], t, sa);
 	}
 	P.sumW = sw;
 	P.normSq0 = group_sum<S>(sa);
+	P.x = x; P.y = y; P.a = a;
 }
 
 // smoothness neighbours (DepthMap.h:376-382 NeighborEstimate): slot k lives in lane k
 struct Close {
-	float d, n0, n1, n2, X0, X1, X2, conf;
+	float d, n0, n1, n2;     // neighbour estimate as loaded
+	float kd, k0, k1, k2;    // interpolated depth + corrected normal (propagation candidates, DepthMap.cpp:1417-1418)
+	float X0, X1, X2, conf;
 	int nx, ny;
-	unsigned long long closeMask, propMask;
+	unsigned long long closeMask, eligMask;
 };
 
 struct PixelGeom {
@@ -188,17 +282,21 @@ struct PixelGeom {
 	float pn0, pn1, pn2, pd;  // smoothness plane (DepthMap.cpp:1730-1738)
 };
 
-// DepthMap.cpp:987-1046 ScorePixel over DepthMap.cpp:522-616 ScorePixelImage, all views at once
+// DepthMap.cpp:987-1046 ScorePixel over DepthMap.cpp:522-616 ScorePixelImage, all views at once.
+// corrMask: slots whose corrected normal is already in effect for this hypothesis.
 template <int S>
 __device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const Close& C,
-                                             const PixelGeom& G, float depth, float n0, float n1, float n2) {
+                                             unsigned long long corrMask, const PixelGeom& G, float depth, float n0,
+                                             float n1, float n2) {
 	constexpr int MAXM = 64 / S;
 	// smoothness factor of my slot (DepthMap.cpp:607-615); slot k is lane k
 	float f = 1.f;
 	if ((C.closeMask >> L.lane) & 1ull) {
+		const bool corr = (corrMask >> L.lane) & 1ull;
+		const float c0 = corr ? C.k0 : C.n0, c1 = corr ? C.k1 : C.n1, c2 = corr ? C.k2 : C.n2;
 		const float dist = dot3(G.pn0, G.pn1, G.pn2, C.X0, C.X1, C.X2) + G.pd;
 		const float fd = pm_expf(HC_SQ(dist / depth) * c.smoothSigmaDepth);
-		float ca = dot3(n0, n1, n2, C.n0, C.n1, C.n2) / sqrtf(dot3(n0, n1, n2, n0, n1, n2) * dot3(C.n0, C.n1, C.n2, C.n0, C.n1, C.n2));
+		float ca = dot3(n0, n1, n2, c0, c1, c2) / sqrtf(dot3(n0, n1, n2, n0, n1, n2) * dot3(c0, c1, c2, c0, c1, c2));
 		ca = ca < -1.f ? -1.f : (ca > 1.f ? 1.f : ca);
 		const float ang = pm_acosf(ca);
 		const float fn = pm_expf(HC_SQ(ang) * c.smoothSigmaNormal);
@@ -207,48 +305,77 @@ __device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>
 	// homography of my view (DepthMap.h:565-574), association H = A + Hm (Hr^T n)^T / (n.X0 d)
 	float H[9];
 	{
-		const double d0 = n0, d1 = n1, d2 = n2;
-		const double nx0 = fma(d2, 1.0, fma(d1, G.X0y, d0 * G.X0x));
-		const double inv = 1.0 / (nx0 * (double)depth);
-		double q[3];
+		const float nx0 = fmaf(n2, 1.0f, fmaf(n1, G.v1, n0 * G.v0));
+		const float inv = 1.0f / (nx0 * depth);
+		float q[3];
 #pragma unroll
-		for (int j = 0; j < 3; ++j) q[j] = fma(d2, c.Hr[6 + j], fma(d1, c.Hr[3 + j], d0 * c.Hr[j])) * inv;
+		for (int j = 0; j < 3; ++j) q[j] = fmaf(n2, c.Hr[6 + j], fmaf(n1, c.Hr[3 + j], n0 * c.Hr[j])) * inv;
 #pragma unroll
 		for (int i = 0; i < 3; ++i)
 #pragma unroll
-			for (int j = 0; j < 3; ++j) H[i * 3 + j] = (float)fma(L.Hm[i], q[j], L.A[i * 3 + j]);
+			for (int j = 0; j < 3; ++j) H[i * 3 + j] = fmaf(L.Hm[i], q[j], L.A[i * 3 + j]);
 	}
-	float sum = 0.f, sumSq = 0.f, num = 0.f;
-	bool bad = false;
-	const float wmax = (float)(L.iw - 2), hmax = (float)(L.ih - 2);
+	// three straight-line phases so that all 2*MAXM row loads of an evaluation are in flight together:
+	// (1) warp every tap, (2) issue the loads, (3) interpolate + accumulate.  Out-of-image taps only raise
+	// `bad`; their loads go to offset 0.
+	float Xx[MAXM], Xy[MAXM], Xz[MAXM], iz[MAXM];
 #pragma unroll
 	for (int m = 0; m < MAXM; ++m) {
-		const int k = m * S + L.seg;
-		if (k < P.ntaps && L.vact) {
-			const float px = P.px[m], py = P.py[m];
-			const float Xx = fmaf(H[0], px, fmaf(H[1], py, H[2]));
-			const float Xy = fmaf(H[3], px, fmaf(H[4], py, H[5]));
-			const float Xz = fmaf(H[6], px, fmaf(H[7], py, H[8]));
-			const float iz = 1.0f / Xz;
-			const float qx = Xx * iz, qy = Xy * iz;
-			if (qx >= 1.f && qy >= 1.f && qx <= wmax && qy <= hmax) { // Types.h:1633-1635
-				const int lx = (int)qx, ly = (int)qy;
-				const float fx = qx - (float)lx, fx1 = 1.f - fx;
-				const float fy = qy - (float)ly, fy1 = 1.f - fy;
-				const float* r0 = L.img + (size_t)ly * L.iw + lx;
-				const float* r1 = r0 + L.iw;
-				const float i00 = r0[0], i01 = r0[1], i10 = r1[0], i11 = r1[1];
-				float t = i00 * fx1; t = fmaf(i01, fx, t);
-				float b = i10 * fx1; b = fmaf(i11, fx, b);
-				float val = t * fy1; val = fmaf(b, fy, val); // Types.inl:2250-2258
-				const float vw = val * P.w[m];
-				sum = sum + vw;
-				sumSq = fmaf(val, vw, sumSq);
-				num = fmaf(val, P.tw[m], num);
-			} else {
-				bad = true;
-			}
+		int ti, tj;
+		tap_offset<S>(P.a, L.seg, m, ti, tj);
+		const float px = (float)(P.x + tj), py = (float)(P.y + ti);
+		Xx[m] = fmaf(H[0], px, fmaf(H[1], py, H[2]));
+		Xy[m] = fmaf(H[3], px, fmaf(H[4], py, H[5]));
+		Xz[m] = fmaf(H[6], px, fmaf(H[7], py, H[8]));
+	}
+	// perspective divide: ONE IEEE reciprocal per group of up to four taps (1/z_i = (1/prod z) * prod_{j!=i} z_j)
+	if constexpr (MAXM >= 4) {
+#pragma unroll
+		for (int g = 0; g < MAXM; g += 4) {
+			const float p01 = Xz[g] * Xz[g + 1], p23 = Xz[g + 2] * Xz[g + 3];
+			const float r = 1.0f / (p01 * p23);
+			const float r01 = r * p23, r23 = r * p01;
+			iz[g] = r01 * Xz[g + 1]; iz[g + 1] = r01 * Xz[g];
+			iz[g + 2] = r23 * Xz[g + 3]; iz[g + 3] = r23 * Xz[g + 2];
 		}
+	} else if constexpr (MAXM == 2) {
+		const float r = 1.0f / (Xz[0] * Xz[1]);
+		iz[0] = r * Xz[1]; iz[1] = r * Xz[0];
+	} else {
+		iz[0] = 1.0f / Xz[0];
+	}
+	float fx[MAXM], fy[MAXM];
+	int off[MAXM];
+	bool bad = false;
+#pragma unroll
+	for (int m = 0; m < MAXM; ++m) {
+		const float qx = Xx[m] * iz[m], qy = Xy[m] * iz[m];
+		const bool inside = qx >= 1.f && qy >= 1.f && qx <= L.wmax && qy <= L.hmax; // Types.h:1633-1635
+		bad = bad || !inside;
+		const int lx = (int)qx, ly = (int)qy;
+		fx[m] = qx - (float)lx;
+		fy[m] = qy - (float)ly;
+		off[m] = inside ? __mul24(ly, L.iw) + lx : 0;
+	}
+	float2 top[MAXM], bot[MAXM];
+#pragma unroll
+	for (int m = 0; m < MAXM; ++m) {
+		gcfptr r0 = L.img + off[m];
+		gcfptr r1 = r0 + L.iw;
+		top[m] = make_float2(r0[0], r0[1]);
+		bot[m] = make_float2(r1[0], r1[1]);
+	}
+	float sum = 0.f, sumSq = 0.f, num = 0.f;
+#pragma unroll
+	for (int m = 0; m < MAXM; ++m) {
+		// bilinear sample (Types.inl:2250-2258) in lerp form
+		const float t = fmaf(fx[m], top[m].y - top[m].x, top[m].x);
+		const float b = fmaf(fx[m], bot[m].y - bot[m].x, bot[m].x);
+		const float val = fmaf(fy[m], b - t, t);
+		const float vw = val * P.w[m];
+		sum = sum + vw;
+		sumSq = fmaf(val, vw, sumSq);
+		num = fmaf(val, P.tw[m], num);
 	}
 	const bool viewBad = (__ballot(bad) & L.groupMask) != 0ull;
 	sum = group_sum<S>(sum); sumSq = group_sum<S>(sumSq); num = group_sum<S>(num);
@@ -265,13 +392,7 @@ __device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>
 	s = c.pfScale * s;
 	if (viewBad || !(nrmSq > 0.f)) s = c.thRobust;
 	float m1 = L.vact ? s : __builtin_huge_valf(), m2 = __builtin_huge_valf();
-#pragma unroll
-	for (int step = S; step < 64; step <<= 1) { // two smallest scores across view groups
-		const float o1 = __shfl_xor(m1, step, 64), o2 = __shfl_xor(m2, step, 64);
-		const float lo = fminf(m1, o1), hi = fmaxf(m1, o1);
-		m2 = fminf(hi, fminf(m2, o2));
-		m1 = lo;
-	}
+	min2_across<S>(m1, m2);
 	if (c.V <= 1) return m1;
 	return m2 >= c.thRobust ? m1 : (m1 + m2) / 2.f;
 }
@@ -329,7 +450,7 @@ __device__ __forceinline__ void correct_normal(const PixelGeom& G, float& n0, fl
 __device__ __forceinline__ float interpolate_pixel(const EstConst& c, const PixelGeom& G, int nx, int ny, float depth,
                                                    float n0, float n1, float n2) {
 	const double p0 = n0, p1 = n1, p2 = n2, z = depth;
-	const double P0 = ((double)nx - c.cx) * z / c.fx, P1 = ((double)ny - c.cy) * z / c.fy;
+	const double P0 = ((double)nx - c.cx) * z * c.ifx, P1 = ((double)ny - c.cy) * z * c.ify;
 	const double planeD = p0 * P0 + p1 * P1 + p2 * z;
 	const float dn = (float)(planeD / (p0 * G.X0x + p1 * G.X0y + p2 * 1.0));
 	return (c.dMin <= dn && dn < c.dMax) ? dn : depth;
@@ -339,32 +460,80 @@ __device__ __forceinline__ void init_plane(PixelGeom& G, float depth, float n0, 
 	G.pd = -depth * dot3(n0, n1, n2, G.v0, G.v1, 1.f);
 }
 __device__ __forceinline__ void pixel_geom(const EstConst& c, int x, int y, PixelGeom& G) {
-	G.X0x = ((double)x - c.cx) / c.fx;
-	G.X0y = ((double)y - c.cy) / c.fy;
+	G.X0x = ((double)x - c.cx) * c.ifx;
+	G.X0y = ((double)y - c.cy) * c.ify;
 	G.v0 = (float)G.X0x; G.v1 = (float)G.X0y;
 	G.pn0 = G.pn1 = G.pn2 = G.pd = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------------
-// DepthMap.cpp:1050-1501 ProcessPixel for pixel (x,y), executed by one wave
+// sweep: NW waves cooperate on one image row.  Every wave carries the complete (identical) pixel state;
+// in each round wave w scores hypothesis number w of the batch and the scores are exchanged through LDS,
+// after which every wave replays the reference's sequential accept logic (DepthMap.cpp:1425, 1455, 1484).
+// Propagation candidates and full-random hypotheses do not depend on earlier accepts, so a batch is
+// exact; refinement trials do (they perturb the current estimate), so the trials after an accepted one
+// are discarded and re-issued from the new state.  The maps are identical to the sequential sweep.
 
+constexpr int kHist = 16; // ring of the row's own latest results (neighbours behind in the same row)
+
+template <int NW>
+struct RowShared {
+	float ex[2][NW][8]; // per round parity, per wave: score, depth, n0, n1, n2, p0, p1, pad
+	float hist[kHist][6];
+	int row;
+};
+
+template <int NW>
+__device__ __forceinline__ void exchange(RowShared<NW>& sh, int par, int wv, int lane, float sc, float d, float n0,
+                                         float n1, float n2, float p0, float p1) {
+	if (NW > 1) {
+		if (lane == 0) {
+			float* e = sh.ex[par][wv];
+			e[0] = sc; e[1] = d; e[2] = n0; e[3] = n1; e[4] = n2; e[5] = p0; e[6] = p1;
+		}
+		__syncthreads();
+	}
+}
+
+__device__ __forceinline__ int wait_progress(int32_t* word, int need, int32_t* err) {
+	int v;
+	unsigned spins = 0;
+	while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, HC_SCOPE)) < need) {
+		__builtin_amdgcn_s_sleep(1);
+		++spins;
+		if ((spins & 255u) == 0u) {
+			if (__hip_atomic_load(err, __ATOMIC_RELAXED, HC_SCOPE) != 0) return -1;
+			if (spins > (1u << 22)) { // bounded: give up instead of hanging the device
+				__hip_atomic_store(err, 1, __ATOMIC_RELAXED, HC_SCOPE);
+				return -1;
+			}
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler-only: keep payload loads below the poll
+	return v;
+}
+
+// state of one row worker that lives across pixels: the software pipeline of memory accesses
 template <int S>
-__device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S>& L, int x, int y, int iter, bool rev,
-                                              unsigned& evals) {
-	const int W = c.W, H = c.H, lane = L.lane;
-	Patch<S> P;
-	fill_patch<S>(c, L, x, y, P);
-	PixelGeom G;
-	pixel_geom(c, x, y, G);
+struct RowPipe {
+	uint8_t tx1;      // gradient-map byte of the next column (kept raw so that nothing waits on the load)
+	int known;        // columns the previous logical row is known to have finished
+	int poll;         // progress value of an in-flight poll
+	int pendingPub;   // > 0: results up to this column are stored but not yet published
+	int32_t *upWord, *myWord, *err;
+	int r, y, ncols;
+	bool rev, fail;
+};
 
-	// neighbour slots: slot k in lane k
-	Close C;
+// neighbour slot of this lane for pixel (x,y), logical column q (DepthMap.cpp:1064-1391)
+template <int S>
+__device__ __forceinline__ void slot_setup(const EstConst& c, int lane, int x, int y, bool rev, PixIn<S>& in) {
+	const int W = c.W, H = c.H;
 	int nx = x, ny = y;
 	bool slot = false, sprop = false;
 	if (c.itExternal >= 1) {
-		// DepthMap.cpp:1064-1274: cross pattern (same set for both sweep directions)
-		const float tx = (float)c.gra[y * W + x];
-		int phw = tx > 150.f ? 5 : c.propHalfwin;
+		// cross pattern, the same set for both sweep directions
+		int phw = in.tx > 150.f ? 5 : c.propHalfwin;
 		if (phw > 7) phw = 7;
 		const int step = c.propStep > 0 ? c.propStep : 1;
 		int i = 0;
@@ -379,7 +548,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		ny = y + (t == 0 ? -i : (t == 1 ? i : 0));
 		sprop = slot;
 	} else {
-		// DepthMap.cpp:1275-1391: 2 causal neighbours propagate, all 4 smooth
+		// 2 causal neighbours propagate, all 4 smooth
 		if (lane < 4) {
 			const int d = rev ? ((lane + 2) & 3) : lane; // 0 left, 1 up, 2 right, 3 down
 			nx = x + (d == 0 ? -1 : (d == 2 ? 1 : 0));
@@ -388,63 +557,180 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			sprop = lane < 2;
 		}
 	}
-	C.d = 0.f; C.n0 = C.n1 = C.n2 = 0.f; C.conf = 0.f; C.nx = nx; C.ny = ny;
-	if (slot) {
-		const float4 v = load_dn(&c.dn[ny * W + nx]);
-		C.d = v.x; C.n0 = v.y; C.n1 = v.z; C.n2 = v.w;
-		C.conf = load_f(&c.conf[ny * W + nx]);
+	in.nx = nx; in.ny = ny; in.slot = slot; in.sprop = sprop;
+	in.back = ny == y ? (rev ? nx - x : x - nx) : 0;
+	in.isUp = slot && (rev ? ny > y : ny < y);
+	in.loaded = false;
+	in.ndn = make_float4(0.f, 0.f, 0.f, 0.f);
+	in.nconf = 0.f;
+}
+
+// issue the loads of pixel (x,y) that do not depend on other rows' progress in this sweep
+template <int S>
+__device__ __forceinline__ void prefetch_static(const EstConst& c, const LaneCtx<S>& L, int x, int y, int q, bool rev, PixIn<S>& in) {
+	slot_setup<S>(c, L.lane, x, y, rev, in);
+	load_patch_inputs<S>(c, L, x, y, in);
+	const int idx = y * c.W + x;
+	in.cur = load_dn(&c.dn[idx]);
+	in.curConf = load_f(&c.conf[idx]);
+	// slots ahead of me in my row, in later rows, or left of the swept range still hold last pass's values
+	if (in.slot && !in.isUp && !(in.back > 0 && in.back <= q)) {
+		in.ndn = load_dn(&c.dn[in.ny * c.W + in.nx]);
+		in.nconf = load_f(&c.conf[in.ny * c.W + in.nx]);
+		in.loaded = true;
 	}
-	const bool closeV = slot && C.d > 0.f;
+}
+template <int S>
+__device__ __forceinline__ void prefetch_up(const EstConst& c, PixIn<S>& in) {
+	if (in.isUp && !in.loaded) {
+		in.ndn = load_dn(&c.dn[in.ny * c.W + in.nx]);
+		in.nconf = load_f(&c.conf[in.ny * c.W + in.nx]);
+		in.loaded = true;
+	}
+}
+
+// DepthMap.cpp:1050-1501 ProcessPixel for logical column q of the row, pixel (x,y).  `in` holds the
+// inputs (complete); `pp` is the row pipeline (prefetch of column q+1, progress polls, deferred publish).
+template <int S, int NW>
+__device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S>& L, RowShared<NW>& sh, int& par, int wv,
+                                              int x, int y, int q, int iter, const PixIn<S>& in, const Patch<S>& P,
+                                              RowPipe<S>& pp, unsigned& evals, unsigned& issued STAMP_ARGS) {
+	const int W = c.W, lane = L.lane;
+	PixelGeom G;
+	pixel_geom(c, x, y, G);
+
+	// neighbour slots: slot k in lane k
+	Close C;
+	const int nx = in.nx, ny = in.ny;
+	C.d = in.ndn.x; C.n0 = in.ndn.y; C.n1 = in.ndn.z; C.n2 = in.ndn.w; C.conf = in.nconf; C.nx = nx; C.ny = ny;
+	C.kd = 0.f; C.k0 = C.k1 = C.k2 = 0.f;
+	if (in.slot && in.back > 0 && in.back <= q) { // finished by this row earlier in this sweep: the row ring has it
+		const float* hrec = sh.hist[(q - in.back) & (kHist - 1)];
+		C.d = hrec[0]; C.n0 = hrec[1]; C.n1 = hrec[2]; C.n2 = hrec[3]; C.conf = hrec[4];
+	}
+	const bool closeV = in.slot && C.d > 0.f;
 	C.closeMask = __ballot(closeV);
-	C.propMask = __ballot(closeV && sprop);
 	{ // Cast<float>(camera.TransformPointI2C(Point3(nx, ndepth))), Camera.h:306-312
 		const double z = C.d;
-		C.X0 = (float)(((double)nx - c.cx) * z / c.fx);
-		C.X1 = (float)(((double)ny - c.cy) * z / c.fy);
+		C.X0 = (float)(((double)nx - c.cx) * z * c.ifx);
+		C.X1 = (float)(((double)ny - c.cy) * z * c.ify);
 		C.X2 = (float)z;
+	}
+	// propagation candidates (DepthMap.cpp:1412-1418), lane-parallel: ray-plane depth + corrected normal
+	const bool elig = closeV && in.sprop && !(C.conf >= c.thKeep);
+	C.eligMask = __ballot(elig);
+	if (elig) {
+		C.kd = interpolate_pixel(c, G, nx, ny, C.d, C.n0, C.n1, C.n2);
+		C.k0 = C.n0; C.k1 = C.n1; C.k2 = C.n2;
+		correct_normal(G, C.k0, C.k1, C.k2);
 	}
 
 	const int idx = y * W + x;
-	const float4 cur = load_dn(&c.dn[idx]);
-	float conf = load_f(&c.conf[idx]);
-	float depth = cur.x, n0 = cur.y, n1 = cur.z, n2 = cur.w;
+	float conf = in.curConf;
+	float depth = in.cur.x, n0 = in.cur.y, n1 = in.cur.z, n2 = in.cur.w;
 	init_plane(G, depth, n0, n1, n2);
+	STAMP(2)
 
-	// propagation, DepthMap.cpp:1406-1440
-	for (unsigned long long mk = C.propMask; mk;) {
-		const int k = __builtin_ctzll(mk);
-		mk &= mk - 1ull;
-		if (rlf(C.conf, k) >= c.thKeep) continue;
-		float kd = rlf(C.d, k), k0 = rlf(C.n0, k), k1 = rlf(C.n1, k), k2 = rlf(C.n2, k);
-		const int knx = rli(C.nx, k), kny = rli(C.ny, k);
-		kd = interpolate_pixel(c, G, knx, kny, kd, k0, k1, k2);
-		correct_normal(G, k0, k1, k2);
-		if (lane == k) { C.d = kd; C.n0 = k0; C.n1 = k1; C.n2 = k2; }
-		init_plane(G, kd, k0, k1, k2);
-		const float nconf = score_pixel<S>(c, L, P, C, G, kd, k0, k1, k2);
-		++evals;
-		if (conf > nconf) { conf = nconf; depth = kd; n0 = k0; n1 = k1; n2 = k2; }
+	// ---- propagation, DepthMap.cpp:1406-1440: candidate j sees slots <= j corrected ----
+	{
+		unsigned long long rest = C.eligMask;
+		while (rest) {
+			int slots[NW];
+			unsigned long long corr[NW];
+			int nb = 0;
+#pragma unroll
+			for (int w = 0; w < NW; ++w) {
+				slots[w] = -1; corr[w] = 0ull;
+				if (rest) {
+					const int k = __builtin_ctzll(rest);
+					rest &= rest - 1ull;
+					slots[w] = k;
+					corr[w] = C.eligMask & ((2ull << k) - 1ull);
+					nb = w + 1;
+				}
+			}
+			int myk = -1;
+			unsigned long long myCorr = 0ull;
+#pragma unroll
+			for (int w = 0; w < NW; ++w) if (w == wv) { myk = slots[w]; myCorr = corr[w]; }
+			float sc = __builtin_huge_valf();
+			if (myk >= 0) {
+				const float kd = rlf(C.kd, myk), k0 = rlf(C.k0, myk), k1 = rlf(C.k1, myk), k2 = rlf(C.k2, myk);
+				PixelGeom Gc = G;
+				init_plane(Gc, kd, k0, k1, k2);
+				sc = score_pixel<S>(c, L, P, C, myCorr, Gc, kd, k0, k1, k2);
+				++issued;
+			}
+			STAMP(3)
+			exchange<NW>(sh, par, wv, lane, sc, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+			STAMP(4)
+#pragma unroll
+			for (int w = 0; w < NW; ++w) {
+				if (w < nb) {
+					const float nconf = NW > 1 ? sh.ex[par][w][0] : sc;
+					const int k = slots[w];
+					++evals;
+					if (conf > nconf) { conf = nconf; depth = rlf(C.kd, k); n0 = rlf(C.k0, k); n1 = rlf(C.k1, k); n2 = rlf(C.k2, k); }
+					if (w == nb - 1) init_plane(G, rlf(C.kd, k), rlf(C.k0, k), rlf(C.k1, k), rlf(C.k2, k)); // plane of the last candidate stays
+				}
+			}
+			par ^= 1;
+		}
+	}
+	const unsigned long long allCorr = C.eligMask;
+	STAMP(5)
+
+	// ---- pipeline hook 1: publish the previous column, start the next column's loads, refresh progress ----
+	{
+		if (wv == 0 && pp.pendingPub > 0) {
+			// the stores of the previous column were issued a whole scoring round ago: this wait is free
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (lane == 0) __hip_atomic_store(pp.myWord, pp.pendingPub, __ATOMIC_RELAXED, HC_SCOPE);
+			pp.pendingPub = 0;
+		}
+		if (pp.r > 0) pp.poll = __hip_atomic_load(pp.upWord, __ATOMIC_RELAXED, HC_SCOPE);
 	}
 
-	// refinement, DepthMap.cpp:1442-1501
-	const uint32_t st = (uint32_t)c.itExternal * 64u + 1u + (uint32_t)iter;
+	STAMP(6)
+	// ---- refinement, DepthMap.cpp:1442-1501 ----
+	const uint32_t rk = rand_key(c.seed, (uint32_t)idx, (uint32_t)c.itExternal * 64u + 1u + (uint32_t)iter);
+	const int nR = c.nRandomIters;
 	unsigned idxScaleRange = 0;
 	bool done = false;
+	bool hook2 = false;
 	for (;;) {
 		if (conf <= c.thConfSmall) idxScaleRange = 2;
 		else if (conf <= c.thConfBig) idxScaleRange = 1;
 		else if (conf >= c.thConfRand) {
+			// completely random hypotheses: independent of the current estimate, batches are exact
 			bool again = false;
-			for (int it = 0; it < c.nRandomIters; ++it) {
-				const float nd = random_depth(c, rand_unit(c.seed, (uint32_t)idx, st, 3u * it));
-				float r0, r1, r2;
-				random_normal(G, rand_unit(c.seed, (uint32_t)idx, st, 3u * it + 1u), rand_unit(c.seed, (uint32_t)idx, st, 3u * it + 2u), r0, r1, r2);
-				const float nconf = score_pixel<S>(c, L, P, C, G, nd, r0, r1, r2);
-				++evals;
-				if (conf > nconf) {
-					conf = nconf; depth = nd; n0 = r0; n1 = r1; n2 = r2;
-					if (conf < c.thConfRand) { again = true; break; }
+			for (int t0 = 0; t0 < nR && !again; t0 += NW) {
+				const int t = t0 + wv;
+				float sc = __builtin_huge_valf(), nd = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
+				if (t < nR) {
+					nd = random_depth(c, rand_unit(rk, 3u * t));
+					random_normal(G, rand_unit(rk, 3u * t + 1u), rand_unit(rk, 3u * t + 2u), r0, r1, r2);
+					sc = score_pixel<S>(c, L, P, C, allCorr, G, nd, r0, r1, r2);
+					++issued;
 				}
+				STAMP(7)
+				exchange<NW>(sh, par, wv, lane, sc, nd, r0, r1, r2, 0.f, 0.f);
+				STAMP(8)
+#pragma unroll
+				for (int w = 0; w < NW; ++w) {
+					if (t0 + w < nR && !again) {
+						const float* e = sh.ex[par][w];
+						const float nconf = NW > 1 ? e[0] : sc;
+						++evals;
+						if (conf > nconf) {
+							conf = nconf;
+							if (NW > 1) { depth = e[1]; n0 = e[2]; n1 = e[3]; n2 = e[4]; }
+							else { depth = nd; n0 = r0; n1 = r1; n2 = r2; }
+							if (conf < c.thConfRand) again = true;
+						}
+					}
+				}
+				par ^= 1;
 			}
 			if (again) continue;
 			done = true;
@@ -455,89 +741,144 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		float scaleRange = 1.f / (float)(1u << idxScaleRange);
 		const float depthRange = depth * c.depthRatio;
 		float p0 = pm_atan2f(n1, n0), p1 = pm_acosf(n2); // Normal2Dir
-		for (int it = 0; it < c.nRandomIters; ++it) {
-			const uint32_t cb = 64u + 3u * it;
-			const float nd = depth + (depthRange * scaleRange) * (2.f * rand_unit(c.seed, (uint32_t)idx, st, cb) - 1.f);
-			if (!(c.dMin <= nd && nd < c.dMax)) continue;
-			const float np0 = p0 + (c.angle1Range * scaleRange) * (2.f * rand_unit(c.seed, (uint32_t)idx, st, cb + 1u) - 1.f);
-			const float np1 = p1 + (c.angle2Range * scaleRange) * (2.f * rand_unit(c.seed, (uint32_t)idx, st, cb + 2u) - 1.f);
-			float r0, r1, r2;
-			dir2normal(np0, np1, r0, r1, r2);
-			if (dot3(r0, r1, r2, G.v0, G.v1, 1.f) >= 0.f) continue;
-			init_plane(G, nd, r0, r1, r2);
-			const float nconf = score_pixel<S>(c, L, P, C, G, nd, r0, r1, r2);
-			++evals;
-			if (conf > nconf) {
-				conf = nconf; depth = nd; n0 = r0; n1 = r1; n2 = r2;
-				p0 = np0; p1 = np1;
-				++idxScaleRange;
-				scaleRange = 1.f / (float)(1u << idxScaleRange);
+		int t0 = 0;
+		while (t0 < nR) {
+			const int t = t0 + wv;
+			float sc = __builtin_huge_valf(), nd = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f, np0 = 0.f, np1 = 0.f;
+			if (t < nR) {
+				const uint32_t cb = 64u + 3u * t;
+				nd = depth + (depthRange * scaleRange) * (2.f * rand_unit(rk, cb) - 1.f);
+				if (c.dMin <= nd && nd < c.dMax) {
+					np0 = p0 + (c.angle1Range * scaleRange) * (2.f * rand_unit(rk, cb + 1u) - 1.f);
+					np1 = p1 + (c.angle2Range * scaleRange) * (2.f * rand_unit(rk, cb + 2u) - 1.f);
+					dir2normal(np0, np1, r0, r1, r2);
+					if (!(dot3(r0, r1, r2, G.v0, G.v1, 1.f) >= 0.f)) {
+						PixelGeom Gc = G;
+						init_plane(Gc, nd, r0, r1, r2);
+						sc = score_pixel<S>(c, L, P, C, allCorr, Gc, nd, r0, r1, r2);
+						++issued;
+					}
+				}
 			}
+			STAMP(7)
+			exchange<NW>(sh, par, wv, lane, sc, nd, r0, r1, r2, np0, np1);
+			STAMP(8)
+			if (!hook2) { // pipeline hook 2: the poll issued at hook 1 has landed by now
+				hook2 = true;
+				if (pp.r > 0) {
+					if (pp.poll > pp.known) pp.known = pp.poll;
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					pp.poll = __hip_atomic_load(pp.upWord, __ATOMIC_RELAXED, HC_SCOPE);
+				}
+			}
+			bool accepted = false;
+			int tnext = t0 + NW;
+#pragma unroll
+			for (int w = 0; w < NW; ++w) {
+				if (t0 + w < nR && !accepted) {
+					const float* e = sh.ex[par][w];
+					const float nconf = NW > 1 ? e[0] : sc;
+					if (nconf < __builtin_huge_valf()) ++evals; // the sequential algorithm scores only valid trials
+					if (conf > nconf) {
+						conf = nconf;
+						if (NW > 1) { depth = e[1]; n0 = e[2]; n1 = e[3]; n2 = e[4]; p0 = e[5]; p1 = e[6]; }
+						else { depth = nd; n0 = r0; n1 = r1; n2 = r2; p0 = np0; p1 = np1; }
+						++idxScaleRange;
+						scaleRange = 1.f / (float)(1u << idxScaleRange);
+						accepted = true; // later trials of this batch used the old estimate: re-issue them
+						tnext = t0 + w + 1;
+					}
+				}
+			}
+			par ^= 1;
+			t0 = tnext;
 		}
 	}
+	if (pp.r > 0 && pp.poll > pp.known) pp.known = pp.poll; // consume the latest poll
 	if (lane == 0) {
-		store_dn(&c.dn[idx], depth, n0, n1, n2);
-		store_f(&c.conf[idx], conf);
+		float* hrec = sh.hist[q & (kHist - 1)];
+		hrec[0] = depth; hrec[1] = n0; hrec[2] = n1; hrec[3] = n2; hrec[4] = conf;
+		if (wv == 0) {
+			store_dn(&c.dn[idx], depth, n0, n1, n2);
+			store_f(&c.conf[idx], conf);
+		}
 	}
+	pp.pendingPub = q + 1;
+	STAMP(9)
 }
 
 // ------------------------------------------------------------------------------------------------------
 // sweep kernel: persistent row workers (SceneDensify.cpp:677-686 EstimateDepthMapTmp)
 
-__device__ __forceinline__ int wait_progress(int32_t* word, int need, int32_t* err) {
-	int v;
-	unsigned spins = 0;
-	while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, HC_SCOPE)) < need) {
-		__builtin_amdgcn_s_sleep(4);
-		++spins;
-		if ((spins & 255u) == 0u) {
-			if (__hip_atomic_load(err, __ATOMIC_RELAXED, HC_SCOPE) != 0) return -1;
-			if (spins > (1u << 22)) { // bounded: give up instead of hanging the device
-				__hip_atomic_store(err, 1, __ATOMIC_RELAXED, HC_SCOPE);
-				return -1;
-			}
-		}
-	}
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler-only: keep payload loads below the poll
-	return v;
-}
-
-template <int S>
-__global__ __launch_bounds__(64) void sweep_kernel(EstConst c, SweepSync sy, int iter, int lag) {
+template <int S, int NW>
+__global__ __launch_bounds__(64 * NW) void sweep_kernel(EstConst c, SweepSync sy, int iter, int lag) {
+	__shared__ RowShared<NW> sh;
 	LaneCtx<S> L;
 	lane_init<S>(c, L);
+	const int wv = threadIdx.x >> 6;
 	const bool rev = (iter & 1) != 0; // dir = RB2LT on odd iterations, DepthMap.cpp:418
 	const int nrows = c.H - 2 * kHalfWindow, ncols = c.W - 2 * kHalfWindow;
-	unsigned evals = 0;
+	unsigned evals = 0, issued = 0;
+	unsigned long long taps = 0; // patch taps of the sequential algorithm's evaluations (per source view)
+	int par = 0;
+	STAMP_DECL
+	RowPipe<S> pp;
+	pp.err = sy.error; pp.ncols = ncols; pp.rev = rev;
 	for (;;) {
-		int r = 0;
-		if (L.lane == 0) r = atomicAdd(sy.ticket, 1);
-		r = __builtin_amdgcn_readfirstlane(r);
+		// rows are handed out in dependency order: whoever holds row r-1 is already running
+		if (NW > 1) __syncthreads(); // everyone is done with the previous row's shared state
+		if (threadIdx.x == 0) sh.row = atomicAdd(sy.ticket, 1);
+		if (NW > 1) __syncthreads();
+		const int r = __builtin_amdgcn_readfirstlane(sh.row);
 		if (r >= nrows) break;
 		const int y = rev ? c.H - 1 - kHalfWindow - r : kHalfWindow + r;
-		int32_t* upWord = sy.progress + (size_t)(r > 0 ? r - 1 : 0) * kProgressStride;
-		int32_t* myWord = sy.progress + (size_t)r * kProgressStride;
-		int known = r > 0 ? 0 : 0x7fffffff; // columns the previous logical row has finished
-		bool fail = false;
-		if (r > 0) { // start `lag` columns behind so that later polls rarely have to wait
+		pp.r = r; pp.y = y;
+		pp.upWord = sy.progress + (size_t)(r > 0 ? r - 1 : 0) * kProgressStride;
+		pp.myWord = sy.progress + (size_t)r * kProgressStride;
+		pp.known = r > 0 ? 0 : 0x7fffffff; // columns the previous logical row has finished
+		pp.poll = 0; pp.pendingPub = 0; pp.fail = false;
+		if (r > 0) {
 			const int need = lag < ncols ? lag : ncols;
-			known = wait_progress(upWord, need, sy.error);
-			fail = known < 0;
+			pp.known = wait_progress(pp.upWord, need, sy.error);
+			pp.fail = pp.known < 0;
 		}
-		for (int q = 0; q < ncols && !fail; ++q) {
-			if (known < q + 1) {
-				known = wait_progress(upWord, q + 1, sy.error);
-				if (known < 0) { fail = true; break; }
-			}
+		const int x0 = rev ? c.W - 1 - kHalfWindow : kHalfWindow;
+		pp.tx1 = c.gra[y * c.W + x0];
+		for (int q = 0; q < ncols && !pp.fail; ++q) {
 			const int x = rev ? c.W - 1 - kHalfWindow - q : kHalfWindow + q;
-			process_pixel<S>(c, L, x, y, iter, rev, evals);
-			// publish: results must have left the wave before the progress word moves
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (L.lane == 0) __hip_atomic_store(myWord, q + 1, __ATOMIC_RELAXED, HC_SCOPE);
+			// all loads of this pixel that do not depend on other rows go out in one batch ...
+			PixIn<S> in;
+			in.tx = (float)pp.tx1;
+			prefetch_static<S>(c, L, x, y, q, rev, in);
+			if (q + 1 < ncols) pp.tx1 = c.gra[y * c.W + (rev ? x - 1 : x + 1)];
+			if (pp.known >= q + 1) prefetch_up<S>(c, in);
+			// ... and the patch weights are computed while they (and the previous row) arrive
+			Patch<S> P;
+			fill_patch<S>(c, L, x, y, in, P);
+			STAMP(1)
+			if (pp.known < q + 1) { // the previous row must have finished this column
+				pp.known = wait_progress(pp.upWord, q + 1, sy.error);
+				if (pp.known < 0) { pp.fail = true; break; }
+				prefetch_up<S>(c, in);
+			}
+			STAMP(0)
+			const unsigned e0 = evals;
+			process_pixel<S, NW>(c, L, sh, par, wv, x, y, q, iter, in, P, pp, evals, issued STAMP_PASS);
+			taps += (unsigned long long)(evals - e0) * (unsigned)((P.a + 1) * (P.a + 1));
 		}
-		if (fail) break;
+		if (pp.fail) break;
+		if (wv == 0 && pp.pendingPub > 0) { // last column of the row
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (L.lane == 0) __hip_atomic_store(pp.myWord, pp.pendingPub, __ATOMIC_RELAXED, HC_SCOPE);
+			pp.pendingPub = 0;
+		}
 	}
-	if (L.lane == 0 && evals) atomicAdd(sy.evals, (unsigned long long)evals);
+	STAMP(10)
+	STAMP_FLUSH
+	if (L.lane == 0) {
+		if (wv == 0 && evals) { atomicAdd(sy.evals, (unsigned long long)evals); atomicAdd(sy.evals + 2, taps); }
+		if (issued) atomicAdd(sy.evals + 1, (unsigned long long)issued);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -567,33 +908,43 @@ __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long lo
 	const int wavesPerBlock = blockDim.x >> 6;
 	const int gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), nw = gridDim.x * wavesPerBlock;
 	unsigned evals = 0;
+	unsigned long long taps = 0;
 	const uint32_t st = (uint32_t)c.itExternal * 64u;
 	for (int p = gw; p < total; p += nw) {
 		const int x = kHalfWindow + p % ncols, y = kHalfWindow + p / ncols;
 		const int idx = y * c.W + x;
+		const uint32_t rk = rand_key(c.seed, (uint32_t)idx, st);
+		PixIn<S> in;
+		in.tx = (float)c.gra[idx];
+		load_patch_inputs<S>(c, L, x, y, in);
 		Patch<S> P;
-		fill_patch<S>(c, L, x, y, P);
+		fill_patch<S>(c, L, x, y, in, P);
 		PixelGeom G;
 		pixel_geom(c, x, y, G);
 		Close C;
-		C.closeMask = 0ull; C.propMask = 0ull;
-		C.d = C.n0 = C.n1 = C.n2 = C.X0 = C.X1 = C.X2 = C.conf = 0.f; C.nx = C.ny = 0;
+		C.closeMask = 0ull; C.eligMask = 0ull;
+		C.d = C.n0 = C.n1 = C.n2 = C.kd = C.k0 = C.k1 = C.k2 = C.X0 = C.X1 = C.X2 = C.conf = 0.f; C.nx = C.ny = 0;
 		const float4 cur = c.dn[idx];
 		float d = cur.x, n0 = cur.y, n1 = cur.z, n2 = cur.w;
 		if (!(c.dMin <= d && d < c.dMax)) {
-			d = random_depth(c, rand_unit(c.seed, (uint32_t)idx, st, 0u));
-			random_normal(G, rand_unit(c.seed, (uint32_t)idx, st, 1u), rand_unit(c.seed, (uint32_t)idx, st, 2u), n0, n1, n2);
+			d = random_depth(c, rand_unit(rk, 0u));
+			random_normal(G, rand_unit(rk, 1u), rand_unit(rk, 2u), n0, n1, n2);
 		} else if (dot3(n0, n1, n2, G.v0, G.v1, 1.f) >= 0.f) {
-			random_normal(G, rand_unit(c.seed, (uint32_t)idx, st, 1u), rand_unit(c.seed, (uint32_t)idx, st, 2u), n0, n1, n2);
+			random_normal(G, rand_unit(rk, 1u), rand_unit(rk, 2u), n0, n1, n2);
 		}
-		const float s = score_pixel<S>(c, L, P, C, G, d, n0, n1, n2);
+		const float s = score_pixel<S>(c, L, P, C, 0ull, G, d, n0, n1, n2);
 		++evals;
+		taps += (unsigned)((P.a + 1) * (P.a + 1));
 		if (L.lane == 0) {
 			c.dn[idx] = make_float4(d, n0, n1, n2);
 			c.conf[idx] = s;
 		}
 	}
-	if (L.lane == 0 && evals) atomicAdd(evalsOut, (unsigned long long)evals);
+	if (L.lane == 0 && evals) {
+		atomicAdd(evalsOut, (unsigned long long)evals);
+		atomicAdd(evalsOut + 1, (unsigned long long)evals);
+		atomicAdd(evalsOut + 2, taps);
+	}
 }
 
 // SceneDensify.cpp:688-744 EndDepthMapTmp (finalPass) or plain export of the working state
@@ -673,6 +1024,13 @@ __global__ void median3_kernel(const float* in, float* out, int W, int H) {
 // ------------------------------------------------------------------------------------------------------
 // launch wrappers
 
+#ifdef HCMVS_STAMPS
+void debug_read_stamps(unsigned long long* out, int reset) {
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+	if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z); }
+}
+#endif
+
 static inline int segments_for(int V) { return V <= 1 ? 64 : (V <= 2 ? 32 : (V <= 4 ? 16 : (V <= 8 ? 8 : 4))); }
 
 void launch_gray_to_u8(const float* gray, uint8_t* out, int n, hipStream_t s) {
@@ -701,18 +1059,29 @@ void launch_score_pass(const EstConst& c, const float* depthIn, const float* nor
 	}
 }
 
-void launch_sweep(const EstConst& c, const SweepSync& sync, int iter, int lag, hipStream_t s) {
+template <int NW>
+static void launch_sweep_nw(const EstConst& c, const SweepSync& sync, int iter, int lag, hipStream_t s) {
 	const int nrows = c.H - 2 * kHalfWindow;
-	// one wave per workgroup; rows beyond the resident set are picked up through the ticket
+	// one workgroup per row; rows beyond the resident set are picked up through the ticket
 	int grid = nrows < 8192 ? nrows : 8192;
 	if (grid < 1) return;
-	const dim3 g(grid), b(64);
+	const dim3 g(grid), b(64 * NW);
 	switch (segments_for(c.V)) {
-	case 64: hipLaunchKernelGGL(sweep_kernel<64>, g, b, 0, s, c, sync, iter, lag); break;
-	case 32: hipLaunchKernelGGL(sweep_kernel<32>, g, b, 0, s, c, sync, iter, lag); break;
-	case 16: hipLaunchKernelGGL(sweep_kernel<16>, g, b, 0, s, c, sync, iter, lag); break;
-	case 8: hipLaunchKernelGGL(sweep_kernel<8>, g, b, 0, s, c, sync, iter, lag); break;
-	default: hipLaunchKernelGGL(sweep_kernel<4>, g, b, 0, s, c, sync, iter, lag); break;
+	case 64: hipLaunchKernelGGL((sweep_kernel<64, NW>), g, b, 0, s, c, sync, iter, lag); break;
+	case 32: hipLaunchKernelGGL((sweep_kernel<32, NW>), g, b, 0, s, c, sync, iter, lag); break;
+	case 16: hipLaunchKernelGGL((sweep_kernel<16, NW>), g, b, 0, s, c, sync, iter, lag); break;
+	case 8: hipLaunchKernelGGL((sweep_kernel<8, NW>), g, b, 0, s, c, sync, iter, lag); break;
+	default: hipLaunchKernelGGL((sweep_kernel<4, NW>), g, b, 0, s, c, sync, iter, lag); break;
+	}
+}
+void launch_sweep(const EstConst& c, const SweepSync& sync, int iter, int lag, int wavesPerRow, hipStream_t s) {
+	switch (wavesPerRow) {
+	case 1: launch_sweep_nw<1>(c, sync, iter, lag, s); break;
+	case 2: launch_sweep_nw<2>(c, sync, iter, lag, s); break;
+	case 3: launch_sweep_nw<3>(c, sync, iter, lag, s); break;
+	case 6: launch_sweep_nw<6>(c, sync, iter, lag, s); break;
+	case 8: launch_sweep_nw<8>(c, sync, iter, lag, s); break;
+	default: launch_sweep_nw<4>(c, sync, iter, lag, s); break;
 	}
 }
 

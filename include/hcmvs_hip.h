@@ -72,7 +72,9 @@ typedef struct {
 } hcmvs_params;
 
 typedef struct {
-	uint64_t evals;       /* ScorePixel evaluations of the last estimate (each covers all source views) */
+	uint64_t evals;       /* ScorePixel evaluations of the sequential algorithm (each covers all source views) */
+	uint64_t evals_issued;/* evaluations the device executed, including discarded speculative ones */
+	uint64_t tap_evals;   /* sum over `evals` of the patch taps each one samples per source view (36/49/64) */
 	float ms_score;       /* device time of the init-score pass (HIP events on the context's stream) */
 	float ms_sweeps;      /* device time of all propagate/refine sweeps */
 	float ms_sweep_avg;   /* average duration of one sweep kernel launch */

@@ -12,7 +12,7 @@
  *     incremental warp, H = (Hl + Hm n^T/(n.X0 d)) Hr in double);
  *   HCOR_ARITH_DEVICE evaluates the same quantities in the association the gfx950 kernels use
  *     (per-segment partial sums + xor butterfly, direct per-tap warp with fmaf, one IEEE reciprocal
- *     per tap, H = Hl Hr + Hm (Hr^T n)^T/(n.X0 d), portable_math.h transcendental functions) so that
+ *     per tap, H = Hl Hr + Hm (Hr^T n)^T/(n.X0 d) in float, portable_math.h transcendental functions) so that
  *     the GPU result can be compared BIT FOR BIT.
  *
  * Deliberate, documented departures from the reference (it is nondeterministic / undefined there):
@@ -268,6 +268,8 @@ typedef struct {
 	const mathtab* mt;
 	double Hl[HCOR_MAX_VIEWS][9], Hm[HCOR_MAX_VIEWS][3], Hr[9]; /* DM.h:412-444 */
 	double A[HCOR_MAX_VIEWS][9];                                 /* Hl*Hr (device association) */
+	float Af[HCOR_MAX_VIEWS][9], Hmf[HCOR_MAX_VIEWS][3], Hrf[9]; /* ... rounded to float: what the kernels hold */
+	double ifx, ify;                                             /* device association multiplies by 1/f */
 	int S;                                                       /* device: segments per view */
 	float dMin, dMax, dMinSqr, dMaxSqr;
 	float smoothBonusDepth, smoothBonusNormal, smoothSigmaDepth, smoothSigmaNormal;
@@ -297,7 +299,11 @@ static void ctx_init(est_ctx* c, const hcor_view* ref, const hcor_view* srcs, in
 		const double dC[3] = {ref->C[0] - srcs[v].C[0], ref->C[1] - srcs[v].C[1], ref->C[2] - srcs[v].C[2]};
 		for (int i = 0; i < 3; ++i) c->Hm[v][i] = KR[i * 3] * dC[0] + KR[i * 3 + 1] * dC[1] + KR[i * 3 + 2] * dC[2];
 		mat3_mul(c->Hl[v], c->Hr, c->A[v]);
+		for (int i = 0; i < 9; ++i) c->Af[v][i] = (float)c->A[v][i];
+		for (int i = 0; i < 3; ++i) c->Hmf[v][i] = (float)c->Hm[v][i];
 	}
+	for (int i = 0; i < 9; ++i) c->Hrf[i] = (float)c->Hr[i];
+	c->ifx = 1.0 / ref->K[0]; c->ify = 1.0 / ref->K[4];
 	c->S = device_segments(V);
 	c->dMin = dMin; c->dMax = dMax;
 	c->dMinSqr = sqrtf(dMin); c->dMaxSqr = sqrtf(dMax);
@@ -331,6 +337,24 @@ typedef struct {
 static inline int border_ok(const hcor_view* ref, int x, int y) { /* DM.cpp:442-447 */
 	return x - HCOR_HALF_WINDOW >= 0 && y - HCOR_HALF_WINDOW >= 0 && x + HCOR_HALF_WINDOW < ref->width &&
 	       y + HCOR_HALF_WINDOW < ref->height;
+}
+
+/* device association: tap handled by segment seg at step m (same mapping as the kernels' tap_offset) */
+static int dev_tap(int S, int a, int seg, int m, int* ti, int* tj) {
+	const int nside = a + 1;
+	int row, col;
+	if (S >= 8) {
+		const int RH = 64 / S;
+		col = seg & 7;
+		row = (seg >> 3) * RH + m;
+	} else {
+		col = seg * 2 + (m >> 3);
+		row = m & 7;
+	}
+	const int valid = row < nside && col < nside;
+	*ti = row < nside ? row : nside - 1;
+	*tj = col < nside ? col : nside - 1;
+	return valid;
 }
 
 /* butterfly-ordered sum of S partials (device association): p[s] += p[s^step], step = 1,2,4,.. */
@@ -378,18 +402,26 @@ static void fill_patch(const est_ctx* c, pix_state* ps, int x, int y) {
 		}
 		ps->sumW = sw; ps->normSq0 = nrm;
 	} else {
-		const int S = c->S;
+		const int S = c->S, MAXM = 64 / S, nside = ps->nside;
 		float pa[64], pb[64];
 		for (int s = 0; s < S; ++s) {
 			float sa = 0, sb = 0;
-			for (int k = s; k < n; k += S) { sa = fmaf(I[k], ps->w[k], sa); sb = sb + ps->w[k]; }
+			for (int m = 0; m < MAXM; ++m) {
+				int ti, tj;
+				if (!dev_tap(S, a, s, m, &ti, &tj)) continue;
+				const int k = ti * nside + tj;
+				sa = fmaf(I[k], ps->w[k], sa); sb = sb + ps->w[k];
+			}
 			pa[s] = sa; pb[s] = sb;
 		}
 		const float swi = butterfly_sum(pa, S), sw = butterfly_sum(pb, S);
 		const float tm = swi / sw;
 		for (int s = 0; s < S; ++s) {
 			float sa = 0;
-			for (int k = s; k < n; k += S) {
+			for (int m = 0; m < MAXM; ++m) {
+				int ti, tj;
+				if (!dev_tap(S, a, s, m, &ti, &tj)) continue;
+				const int k = ti * nside + tj;
 				const float t = I[k] - tm;
 				ps->tw[k] = ps->w[k] * t;
 				sa = fmaf(ps->tw[k], t, sa);
@@ -399,8 +431,13 @@ static void fill_patch(const est_ctx* c, pix_state* ps, int x, int y) {
 		ps->sumW = sw; ps->normSq0 = butterfly_sum(pa, S);
 	}
 	/* DM.cpp:517, Camera.h:299-304 */
-	ps->X0[0] = ((double)x - ref->K[2]) / ref->K[0];
-	ps->X0[1] = ((double)y - ref->K[5]) / ref->K[4];
+	if (c->p.arith_mode == HCOR_ARITH_DEVICE) {
+		ps->X0[0] = ((double)x - ref->K[2]) * c->ifx;
+		ps->X0[1] = ((double)y - ref->K[5]) * c->ify;
+	} else {
+		ps->X0[0] = ((double)x - ref->K[2]) / ref->K[0];
+		ps->X0[1] = ((double)y - ref->K[5]) / ref->K[4];
+	}
 	ps->X0[2] = 1.0;
 	for (int i = 0; i < 3; ++i) ps->viewDir[i] = (float)ps->X0[i];
 	ps->nClose = 0;
@@ -419,14 +456,13 @@ static inline float sample_ref(const hcor_view* im, float px, float py) {
 }
 static inline float sample_dev(const hcor_view* im, float px, float py) {
 	const int lx = (int)px, ly = (int)py;
-	const float x = px - (float)lx, x1 = 1.f - x;
-	const float y = py - (float)ly, y1 = 1.f - y;
+	const float x = px - (float)lx;
+	const float y = py - (float)ly;
 	const float* r0 = im->gray + (size_t)ly * im->width + lx;
 	const float* r1 = r0 + im->width;
-	float t = r0[0] * x1; t = fmaf(r0[1], x, t);
-	float b = r1[0] * x1; b = fmaf(r1[1], x, b);
-	float v = t * y1;
-	return fmaf(b, y, v);
+	const float t = fmaf(x, r0[1] - r0[0], r0[0]);
+	const float b = fmaf(x, r1[1] - r1[0], r1[0]);
+	return fmaf(y, b - t, t);
 }
 static inline int inside_border1(const hcor_view* im, float px, float py) { /* Types.h:1633-1635 */
 	return px >= 1.f && py >= 1.f && px <= (float)(im->width - 2) && py <= (float)(im->height - 2);
@@ -495,33 +531,56 @@ static float score_view_ref(const est_ctx* c, const pix_state* ps, int v, float 
 
 /* device association of the same computation */
 static void device_H(const est_ctx* c, const pix_state* ps, int v, float depth, const float* normal, float* H) {
-	const double n0 = normal[0], n1 = normal[1], n2 = normal[2];
-	const double nx0 = fma(n2, ps->X0[2], fma(n1, ps->X0[1], n0 * ps->X0[0]));
-	const double inv = 1.0 / (nx0 * (double)depth);
-	double q[3];
-	for (int j = 0; j < 3; ++j) q[j] = fma(n2, c->Hr[6 + j], fma(n1, c->Hr[3 + j], n0 * c->Hr[j])) * inv;
+	const float n0 = normal[0], n1 = normal[1], n2 = normal[2];
+	const float nx0 = fmaf(n2, 1.0f, fmaf(n1, ps->viewDir[1], n0 * ps->viewDir[0]));
+	const float inv = 1.0f / (nx0 * depth);
+	float q[3];
+	for (int j = 0; j < 3; ++j) q[j] = fmaf(n2, c->Hrf[6 + j], fmaf(n1, c->Hrf[3 + j], n0 * c->Hrf[j])) * inv;
 	for (int i = 0; i < 3; ++i)
-		for (int j = 0; j < 3; ++j) H[i * 3 + j] = (float)fma(c->Hm[v][i], q[j], c->A[v][i * 3 + j]);
+		for (int j = 0; j < 3; ++j) H[i * 3 + j] = fmaf(c->Hmf[v][i], q[j], c->Af[v][i * 3 + j]);
 }
 static float score_view_dev(const est_ctx* c, const pix_state* ps, int v, float depth, const float* normal,
                             const float* sf, int nsf) {
 	const hcor_view* im = &c->srcs[v];
 	float H[9];
 	device_H(c, ps, v, depth, normal, H);
-	const int a = ps->a, nside = ps->nside, n = ps->ntaps, S = c->S;
+	const int a = ps->a, nside = ps->nside, S = c->S;
+	const int MAXM = 64 / S; /* taps per lane; lanes past the patch repeat the last tap with zero weight */
 	float p0[64], p1[64], p2[64];
 	int ok = 1;
 	for (int s = 0; s < S; ++s) {
-		float sum = 0, sumSq = 0, num = 0;
-		for (int k = s; k < n; k += S) {
-			const int ti = k / nside, tj = k - ti * nside;
+		float Xx[64], Xy[64], Xz[64], iz[64];
+		int kk[64];
+		int vv[64];
+		for (int m = 0; m < MAXM; ++m) {
+			int ti, tj;
+			vv[m] = dev_tap(S, a, s, m, &ti, &tj);
+			kk[m] = ti * nside + tj;
 			const float px = (float)(ps->x - a + 2 * tj), py = (float)(ps->y - a + 2 * ti);
-			const float Xx = fmaf(H[0], px, fmaf(H[1], py, H[2]));
-			const float Xy = fmaf(H[3], px, fmaf(H[4], py, H[5]));
-			const float Xz = fmaf(H[6], px, fmaf(H[7], py, H[8]));
-			const float iz = 1.0f / Xz;
-			const float qx = Xx * iz, qy = Xy * iz;
+			Xx[m] = fmaf(H[0], px, fmaf(H[1], py, H[2]));
+			Xy[m] = fmaf(H[3], px, fmaf(H[4], py, H[5]));
+			Xz[m] = fmaf(H[6], px, fmaf(H[7], py, H[8]));
+		}
+		if (MAXM >= 4) { /* one IEEE reciprocal per group of four taps */
+			for (int g = 0; g < MAXM; g += 4) {
+				const float q01 = Xz[g] * Xz[g + 1], q23 = Xz[g + 2] * Xz[g + 3];
+				const float r = 1.0f / (q01 * q23);
+				const float r01 = r * q23, r23 = r * q01;
+				iz[g] = r01 * Xz[g + 1]; iz[g + 1] = r01 * Xz[g];
+				iz[g + 2] = r23 * Xz[g + 3]; iz[g + 3] = r23 * Xz[g + 2];
+			}
+		} else if (MAXM == 2) {
+			const float r = 1.0f / (Xz[0] * Xz[1]);
+			iz[0] = r * Xz[1]; iz[1] = r * Xz[0];
+		} else {
+			iz[0] = 1.0f / Xz[0];
+		}
+		float sum = 0, sumSq = 0, num = 0;
+		for (int m = 0; m < MAXM; ++m) {
+			const float qx = Xx[m] * iz[m], qy = Xy[m] * iz[m];
 			if (!inside_border1(im, qx, qy)) { ok = 0; continue; }
+			if (!vv[m]) continue; /* clamped duplicate of a real tap: zero weight */
+			const int k = kk[m];
 			const float val = sample_dev(im, qx, qy);
 			const float vw = val * ps->w[k];
 			sum = sum + vw;
@@ -605,7 +664,11 @@ static float interpolate_pixel(const est_ctx* c, const pix_state* ps, int nx, in
 	const hcor_view* ref = c->ref;
 	const double pn[3] = {normal[0], normal[1], normal[2]};
 	const double z = depth;
-	const double P[3] = {((double)nx - ref->K[2]) * z / ref->K[0], ((double)ny - ref->K[5]) * z / ref->K[4], z};
+	double P[3] = {((double)nx - ref->K[2]) * z / ref->K[0], ((double)ny - ref->K[5]) * z / ref->K[4], z};
+	if (c->p.arith_mode == HCOR_ARITH_DEVICE) {
+		P[0] = ((double)nx - ref->K[2]) * z * c->ifx;
+		P[1] = ((double)ny - ref->K[5]) * z * c->ify;
+	}
 	const double planeD = pn[0] * P[0] + pn[1] * P[1] + pn[2] * P[2];
 	const float dn = (float)(planeD / (pn[0] * ps->X0[0] + pn[1] * ps->X0[1] + pn[2] * ps->X0[2]));
 	return (c->dMin <= dn && dn < c->dMax) ? dn : depth;
@@ -706,8 +769,13 @@ static void add_close(const est_ctx* c, pix_state* ps, int nx, int ny, float nd,
 	ps->cNormal[k][0] = nmap[3 * nidx]; ps->cNormal[k][1] = nmap[3 * nidx + 1]; ps->cNormal[k][2] = nmap[3 * nidx + 2];
 	/* Cast<float>(camera.TransformPointI2C(Point3(nx, ndepth))), Camera.h:306-312 */
 	const double z = nd;
-	ps->cX[k][0] = (float)(((double)nx - ref->K[2]) * z / ref->K[0]);
-	ps->cX[k][1] = (float)(((double)ny - ref->K[5]) * z / ref->K[4]);
+	if (c->p.arith_mode == HCOR_ARITH_DEVICE) {
+		ps->cX[k][0] = (float)(((double)nx - ref->K[2]) * z * c->ifx);
+		ps->cX[k][1] = (float)(((double)ny - ref->K[5]) * z * c->ify);
+	} else {
+		ps->cX[k][0] = (float)(((double)nx - ref->K[2]) * z / ref->K[0]);
+		ps->cX[k][1] = (float)(((double)ny - ref->K[5]) * z / ref->K[4]);
+	}
 	ps->cX[k][2] = (float)z;
 }
 

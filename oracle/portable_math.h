@@ -5,11 +5,10 @@
  * (expf / sinf / cosf / acosf / atan2f: DepthMap.h:547 GetWeight, DepthMap.cpp:609-613 smoothness,
  * Util.inl:614-626 Normal2Dir/Dir2Normal, DepthMap.h:629-634 CorrectNormal).
  *
- * They are built ONLY from IEEE-754 double add/mul/div/sqrt/fma/floor, so the same operation sequence
- * gives the same bits on the host CPU and on gfx950 (the HIP side carries its own copy of this
- * sequence in hc-mvs_amd/csrc/pm_math.h).  Results are evaluated in double and rounded once to float:
- * they agree with glibc's correctly-rounded-in-practice float functions except for rare 1-ulp cases
- * (checked in tests/test_oracle_math.py).  Used when arith_mode == HCOR_ARITH_DEVICE; the
+ * They are built ONLY from IEEE-754 binary32 add/mul/div/sqrt/fmaf/floorf, so the same operation
+ * sequence gives the same bits on the host CPU and on gfx950 (the HIP side carries its own copy of this
+ * sequence in hc-mvs_amd/csrc/pm_math.h).  Accuracy is within ~2 ulp of libm over the ranges the path
+ * uses (checked in tests/test_oracle_math.py).  Used when arith_mode == HCOR_ARITH_DEVICE; the
  * reference-faithful mode (HCOR_ARITH_REFERENCE) calls libm exactly like the reference does.
  */
 #ifndef HCOR_PORTABLE_MATH_H
@@ -19,134 +18,120 @@
 #include <stdint.h>
 #include <string.h>
 
-#define PM_PI      0x1.921fb54442d18p+1
-#define PM_PIO2    0x1.921fb54442d18p+0
-#define PM_PIO2_HI 0x1.921fb50000000p+0
-#define PM_PIO2_LO 0x1.110b4611a6263p-26
-#define PM_2OPI    0x1.45f306dc9c883p-1 /* 2/pi */
-#define PM_LN2_HI  0x1.62e42f8000000p-1
-#define PM_LN2_LO  0x1.be8e7bcd5e4f2p-27
-#define PM_INVLN2  0x1.71547652b82fep+0
+#define PM_PI_F      0x1.921fb6p+1f
+#define PM_PI_LO_F   (-0x1.777a5cp-24f)  /* pi - (float)pi */
+#define PM_PIO2_F    0x1.921fb6p+0f
+#define PM_PIO2_LO_F (-0x1.777a5cp-25f)
+#define PM_PIO4_F    0x1.921fb6p-1f
+#define PM_2OPI_F    0x1.45f306p-1f
+#define PM_PIO2_HI_F 0x1.92p+0f         /* 3-part Cody-Waite split of pi/2 */
+#define PM_PIO2_MI_F 0x1.fb4p-12f
+#define PM_PIO2_LO3_F 0x1.4442d2p-24f
+#define PM_LN2_HI_F  0x1.62ep-1f
+#define PM_LN2_LO_F  0x1.0bfbe8p-15f
+#define PM_INVLN2_F  0x1.715476p+0f
+#define PM_TANPIO8_F 0x1.a8279ap-2f
 
-static inline double pm_pow2i(int k) { /* 2^k, -1022 <= k <= 1023 */
-	uint64_t b = (uint64_t)(k + 1023) << 52;
-	double d;
-	memcpy(&d, &b, sizeof d);
-	return d;
-}
+static inline float pm_bits2f(uint32_t b) { float f; memcpy(&f, &b, sizeof f); return f; }
 
-/* e^x rounded to float; x float */
+/* e^x, x float.  Results below 2^-126 flush to 0 (inputs below -87) */
 static inline float pm_expf(float x) {
-	if (!(x > -104.0f)) return (x != x) ? x : 0.0f;
-	if (x > 88.75f) return INFINITY;
-	const double xd = (double)x;
-	const double kd = floor(fma(xd, PM_INVLN2, 0.5));
-	double r = fma(-kd, PM_LN2_HI, xd);
-	r = fma(-kd, PM_LN2_LO, r); /* |r| <= 0.3466 */
-	/* Taylor, degree 11 (remainder < 1e-15 relative) */
-	double p = 1.0 / 39916800.0;
-	p = fma(p, r, 1.0 / 3628800.0);
-	p = fma(p, r, 1.0 / 362880.0);
-	p = fma(p, r, 1.0 / 40320.0);
-	p = fma(p, r, 1.0 / 5040.0);
-	p = fma(p, r, 1.0 / 720.0);
-	p = fma(p, r, 1.0 / 120.0);
-	p = fma(p, r, 1.0 / 24.0);
-	p = fma(p, r, 1.0 / 6.0);
-	p = fma(p, r, 0.5);
-	p = fma(p, r, 1.0);
-	p = fma(p, r, 1.0);
-	return (float)(p * pm_pow2i((int)kd));
+	if (!(x > -87.0f)) return (x != x) ? x : 0.0f;
+	if (x > 88.0f) return INFINITY;
+	const float kf = floorf(fmaf(x, PM_INVLN2_F, 0.5f));
+	float r = fmaf(-kf, PM_LN2_HI_F, x);
+	r = fmaf(-kf, PM_LN2_LO_F, r); /* |r| <= 0.3466 */
+	float p = 1.0f / 5040.0f;
+	p = fmaf(p, r, 1.0f / 720.0f);
+	p = fmaf(p, r, 1.0f / 120.0f);
+	p = fmaf(p, r, 1.0f / 24.0f);
+	p = fmaf(p, r, 1.0f / 6.0f);
+	p = fmaf(p, r, 0.5f);
+	p = fmaf(p, r, 1.0f);
+	p = fmaf(p, r, 1.0f);
+	return p * pm_bits2f((uint32_t)((int)kf + 127) << 23);
 }
 
-/* sin and cos of a float angle (|x| well below 2^20), each rounded to float */
+/* sin and cos of a float angle, |x| < ~100 */
 static inline void pm_sincosf(float x, float* s, float* c) {
-	const double xd = (double)x;
-	const double kd = floor(fma(xd, PM_2OPI, 0.5));
-	double r = fma(-kd, PM_PIO2_HI, xd);
-	r = fma(-kd, PM_PIO2_LO, r); /* |r| <= pi/4 */
-	const double r2 = r * r;
-	/* sin(r) = r + r^3 * S(r^2), Taylor through r^15 */
-	double ps = -1.0 / 1307674368000.0;
-	ps = fma(ps, r2, 1.0 / 6227020800.0);
-	ps = fma(ps, r2, -1.0 / 39916800.0);
-	ps = fma(ps, r2, 1.0 / 362880.0);
-	ps = fma(ps, r2, -1.0 / 5040.0);
-	ps = fma(ps, r2, 1.0 / 120.0);
-	ps = fma(ps, r2, -1.0 / 6.0);
-	const double sr = fma(ps * r2, r, r);
-	/* cos(r) = 1 + r^2 * C(r^2), Taylor through r^16 */
-	double pc = 1.0 / 20922789888000.0;
-	pc = fma(pc, r2, -1.0 / 87178291200.0);
-	pc = fma(pc, r2, 1.0 / 479001600.0);
-	pc = fma(pc, r2, -1.0 / 3628800.0);
-	pc = fma(pc, r2, 1.0 / 40320.0);
-	pc = fma(pc, r2, -1.0 / 720.0);
-	pc = fma(pc, r2, 1.0 / 24.0);
-	pc = fma(pc, r2, -0.5);
-	const double cr = fma(pc, r2, 1.0);
-	const int q = (int)kd & 3;
-	double sv, cv;
+	const float kf = floorf(fmaf(x, PM_2OPI_F, 0.5f));
+	float r = fmaf(-kf, PM_PIO2_HI_F, x);
+	r = fmaf(-kf, PM_PIO2_MI_F, r);
+	r = fmaf(-kf, PM_PIO2_LO3_F, r); /* |r| <= pi/4 */
+	const float r2 = r * r;
+	float ps = 1.0f / 362880.0f;
+	ps = fmaf(ps, r2, -1.0f / 5040.0f);
+	ps = fmaf(ps, r2, 1.0f / 120.0f);
+	ps = fmaf(ps, r2, -1.0f / 6.0f);
+	const float sr = fmaf(ps * r2, r, r);
+	float pc = -1.0f / 3628800.0f;
+	pc = fmaf(pc, r2, 1.0f / 40320.0f);
+	pc = fmaf(pc, r2, -1.0f / 720.0f);
+	pc = fmaf(pc, r2, 1.0f / 24.0f);
+	pc = fmaf(pc, r2, -0.5f);
+	const float cr = fmaf(pc, r2, 1.0f);
+	const int q = (int)kf & 3;
+	float sv, cv;
 	if (q == 0) { sv = sr; cv = cr; }
 	else if (q == 1) { sv = cr; cv = -sr; }
 	else if (q == 2) { sv = -sr; cv = -cr; }
 	else { sv = -cr; cv = sr; }
-	*s = (float)sv;
-	*c = (float)cv;
+	*s = sv;
+	*c = cv;
 }
 static inline float pm_sinf(float x) { float s, c; pm_sincosf(x, &s, &c); return s; }
 static inline float pm_cosf(float x) { float s, c; pm_sincosf(x, &s, &c); return c; }
 
-/* atan(t) for t >= 0 (double in, double out, ~1e-16) */
-static inline double pm_atan_pos(double t) {
-	int inv = 0;
-	if (t > 1.0) { t = 1.0 / t; inv = 1; }
-	/* nearest of c = i/8, i = 0..8 ; atan(t) = atan(c) + atan((t-c)/(1+t*c)) */
-	const int i = (int)floor(fma(t, 8.0, 0.5));
-	static const double ATAN_C[9] = {
-		0.0,
-		0x1.fd5ba9aac2f6ep-4, 0x1.f5b75f92c80ddp-3, 0x1.6f61941e4def1p-2, 0x1.dac670561bb4fp-2,
-		0x1.1e00babdefeb4p-1, 0x1.4978fa3269ee1p-1, 0x1.700a7c5784634p-1, 0x1.921fb54442d18p-1};
-	const double c = (double)i * 0.125;
-	const double u = (t - c) / fma(t, c, 1.0); /* |u| <= 1/16 */
-	const double u2 = u * u;
-	double p = 1.0 / 15.0;
-	p = fma(p, u2, -1.0 / 13.0);
-	p = fma(p, u2, 1.0 / 11.0);
-	p = fma(p, u2, -1.0 / 9.0);
-	p = fma(p, u2, 1.0 / 7.0);
-	p = fma(p, u2, -1.0 / 5.0);
-	p = fma(p, u2, 1.0 / 3.0);
-	p = -p; /* atan(u) = u - u^3/3 + u^5/5 ... = u + u^3 * (-(1/3 - u^2/5 + ...)) */
-	const double au = fma(p * u2, u, u);
-	const double a = ATAN_C[i] + au;
-	return inv ? (PM_PIO2 - a) : a;
+/* asin(sqrt(z))/sqrt(z) = 1 + z*R(z) on z in [0, 0.25] */
+static inline float pm_asin_r(float z) {
+	float p = 0x1.14efcap-5f;
+	p = fmaf(p, z, 0x1.17cdbcp-6f);
+	p = fmaf(p, z, 0x1.fdce9ep-6f);
+	p = fmaf(p, z, 0x1.6d58dap-5f);
+	p = fmaf(p, z, 0x1.33343cp-4f);
+	p = fmaf(p, z, 0x1.555554p-3f);
+	return p;
 }
-
-/* atan2(y, x) rounded to float */
-static inline float pm_atan2f(float y, float x) {
-	const double yd = (double)y, xd = (double)x;
-	if (x != x || y != y) return x + y;
-	if (yd == 0.0) {
-		if (xd > 0.0 || (xd == 0.0 && !signbit(x))) return y;               /* +-0 */
-		return signbit(y) ? (float)-PM_PI : (float)PM_PI;
-	}
-	if (xd == 0.0) return yd > 0.0 ? (float)PM_PIO2 : (float)-PM_PIO2;
-	const double ay = fabs(yd), ax = fabs(xd);
-	double a = pm_atan_pos(ay / ax);
-	if (xd < 0.0) a = PM_PI - a;
-	return (float)(yd < 0.0 ? -a : a);
-}
-
-/* acos(x) rounded to float; |x| >= 1 clamps to the end points (libm would return NaN beyond them) */
+/* acos(x); |x| >= 1 clamps to the end points (libm returns NaN beyond them) */
 static inline float pm_acosf(float x) {
 	if (x != x) return x;
-	if (x >= 1.0f) return 0.0f;
-	if (x <= -1.0f) return (float)PM_PI;
-	const double xd = (double)x;
-	/* acos(x) = 2 atan( sqrt((1-x)/(1+x)) ) ; 1-x and 1+x are exact in double */
-	const double t = sqrt((1.0 - xd) / (1.0 + xd));
-	return (float)(2.0 * pm_atan_pos(t));
+	const float ax = fabsf(x);
+	if (ax >= 1.0f) return x > 0.0f ? 0.0f : PM_PI_F;
+	if (ax <= 0.5f) {
+		const float z = x * x;
+		const float a = fmaf(x * z, pm_asin_r(z), x); /* asin(x) */
+		return (PM_PIO2_F - a) + PM_PIO2_LO_F;
+	}
+	const float z = (1.0f - ax) * 0.5f;
+	const float s = sqrtf(z);
+	const float t = fmaf(s * z, pm_asin_r(z), s); /* asin(sqrt(z)) = acos(ax)/2 */
+	if (x > 0.0f) return 2.0f * t;
+	return (PM_PI_F - 2.0f * t) + PM_PI_LO_F;
+}
+
+/* atan2(y, x) */
+static inline float pm_atan2f(float y, float x) {
+	if (x != x || y != y) return x + y;
+	const float ax = fabsf(x), ay = fabsf(y);
+	if (ay == 0.0f) {
+		if (x > 0.0f || (x == 0.0f && !signbit(x))) return y; /* +-0 */
+		return signbit(y) ? -PM_PI_F : PM_PI_F;
+	}
+	if (ax == 0.0f) return y > 0.0f ? PM_PIO2_F : -PM_PIO2_F;
+	const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+	const float t = mn / mx; /* [0,1] */
+	float u = t, base = 0.0f;
+	if (t > PM_TANPIO8_F) { u = (t - 1.0f) / (t + 1.0f); base = PM_PIO4_F; }
+	const float w = u * u;
+	float p = -0x1.089378p-4f;
+	p = fmaf(p, w, 0x1.b82b1cp-4f);
+	p = fmaf(p, w, -0x1.2421a8p-3f);
+	p = fmaf(p, w, 0x1.99973ep-3f);
+	p = fmaf(p, w, -0x1.555554p-2f);
+	float a = fmaf(u * w, p, u) + base; /* atan(mn/mx) in [0, pi/4] */
+	if (ay > ax) a = PM_PIO2_F - a;
+	if (x < 0.0f) a = PM_PI_F - a;
+	return y < 0.0f ? -a : a;
 }
 
 #endif
