@@ -43,7 +43,8 @@ _lib = None
 SYMBOLS = ["hcmvs_default_params", "hcmvs_create", "hcmvs_destroy", "hcmvs_last_error", "hcmvs_set_stream",
            "hcmvs_synchronize", "hcmvs_upload_view", "hcmvs_set_view_device", "hcmvs_release_view",
            "hcmvs_get_gradient_map", "hcmvs_estimate", "hcmvs_estimate_device", "hcmvs_get_stats",
-           "hcmvs_splat_init"]
+           "hcmvs_splat_init", "hcmvs_set_depthmap", "hcmvs_set_depthmap_device", "hcmvs_get_depthmap",
+           "hcmvs_set_neighbors", "hcmvs_filter", "hcmvs_fuse"]
 
 
 def lib():
@@ -80,6 +81,15 @@ def lib():
                                             vp, vp, vp]
         L.hcmvs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.hcmvs_splat_init.argtypes = [vp, C.c_uint32, fp, C.c_int32, fp, fp, fp, fp]
+        u64p = C.POINTER(C.c_uint64)
+        L.hcmvs_set_depthmap.argtypes = [vp, C.c_uint32, fp, fp, fp, C.c_float, C.c_float]
+        L.hcmvs_set_depthmap_device.argtypes = [vp, C.c_uint32, vp, vp, vp, C.c_float, C.c_float]
+        L.hcmvs_get_depthmap.argtypes = [vp, C.c_uint32, fp, fp, fp]
+        L.hcmvs_set_neighbors.argtypes = [vp, C.c_uint32, u32p, C.c_int32]
+        L.hcmvs_filter.argtypes = [vp, C.c_uint32, u32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, fp, fp,
+                                   u64p, u64p]
+        L.hcmvs_fuse.argtypes = [vp, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint64,
+                                 fp, fp, u8p, u32p, u64p, u64p]
         _lib = L
     return _lib
 
@@ -193,3 +203,47 @@ class Context:
         s = Stats()
         self._chk(lib().hcmvs_get_stats(self._h, C.byref(s)))
         return s
+
+    # ---- filter / fuse (SceneDensify.h:69-70) -----------------------------------------------------------
+
+    def set_depthmap(self, vid, depth, normal, conf, d_min, d_max):
+        d = np.ascontiguousarray(depth, np.float32); c = np.ascontiguousarray(conf, np.float32)
+        n = None if normal is None else np.ascontiguousarray(normal, np.float32)
+        self._chk(lib().hcmvs_set_depthmap(self._h, vid, _f(d), None if n is None else _f(n), _f(c), d_min, d_max))
+
+    def get_depthmap(self, vid):
+        h, w = self.shapes[vid]
+        d = np.empty((h, w), np.float32); c = np.empty((h, w), np.float32)
+        self._chk(lib().hcmvs_get_depthmap(self._h, vid, _f(d), None, _f(c)))
+        return d, c
+
+    def set_neighbors(self, vid, ids):
+        arr = (C.c_uint32 * max(len(ids), 1))(*ids)
+        self._chk(lib().hcmvs_set_neighbors(self._h, vid, arr, len(ids)))
+
+    def filter(self, ref_id, neighbor_ids, adjust=True, n_min_views=2, n_min_views_adjust=1, depth_diff_threshold=0.01):
+        """FilterDepthMap: returns (new_depth, new_conf, n_processed, n_discarded)"""
+        h, w = self.shapes[ref_id]
+        d = np.empty((h, w), np.float32); c = np.empty((h, w), np.float32)
+        ids = (C.c_uint32 * len(neighbor_ids))(*neighbor_ids)
+        npr = C.c_uint64(); nd = C.c_uint64()
+        self._chk(lib().hcmvs_filter(self._h, ref_id, ids, len(neighbor_ids), int(adjust), n_min_views, n_min_views_adjust,
+                                     depth_diff_threshold, _f(d), _f(c), C.byref(npr), C.byref(nd)))
+        return d, c, npr.value, nd.value
+
+    def fuse(self, order, capacity, n_min_views_fuse=2, depth_diff_threshold=0.01, normal_diff_deg=25.0, depthweight=1.0,
+             normalweight=1.0, with_normals=True, with_colors=True):
+        """FuseDepthMaps: returns dict(xyz, normal, bgr, n_views, n_points, n_depths)"""
+        xyz = np.zeros((capacity, 3), np.float32)
+        nrm = np.zeros((capacity, 3), np.float32) if with_normals else None
+        bgr = np.zeros((capacity, 3), np.uint8) if with_colors else None
+        nv = np.zeros(capacity, np.uint32)
+        ids = (C.c_uint32 * len(order))(*order)
+        npts = C.c_uint64(); nd = C.c_uint64()
+        self._chk(lib().hcmvs_fuse(self._h, ids, len(order), n_min_views_fuse, depth_diff_threshold, normal_diff_deg,
+                                   depthweight, normalweight, capacity, _f(xyz), None if nrm is None else _f(nrm),
+                                   None if bgr is None else bgr.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                   nv.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(npts), C.byref(nd)))
+        k = npts.value
+        return dict(xyz=xyz[:k], normal=None if nrm is None else nrm[:k], bgr=None if bgr is None else bgr[:k],
+                    n_views=nv[:k], n_points=k, n_depths=nd.value)

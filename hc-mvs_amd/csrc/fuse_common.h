@@ -1,0 +1,44 @@
+/*
+ * hc-mvs_amd/csrc/fuse_common.h -- structures shared by the host API and the filter / fuse kernels.
+ */
+#ifndef HCMVS_FUSE_COMMON_H
+#define HCMVS_FUSE_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hcmvs {
+
+constexpr int kFuseMaxViews = 32; // views merged into one point / estimates one point can invalidate
+
+// one image's estimated maps + camera as the filter / fuse kernels see it (DepthMap.h:214-262 DepthData)
+struct DevMap {
+	uint32_t id;
+	int32_t w, h, nNeighbors;
+	double K[9], R[9], C[3], P[12]; // P = K [R | -R C] (Camera.h:276-282)
+	float* depth;            // mutated by fusion (SceneDensify.cpp:3447-3449)
+	const float* normal;     // camera space, may be null
+	const float* conf;
+	const uint8_t* bgr;      // may be null
+	uint32_t* claim;         // SceneDensify.cpp:3313 arrDepthIdx: NO_ID or claimed
+	uint32_t* bid;           // lowest pending raster index projecting onto each pixel (fusion rounds)
+	const uint32_t* neighbors; // device array of image ids, decreasing importance
+	float dMin, dMax;
+};
+
+void launch_fill_u32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
+void launch_fill_u64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s);
+void launch_filter_splat(const DevMap& ref, const DevMap& nb, unsigned long long* key, hipStream_t s);
+void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsigned long long* keys, int adjust, int nMinViews,
+                        int nMinViewsAdjust, float thr, float* newDepth, float* newConf, unsigned long long* counters, hipStream_t s);
+void launch_fuse_begin(const DevMap& A, uint8_t* state, uint8_t* flag, unsigned long long* counters, hipStream_t s);
+void launch_fuse_bid(const DevMap& A, const DevMap* maps, uint8_t* state, int reset, hipStream_t s);
+void launch_fuse_decide(const DevMap& A, const DevMap* maps, uint8_t* state, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv,
+                        uint8_t* oflag, int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, hipStream_t s);
+size_t fuse_scan_temp_bytes(int n);
+void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,
+                         float* onormal, uint8_t* obgr, uint32_t* onv, unsigned long long base, unsigned long long capacity, float* xyz,
+                         float* normal, uint8_t* bgr, uint32_t* nviews, hipStream_t s);
+
+} // namespace hcmvs
+#endif

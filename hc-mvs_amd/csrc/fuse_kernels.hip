@@ -1,0 +1,385 @@
+/*
+ * hc-mvs_amd/csrc/fuse_kernels.hip -- gfx950 kernels of the depth-map filter and fusion passes.
+ *
+ * What the reference computes (paths under /root/reference/frame_main/libs/MVS/):
+ *   FilterDepthMap  SceneDensify.cpp:3006-3259  splat every neighbour map into the reference view
+ *                                               (4-pixel footprint, z-buffer), then a per-pixel vote
+ *   FuseDepthMaps   SceneDensify.cpp:3265-3495  single-threaded greedy merge: images in order, pixels in
+ *                                               raster order; a pixel claims agreeing pixels of its
+ *                                               neighbour maps and zeroes the estimates it occludes
+ *
+ * How it is mapped to the GPU:
+ *   - Filter: the z-buffer is a 64-bit atomicMin on (depth bits, ~sequence number), which reproduces the
+ *     sequential rule "nearest wins, the later writer wins ties" exactly; the vote is embarrassingly
+ *     parallel.  HBM-bound integer/float work, one thread per pixel, coalesced over the reference map.
+ *   - Fuse: a pixel of image A interacts with other pixels of A only through the neighbour pixels it
+ *     projects onto (its targets).  Per image pass, rounds of three small kernels pick, for every target,
+ *     the lowest raster index still pending (atomicMin), let exactly the pixels that own all their targets
+ *     run the reference's body, and reset.  Pixels sharing a target are therefore decided in raster order
+ *     and the cloud is identical to the sequential one, point order included (ordered compaction).
+ *
+ * Double precision follows the reference (Point3 = double); no contraction (-ffp-contract=off).
+ */
+#include "fuse_common.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace hcmvs {
+
+#define NO_ID 0xFFFFFFFFu
+
+__device__ __forceinline__ void i2w(const DevMap& m, double x, double y, double z, double* X) { // Camera.h:306-320
+	const double c0 = (x - m.K[2]) * z / m.K[0], c1 = (y - m.K[5]) * z / m.K[4], c2 = z;
+#pragma unroll
+	for (int i = 0; i < 3; ++i) X[i] = (m.R[0 * 3 + i] * c0 + m.R[1 * 3 + i] * c1 + m.R[2 * 3 + i] * c2) + m.C[i];
+}
+__device__ __forceinline__ void w2c(const DevMap& m, const double* X, double* c) { // Camera.h:357-359
+	const double d0 = X[0] - m.C[0], d1 = X[1] - m.C[1], d2 = X[2] - m.C[2];
+#pragma unroll
+	for (int i = 0; i < 3; ++i) c[i] = m.R[i * 3] * d0 + m.R[i * 3 + 1] * d1 + m.R[i * 3 + 2] * d2;
+}
+__device__ __forceinline__ bool is_depth_similar(float d0, float d1, float th) { return fabsf(d0 - d1) / d0 < th; }
+__device__ __forceinline__ float conf2weight(float conf, float depth) { // SceneDensify.cpp:154-156
+	const float a = 1.f - conf;
+	return 1.f / ((a > 0.03f ? a : 0.03f) * depth * depth);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// filter
+
+__global__ void filter_splat_kernel(DevMap ref, DevMap nb, unsigned long long* key) {
+	const int n = nb.w * nb.h;
+	for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+		const float depth = nb.depth[s];
+		if (depth == 0.f) continue;
+		const int j = s % nb.w, i = s / nb.w;
+		double X[3], c[3];
+		i2w(nb, (double)j, (double)i, (double)depth, X);
+		w2c(ref, X, c);
+		if (c[2] <= 0) continue;
+		const double ix = ref.K[2] + ref.K[0] * (c[0] / c[2]), iy = ref.K[5] + ref.K[4] * (c[1] / c[2]);
+		const int fx = (int)floor(ix), fy = (int)floor(iy), cx = (int)ceil(ix), cy = (int)ceil(iy);
+		const int xs[4] = {fx, fx, cx, cx}, ys[4] = {fy, cy, fy, cy};
+		const float z = (float)c[2];
+#pragma unroll
+		for (int p = 0; p < 4; ++p) {
+			if (xs[p] < 0 || ys[p] < 0 || xs[p] >= ref.w || ys[p] >= ref.h) continue;
+			// nearest depth wins; among equal depths the later (source raster, footprint) writer wins
+			const unsigned long long k = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(0xFFFFFFFFu - ((unsigned)s * 4u + (unsigned)p));
+			atomicMin(&key[(size_t)ys[p] * ref.w + xs[p]], k);
+		}
+	}
+}
+
+__device__ __forceinline__ float key_depth(unsigned long long k) { return k == ~0ull ? 0.f : __uint_as_float((unsigned)(k >> 32)); }
+__device__ __forceinline__ float key_conf(unsigned long long k, const float* conf) {
+	return k == ~0ull ? 0.f : conf[(0xFFFFFFFFu - (unsigned)k) >> 2];
+}
+
+__global__ void filter_vote_kernel(DevMap ref, const DevMap* nbs, int N, const unsigned long long* keys, int adjust, int nMinViews,
+                                   int nMinViewsAdjust, float fDepthDiffThreshold, float* newDepth, float* newConf,
+                                   unsigned long long* counters) {
+	const int W = ref.w, H = ref.h;
+	const size_t area = (size_t)W * H;
+	const float thDepthDiff = fDepthDiffThreshold * 1.2f;
+	unsigned nProc = 0, nDisc = 0;
+	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < W * H; idx += gridDim.x * blockDim.x) {
+		const int j = idx % W, i = idx / W;
+		const float depth = ref.depth[idx];
+		if (depth == 0.f) { newDepth[idx] = 0.f; newConf[idx] = 0.f; continue; }
+		++nProc;
+		if (adjust) { // SceneDensify.cpp:3097-3170
+			float posConf = ref.conf[idx], negConf = 0.f;
+			float avgDepth = depth * posConf;
+			unsigned nPos = 0, nNeg = 0;
+			int n = N;
+			bool discard = false;
+			do {
+				--n;
+				const unsigned long long k = keys[area * n + idx];
+				const float d = key_depth(k);
+				if (d == 0.f) {
+					if (nPos + nNeg + (unsigned)n < (unsigned)nMinViews) { discard = true; break; }
+					continue;
+				}
+				const float cproj = key_conf(k, nbs[n].conf);
+				if (is_depth_similar(depth, d, 0.12f)) {
+					avgDepth += d * cproj;
+					posConf += cproj;
+					++nPos;
+				} else {
+					if (depth > d) {
+						negConf += cproj;
+					} else {
+						const DevMap& nb = nbs[n];
+						double X[3], c[3];
+						i2w(ref, (double)j, (double)i, (double)depth, X);
+						w2c(nb, X, c);
+						const int x = (int)floor(nb.K[2] + nb.K[0] * (c[0] / c[2]) + .5);
+						const int y = (int)floor(nb.K[5] + nb.K[4] * (c[1] / c[2]) + .5);
+						if (x >= 0 && y >= 0 && x < nb.w && y < nb.h) {
+							const float cc = nb.conf[(size_t)y * nb.w + x];
+							negConf += (cc > 0.f ? cc : cproj);
+						} else
+							negConf += cproj;
+					}
+					++nNeg;
+				}
+			} while (n);
+			bool keep = false;
+			if (!discard && nPos >= (unsigned)nMinViewsAdjust && posConf > negConf) {
+				avgDepth /= posConf;
+				if (ref.dMin <= avgDepth && avgDepth < ref.dMax) { newDepth[idx] = avgDepth; newConf[idx] = posConf - negConf; keep = true; }
+			}
+			if (!keep) { newDepth[idx] = 0.f; newConf[idx] = 0.f; ++nDisc; }
+		} else { // SceneDensify.cpp:3171-3249
+			const float thStrict = fDepthDiffThreshold * 0.8f;
+			const unsigned nMinViewsDelta = (unsigned)nMinViews * 2u;
+			unsigned good = 0, views = 0;
+			for (int n = N; n-- > 0;) {
+				const float d = key_depth(keys[area * n + idx]);
+				if (d > 0.f) { ++views; if (is_depth_similar(depth, d, thStrict)) ++good; }
+			}
+			if (good < (unsigned)nMinViews || good < views * 75u / 100u) { newDepth[idx] = 0.f; newConf[idx] = 0.f; ++nDisc; continue; }
+			good = views = 0;
+			const int dx[4] = {-1, 1, 0, 0}, dy[4] = {0, 0, -1, 1};
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int xx = j + dx[q], yy = i + dy[q];
+				if (xx < 0 || yy < 0 || xx >= W || yy >= H) continue;
+				for (int n = N; n-- > 0;) {
+					const float d = key_depth(keys[area * n + (size_t)yy * W + xx]);
+					if (d > 0.f) { ++views; if (is_depth_similar(depth, d, thDepthDiff)) ++good; }
+				}
+			}
+			if (good < nMinViewsDelta || good < views * 65u / 100u) { newDepth[idx] = 0.f; newConf[idx] = 0.f; ++nDisc; continue; }
+			newDepth[idx] = depth; newConf[idx] = ref.conf[idx];
+		}
+	}
+	if (nProc) atomicAdd(&counters[0], (unsigned long long)nProc);
+	if (nDisc) atomicAdd(&counters[1], (unsigned long long)nDisc);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fuse
+
+// target of pixel `point` in neighbour map m: returns false when it projects behind / outside (SceneDensify.cpp:3387-3393)
+__device__ __forceinline__ bool project_target(const DevMap& m, const float* point, float& ptz, int& ib, int& xB, int& yB) {
+	const double* p = m.P;
+	const float ptx = (float)(p[0] * (double)point[0] + p[1] * (double)point[1] + p[2] * (double)point[2] + p[3]);
+	const float pty = (float)(p[4] * (double)point[0] + p[5] * (double)point[1] + p[6] * (double)point[2] + p[7]);
+	ptz = (float)(p[8] * (double)point[0] + p[9] * (double)point[1] + p[10] * (double)point[2] + p[11]);
+	if (ptz <= 0.f) return false;
+	xB = (int)floorf(ptx / ptz + .5f); yB = (int)floorf(pty / ptz + .5f);
+	if (xB < 0 || yB < 0 || xB >= m.w || yB >= m.h) return false;
+	ib = yB * m.w + xB;
+	return true;
+}
+__device__ __forceinline__ void pixel_point(const DevMap& A, int idx, float depth, float* point) {
+	double Xw[3];
+	i2w(A, (double)(idx % A.w), (double)(idx / A.w), (double)depth, Xw);
+	point[0] = (float)Xw[0]; point[1] = (float)Xw[1]; point[2] = (float)Xw[2];
+}
+
+// state: 0 = nothing to do, 1 = pending, 2 / 3 = accepted / rejected in this round, 4 / 5 = ... in an earlier round
+__global__ void fuse_begin_kernel(DevMap A, uint8_t* state, uint8_t* flag, unsigned long long* counters) {
+	const int n = A.w * A.h;
+	unsigned nd = 0, np = 0;
+	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+		uint8_t s = 0;
+		if (A.depth[idx] != 0.f) {
+			++nd;
+			if (A.claim[idx] == NO_ID) { s = 1; ++np; }
+		}
+		state[idx] = s;
+		flag[idx] = 0;
+	}
+	if (nd) atomicAdd(&counters[0], (unsigned long long)nd); // valid depths visited (SceneDensify.cpp:3359)
+	if (np) atomicAdd(&counters[1], (unsigned long long)np); // pending pixels
+}
+
+// reset == 0: every pending pixel bids for its targets.  reset != 0: pending pixels and the ones decided in this
+// round clear their targets again (states 2/3 then become 4/5 = done)
+__global__ void fuse_bid_kernel(DevMap A, const DevMap* maps, uint8_t* state, int reset) {
+	const int n = A.w * A.h;
+	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+		const uint8_t st = state[idx];
+		if (st != 1 && !(reset && (st == 2 || st == 3))) continue;
+		if (reset && st != 1) state[idx] = st + 2;
+		float point[3];
+		pixel_point(A, idx, A.depth[idx], point);
+		for (int q = 0; q < A.nNeighbors; ++q) {
+			const DevMap& B = maps[A.neighbors[q]];
+			if (!B.depth) continue;
+			float ptz; int ib, xB, yB;
+			if (!project_target(B, point, ptz, ib, xB, yB)) continue;
+			if (reset) B.bid[ib] = NO_ID;
+			else atomicMin(&B.bid[ib], (unsigned)idx);
+		}
+	}
+}
+
+struct FuseOut { // per pixel of the current image, compacted in raster order afterwards
+	float* xyz; float* normal; uint8_t* bgr; uint32_t* nviews; uint8_t* flag;
+};
+
+__global__ void fuse_decide_kernel(DevMap A, const DevMap* maps, uint8_t* state, FuseOut out, int nMinViewsFuse, float thDepth,
+                                   float normalError, unsigned long long* counters) {
+	const int n = A.w * A.h;
+	unsigned decided = 0, accepted = 0;
+	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+		if (state[idx] != 1) continue;
+		const float depth = A.depth[idx];
+		float point[3];
+		pixel_point(A, idx, depth, point);
+		// do I own every target?  (then no lower raster index is still undecided on any of them)
+		bool ready = true;
+		for (int q = 0; q < A.nNeighbors && ready; ++q) {
+			const DevMap& B = maps[A.neighbors[q]];
+			if (!B.depth) continue;
+			float ptz; int ib, xB, yB;
+			if (!project_target(B, point, ptz, ib, xB, yB)) continue;
+			ready = B.bid[ib] == (unsigned)idx;
+		}
+		if (!ready) continue;
+		++decided;
+		// the reference's body, SceneDensify.cpp:3364-3450
+		uint32_t vimg[kFuseMaxViews]; int vpix[kFuseMaxViews]; int nv = 0;
+		vimg[nv] = A.id; vpix[nv] = idx; ++nv;
+		double confidence = (double)conf2weight(A.conf[idx], depth);
+		float normal[3] = {0.f, 0.f, -1.f};
+		if (A.normal) {
+			const float* nm = A.normal + 3 * (size_t)idx;
+#pragma unroll
+			for (int k = 0; k < 3; ++k) normal[k] = (float)(A.R[0 * 3 + k] * (double)nm[0] + A.R[1 * 3 + k] * (double)nm[1] + A.R[2 * 3 + k] * (double)nm[2]);
+		}
+		double X[3] = {(double)point[0] * confidence, (double)point[1] * confidence, (double)point[2] * confidence};
+		float Cc[3] = {0.f, 0.f, 0.f}, Nn[3];
+		if (A.bgr) for (int k = 0; k < 3; ++k) Cc[k] = (float)A.bgr[3 * (size_t)idx + k] * (float)confidence;
+		for (int k = 0; k < 3; ++k) Nn[k] = normal[k] * (float)confidence;
+		uint32_t invImg[kFuseMaxViews]; int invPix[kFuseMaxViews]; int ninv = 0;
+		for (int q = 0; q < A.nNeighbors; ++q) {
+			const uint32_t Bid = A.neighbors[q];
+			const DevMap& B = maps[Bid];
+			if (!B.depth) continue;
+			float ptz; int ib, xB, yB;
+			if (!project_target(B, point, ptz, ib, xB, yB)) continue;
+			const float depthB = B.depth[ib];
+			if (depthB == 0.f) continue;
+			if (B.claim[ib] != NO_ID) continue;
+			if (is_depth_similar(ptz, depthB, thDepth)) {
+				float normalB[3] = {0.f, 0.f, -1.f};
+				if (B.normal) {
+					const float* nm = B.normal + 3 * (size_t)ib;
+#pragma unroll
+					for (int k = 0; k < 3; ++k) normalB[k] = (float)(B.R[0 * 3 + k] * (double)nm[0] + B.R[1 * 3 + k] * (double)nm[1] + B.R[2 * 3 + k] * (double)nm[2]);
+				}
+				if (normal[0] * normalB[0] + normal[1] * normalB[1] + normal[2] * normalB[2] > normalError) {
+					const float confB = conf2weight(B.conf[ib], depthB);
+					int pos = nv;
+					while (pos > 0 && vimg[pos - 1] > Bid) { vimg[pos] = vimg[pos - 1]; vpix[pos] = vpix[pos - 1]; --pos; }
+					vimg[pos] = Bid; vpix[pos] = ib; ++nv;
+					B.claim[ib] = 0u;
+					double XB[3];
+					i2w(B, (double)xB, (double)yB, (double)depthB, XB);
+					for (int k = 0; k < 3; ++k) X[k] += XB[k] * (double)confB;
+					if (B.bgr) for (int k = 0; k < 3; ++k) Cc[k] += (float)B.bgr[3 * (size_t)ib + k] * confB;
+					for (int k = 0; k < 3; ++k) Nn[k] += normalB[k] * confB;
+					confidence += (double)confB;
+					continue;
+				}
+			}
+			if (ptz < depthB) { invImg[ninv] = Bid; invPix[ninv] = ib; ++ninv; }
+		}
+		if (nv < nMinViewsFuse) {
+			for (int v = 0; v < nv; ++v) maps[vimg[v]].claim[vpix[v]] = NO_ID;
+			state[idx] = 3;
+		} else {
+			A.claim[idx] = 0u;
+			const double nrm = 1.0 / confidence;
+			for (int k = 0; k < 3; ++k) out.xyz[3 * (size_t)idx + k] = (float)(X[k] * nrm);
+			if (out.bgr) for (int k = 0; k < 3; ++k) {
+				const int r = (int)floorf(Cc[k] * (float)nrm + .5f);
+				out.bgr[3 * (size_t)idx + k] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+			}
+			if (out.normal) {
+				const float n0 = Nn[0] * (float)nrm, n1 = Nn[1] * (float)nrm, n2 = Nn[2] * (float)nrm;
+				const float len = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
+				out.normal[3 * (size_t)idx] = n0 / len; out.normal[3 * (size_t)idx + 1] = n1 / len; out.normal[3 * (size_t)idx + 2] = n2 / len;
+			}
+			out.nviews[idx] = (uint32_t)nv;
+			out.flag[idx] = 1;
+			++accepted;
+			for (int v = 0; v < ninv; ++v) maps[invImg[v]].depth[invPix[v]] = 0.f;
+			state[idx] = 2;
+		}
+	}
+	if (decided) atomicAdd(&counters[2], (unsigned long long)decided);
+	if (accepted) atomicAdd(&counters[3], (unsigned long long)accepted);
+}
+
+// ordered compaction of the accepted pixels of one pass into the cloud
+__global__ void fuse_gather_kernel(int n, const uint8_t* flag, const uint32_t* pos, FuseOut out, unsigned long long base,
+                                   unsigned long long capacity, float* xyz, float* normal, uint8_t* bgr, uint32_t* nviews) {
+	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+		if (!flag[idx]) continue;
+		const unsigned long long o = base + pos[idx];
+		if (o >= capacity) continue;
+		for (int k = 0; k < 3; ++k) xyz[3 * o + k] = out.xyz[3 * (size_t)idx + k];
+		if (normal) for (int k = 0; k < 3; ++k) normal[3 * o + k] = out.normal[3 * (size_t)idx + k];
+		if (bgr) for (int k = 0; k < 3; ++k) bgr[3 * o + k] = out.bgr[3 * (size_t)idx + k];
+		if (nviews) nviews[o] = out.nviews[idx];
+	}
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void fill_u64_kernel(unsigned long long* p, unsigned long long v, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void flag_to_u32_kernel(const uint8_t* f, uint32_t* o, int n) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] = f[i];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// launch wrappers
+
+static const dim3 kGrid(2048), kBlock(256);
+
+void launch_fill_u32(uint32_t* p, uint32_t v, size_t n, hipStream_t s) { hipLaunchKernelGGL(fill_u32_kernel, kGrid, kBlock, 0, s, p, v, n); }
+void launch_fill_u64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s) { hipLaunchKernelGGL(fill_u64_kernel, kGrid, kBlock, 0, s, p, v, n); }
+
+void launch_filter_splat(const DevMap& ref, const DevMap& nb, unsigned long long* key, hipStream_t s) {
+	hipLaunchKernelGGL(filter_splat_kernel, kGrid, kBlock, 0, s, ref, nb, key);
+}
+void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsigned long long* keys, int adjust, int nMinViews,
+                        int nMinViewsAdjust, float thr, float* newDepth, float* newConf, unsigned long long* counters, hipStream_t s) {
+	hipLaunchKernelGGL(filter_vote_kernel, kGrid, kBlock, 0, s, ref, nbs, N, keys, adjust, nMinViews, nMinViewsAdjust, thr, newDepth, newConf, counters);
+}
+void launch_fuse_begin(const DevMap& A, uint8_t* state, uint8_t* flag, unsigned long long* counters, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, state, flag, counters);
+}
+void launch_fuse_bid(const DevMap& A, const DevMap* maps, uint8_t* state, int reset, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_bid_kernel, kGrid, kBlock, 0, s, A, maps, state, reset);
+}
+void launch_fuse_decide(const DevMap& A, const DevMap* maps, uint8_t* state, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv,
+                        uint8_t* oflag, int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, hipStream_t s) {
+	FuseOut out{oxyz, onormal, obgr, onv, oflag};
+	hipLaunchKernelGGL(fuse_decide_kernel, kGrid, kBlock, 0, s, A, maps, state, out, nMinViewsFuse, thDepth, normalError, counters);
+}
+size_t fuse_scan_temp_bytes(int n) {
+	size_t bytes = 0;
+	(void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, n);
+	return bytes;
+}
+void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,
+                         float* onormal, uint8_t* obgr, uint32_t* onv, unsigned long long base, unsigned long long capacity, float* xyz,
+                         float* normal, uint8_t* bgr, uint32_t* nviews, hipStream_t s) {
+	hipLaunchKernelGGL(flag_to_u32_kernel, kGrid, kBlock, 0, s, flag, flag32, n);
+	(void)hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, flag32, pos, n, s);
+	FuseOut out{oxyz, onormal, obgr, onv, const_cast<uint8_t*>(flag)};
+	hipLaunchKernelGGL(fuse_gather_kernel, kGrid, kBlock, 0, s, n, flag, pos, out, base, capacity, xyz, normal, bgr, nviews);
+}
+
+} // namespace hcmvs

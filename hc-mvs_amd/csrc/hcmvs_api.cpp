@@ -8,6 +8,7 @@
  */
 #include "../../include/hcmvs_hip.h"
 #include "pm_common.h"
+#include "fuse_common.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -28,6 +29,12 @@ struct View {
 	uint8_t* gra = nullptr;  // device gradient map (lazy)
 	bool owned = false;
 	double K[9], R[9], C[3];
+	// estimated maps registered for filter / fuse
+	float *mDepth = nullptr, *mNormal = nullptr, *mConf = nullptr;
+	bool mapsOwned = false;
+	float dMin = 0.f, dMax = 0.f;
+	uint32_t *claim = nullptr, *bid = nullptr, *dNeighbors = nullptr;
+	std::vector<uint32_t> neighbors;
 };
 
 } // namespace
@@ -56,6 +63,10 @@ struct hcmvs_ctx {
 	int lastSweeps = 0;
 	bool haveStats = false;
 	int sweepLag = 1;
+	// filter / fuse scratch
+	DevMap* dMaps = nullptr; size_t capMaps = 0;
+	unsigned long long* counters = nullptr;
+	void* fuseScratch = nullptr; size_t capFuseScratch = 0;
 	int wavesPerRow = 2;
 };
 
@@ -163,9 +174,16 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 	return HCMVS_OK;
 }
 
+static void free_maps(View& v) {
+	if (v.mapsOwned) for (void* p : {(void*)v.mDepth, (void*)v.mNormal, (void*)v.mConf}) if (p) (void)hipFree(p);
+	for (void* p : {(void*)v.claim, (void*)v.bid}) if (p) (void)hipFree(p);
+	v.mDepth = v.mNormal = v.mConf = nullptr; v.claim = v.bid = nullptr; v.mapsOwned = false;
+}
 static void free_view(View& v) {
 	if (v.owned) { if (v.gray) (void)hipFree(v.gray); if (v.bgr) (void)hipFree(v.bgr); }
 	if (v.gra) (void)hipFree(v.gra);
+	if (v.dNeighbors) (void)hipFree(v.dNeighbors);
+	free_maps(v);
 	v = View();
 }
 
@@ -175,7 +193,7 @@ void hcmvs_destroy(hcmvs_ctx* c) {
 	(void)hipStreamSynchronize(c->stream);
 	for (auto& kv : c->views) free_view(kv.second);
 	for (void* p : {(void*)c->dn, (void*)c->conf, (void*)c->tmpDepth, (void*)c->tmpU8, (void*)c->sDepth, (void*)c->sNormal,
-	                (void*)c->sConf, (void*)c->dViews, (void*)c->sync, (void*)c->evals})
+	                (void*)c->sConf, (void*)c->dViews, (void*)c->sync, (void*)c->evals, (void*)c->dMaps, (void*)c->counters, c->fuseScratch})
 		if (p) (void)hipFree(p);
 	for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -466,6 +484,231 @@ int hcmvs_splat_init(hcmvs_ctx* c, uint32_t id, const float* pts, int32_t n, flo
 	}
 	*d_min = dmin * 0.9f;
 	*d_max = dmax * 1.1f;
+	return HCMVS_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// filter / fuse
+
+static int set_maps(hcmvs_ctx* c, uint32_t id, const float* depth, const float* normal, const float* conf, float dmin, float dmax, bool copy) {
+	if (!c) return HCMVS_ERR_INVALID;
+	auto it = c->views.find(id);
+	if (it == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "set_depthmap: unknown view %u", id);
+	if (!depth || !conf) return fail(c, HCMVS_ERR_INVALID, "set_depthmap: null map");
+	View& v = it->second;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	free_maps(v);
+	const size_t n = (size_t)v.w * v.h;
+	if (copy) {
+		HIPCHK(c, hipMalloc(&v.mDepth, n * 4));
+		HIPCHK(c, hipMalloc(&v.mConf, n * 4));
+		HIPCHK(c, hipMemcpy(v.mDepth, depth, n * 4, hipMemcpyHostToDevice));
+		HIPCHK(c, hipMemcpy(v.mConf, conf, n * 4, hipMemcpyHostToDevice));
+		if (normal) {
+			HIPCHK(c, hipMalloc(&v.mNormal, n * 12));
+			HIPCHK(c, hipMemcpy(v.mNormal, normal, n * 12, hipMemcpyHostToDevice));
+		}
+		v.mapsOwned = true;
+	} else {
+		v.mDepth = const_cast<float*>(depth); v.mNormal = const_cast<float*>(normal); v.mConf = const_cast<float*>(conf);
+	}
+	v.dMin = dmin; v.dMax = dmax;
+	HIPCHK(c, hipMalloc(&v.claim, n * 4));
+	HIPCHK(c, hipMalloc(&v.bid, n * 4));
+	return HCMVS_OK;
+}
+int hcmvs_set_depthmap(hcmvs_ctx* c, uint32_t id, const float* depth, const float* normal, const float* conf, float d_min, float d_max) {
+	return set_maps(c, id, depth, normal, conf, d_min, d_max, true);
+}
+int hcmvs_set_depthmap_device(hcmvs_ctx* c, uint32_t id, float* d_depth, const float* d_normal, const float* d_conf, float d_min, float d_max) {
+	return set_maps(c, id, d_depth, d_normal, d_conf, d_min, d_max, false);
+}
+int hcmvs_get_depthmap(hcmvs_ctx* c, uint32_t id, float* depth, float* normal, float* conf) {
+	if (!c) return HCMVS_ERR_INVALID;
+	auto it = c->views.find(id);
+	if (it == c->views.end() || !it->second.mDepth) return fail(c, HCMVS_ERR_INVALID, "get_depthmap: view %u has no maps", id);
+	const View& v = it->second;
+	const size_t n = (size_t)v.w * v.h;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if (depth) HIPCHK(c, hipMemcpy(depth, v.mDepth, n * 4, hipMemcpyDeviceToHost));
+	if (normal && v.mNormal) HIPCHK(c, hipMemcpy(normal, v.mNormal, n * 12, hipMemcpyDeviceToHost));
+	if (conf) HIPCHK(c, hipMemcpy(conf, v.mConf, n * 4, hipMemcpyDeviceToHost));
+	return HCMVS_OK;
+}
+int hcmvs_set_neighbors(hcmvs_ctx* c, uint32_t id, const uint32_t* ids, int32_t n) {
+	if (!c) return HCMVS_ERR_INVALID;
+	auto it = c->views.find(id);
+	if (it == c->views.end() || n < 0 || n > 64 || (n > 0 && !ids)) return fail(c, HCMVS_ERR_INVALID, "set_neighbors: bad arguments for view %u", id);
+	View& v = it->second;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if (v.dNeighbors) { (void)hipFree(v.dNeighbors); v.dNeighbors = nullptr; }
+	v.neighbors.assign(ids, ids + n);
+	if (n > 0) {
+		HIPCHK(c, hipMalloc(&v.dNeighbors, (size_t)n * 4));
+		HIPCHK(c, hipMemcpy(v.dNeighbors, ids, (size_t)n * 4, hipMemcpyHostToDevice));
+	}
+	return HCMVS_OK;
+}
+
+static void fill_devmap(uint32_t id, const View& v, DevMap& m) {
+	memset(&m, 0, sizeof m);
+	m.id = id; m.w = v.w; m.h = v.h; m.nNeighbors = (int)v.neighbors.size();
+	memcpy(m.K, v.K, sizeof m.K); memcpy(m.R, v.R, sizeof m.R); memcpy(m.C, v.C, sizeof m.C);
+	double t[3];
+	for (int i = 0; i < 3; ++i) t[i] = -(v.R[i * 3] * v.C[0] + v.R[i * 3 + 1] * v.C[1] + v.R[i * 3 + 2] * v.C[2]);
+	for (int i = 0; i < 3; ++i) { // P = K [R | -R C], Camera.h:276-282
+		for (int j = 0; j < 3; ++j) m.P[i * 4 + j] = v.K[i * 3] * v.R[j] + v.K[i * 3 + 1] * v.R[3 + j] + v.K[i * 3 + 2] * v.R[6 + j];
+		m.P[i * 4 + 3] = v.K[i * 3] * t[0] + v.K[i * 3 + 1] * t[1] + v.K[i * 3 + 2] * t[2];
+	}
+	m.depth = v.mDepth; m.normal = v.mNormal; m.conf = v.mConf; m.bgr = v.bgr; m.claim = v.claim; m.bid = v.bid;
+	m.neighbors = v.dNeighbors; m.dMin = v.dMin; m.dMax = v.dMax;
+}
+// device table indexed by image id (views without maps have depth == null)
+static int build_map_table(hcmvs_ctx* c, std::vector<DevMap>& host) {
+	uint32_t maxId = 0;
+	for (auto& kv : c->views) if (kv.first > maxId) maxId = kv.first;
+	host.assign((size_t)maxId + 1, DevMap());
+	for (auto& m : host) memset(&m, 0, sizeof m);
+	for (auto& kv : c->views) fill_devmap(kv.first, kv.second, host[kv.first]);
+	if (host.size() > c->capMaps) {
+		if (c->dMaps) (void)hipFree(c->dMaps);
+		c->dMaps = nullptr; c->capMaps = 0;
+		HIPCHK(c, hipMalloc(&c->dMaps, host.size() * sizeof(DevMap)));
+		c->capMaps = host.size();
+	}
+	HIPCHK(c, hipMemcpy(c->dMaps, host.data(), host.size() * sizeof(DevMap), hipMemcpyHostToDevice));
+	if (!c->counters) HIPCHK(c, hipMalloc(&c->counters, 8 * sizeof(unsigned long long)));
+	return HCMVS_OK;
+}
+static int ensure_scratch(hcmvs_ctx* c, size_t bytes) {
+	if (bytes <= c->capFuseScratch) return HCMVS_OK;
+	if (c->fuseScratch) (void)hipFree(c->fuseScratch);
+	c->fuseScratch = nullptr; c->capFuseScratch = 0;
+	HIPCHK(c, hipMalloc(&c->fuseScratch, bytes));
+	c->capFuseScratch = bytes;
+	return HCMVS_OK;
+}
+
+int hcmvs_filter(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* nbr, int32_t N, int32_t adjust, int32_t n_min_views,
+                 int32_t n_min_views_adjust, float depth_diff_threshold, float* out_depth, float* out_conf, uint64_t* n_processed,
+                 uint64_t* n_discarded) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!nbr || !out_depth || !out_conf || N < 1 || N > 64) return fail(c, HCMVS_ERR_INVALID, "filter: bad arguments");
+	if (N < n_min_views || N < n_min_views_adjust) return fail(c, HCMVS_ERR_INVALID, "filter: depth map %u can not be filtered (%d neighbours)", ref_id, N); // SceneDensify.cpp:3016-3019
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	std::vector<DevMap> host;
+	int rc = build_map_table(c, host);
+	if (rc) return rc;
+	if (ref_id >= host.size() || !host[ref_id].depth) return fail(c, HCMVS_ERR_INVALID, "filter: view %u has no maps", ref_id);
+	std::vector<DevMap> nbs((size_t)N);
+	for (int n = 0; n < N; ++n) {
+		if (nbr[n] >= host.size() || !host[nbr[n]].depth) return fail(c, HCMVS_ERR_INVALID, "filter: neighbour %u has no maps", nbr[n]);
+		nbs[n] = host[nbr[n]];
+	}
+	const DevMap& ref = host[ref_id];
+	const size_t area = (size_t)ref.w * ref.h;
+	// scratch: keys [N*area u64] | neighbour table | new depth | new conf
+	const size_t offNb = area * N * 8, offD = offNb + ((sizeof(DevMap) * N + 255) & ~(size_t)255), offC = offD + area * 4;
+	rc = ensure_scratch(c, offC + area * 4);
+	if (rc) return rc;
+	char* base = (char*)c->fuseScratch;
+	unsigned long long* keys = (unsigned long long*)base;
+	DevMap* dNbs = (DevMap*)(base + offNb);
+	float* dD = (float*)(base + offD); float* dC = (float*)(base + offC);
+	hipStream_t s = c->stream;
+	HIPCHK(c, hipMemcpyAsync(dNbs, nbs.data(), sizeof(DevMap) * N, hipMemcpyHostToDevice, s));
+	HIPCHK(c, hipMemsetAsync(c->counters, 0, 64, s));
+	launch_fill_u64(keys, ~0ull, area * N, s);
+	for (int n = 0; n < N; ++n) launch_filter_splat(ref, nbs[n], keys + area * n, s);
+	launch_filter_vote(ref, dNbs, N, keys, adjust, n_min_views, n_min_views_adjust, depth_diff_threshold, dD, dC, c->counters, s);
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipMemcpyAsync(out_depth, dD, area * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipMemcpyAsync(out_conf, dC, area * 4, hipMemcpyDeviceToHost, s));
+	unsigned long long cnt[2] = {0, 0};
+	HIPCHK(c, hipMemcpyAsync(cnt, c->counters, 16, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipStreamSynchronize(s));
+	if (n_processed) *n_processed = cnt[0];
+	if (n_discarded) *n_discarded = cnt[1];
+	return HCMVS_OK;
+}
+
+int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
+               float normal_diff_deg, float depthweight, float normalweight, uint64_t capacity, float* xyz, float* normal,
+               uint8_t* bgr, uint32_t* n_views, uint64_t* n_points, uint64_t* n_depths) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!order || n_order < 1 || !xyz || !n_points) return fail(c, HCMVS_ERR_INVALID, "fuse: bad arguments");
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	std::vector<DevMap> host;
+	int rc = build_map_table(c, host);
+	if (rc) return rc;
+	size_t maxArea = 0;
+	for (int i = 0; i < n_order; ++i) {
+		if (order[i] >= host.size() || !host[order[i]].depth) return fail(c, HCMVS_ERR_INVALID, "fuse: view %u has no maps", order[i]);
+		const size_t a = (size_t)host[order[i]].w * host[order[i]].h;
+		if (a > maxArea) maxArea = a;
+		if (host[order[i]].nNeighbors > kFuseMaxViews - 1) return fail(c, HCMVS_ERR_INVALID, "fuse: view %u has too many neighbours", order[i]);
+	}
+	hipStream_t s = c->stream;
+	for (auto& m : host) if (m.depth) { launch_fill_u32(m.claim, 0xFFFFFFFFu, (size_t)m.w * m.h, s); launch_fill_u32(m.bid, 0xFFFFFFFFu, (size_t)m.w * m.h, s); }
+	// per-pass scratch (sized for the largest image) + device cloud
+	const size_t scanBytes = (fuse_scan_temp_bytes((int)maxArea) + 255) & ~(size_t)255;
+	size_t off = 0;
+	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+	const size_t oState = carve(maxArea), oFlag = carve(maxArea), oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
+	             oXyz = carve(maxArea * 12), oNrm = carve(maxArea * 12), oBgr = carve(maxArea * 3), oNv = carve(maxArea * 4),
+	             oCX = carve(capacity * 12), oCN = carve(normal ? capacity * 12 : 0), oCB = carve(bgr ? capacity * 3 : 0), oCV = carve(n_views ? capacity * 4 : 0);
+	rc = ensure_scratch(c, off);
+	if (rc) return rc;
+	char* b = (char*)c->fuseScratch;
+	uint8_t* state = (uint8_t*)(b + oState); uint8_t* flag = (uint8_t*)(b + oFlag);
+	uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos);
+	float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
+	float* cX = (float*)(b + oCX); float* cN = normal ? (float*)(b + oCN) : nullptr; uint8_t* cB = bgr ? (uint8_t*)(b + oCB) : nullptr;
+	uint32_t* cV = n_views ? (uint32_t*)(b + oCV) : nullptr;
+	const float normalError = cosf(normal_diff_deg * normalweight * (3.14159274101257324f / 180.f)); // SceneDensify.cpp:3310
+	const float thDepth = depth_diff_threshold * depthweight;                                       // SceneDensify.cpp:3400
+	unsigned long long total = 0, depths = 0;
+	for (int oi = 0; oi < n_order; ++oi) { // best connected images first (SceneDensify.cpp:3302, order given by the caller)
+		const DevMap& A = host[order[oi]];
+		const int n = A.w * A.h;
+		HIPCHK(c, hipMemsetAsync(c->counters, 0, 64, s));
+		launch_fuse_begin(A, state, flag, c->counters, s);
+		unsigned long long cnt[4];
+		HIPCHK(c, hipMemcpyAsync(cnt, c->counters, 32, hipMemcpyDeviceToHost, s));
+		HIPCHK(c, hipStreamSynchronize(s));
+		depths += cnt[0];
+		unsigned long long pending = cnt[1], accepted = 0;
+		int guard = 0;
+		while (pending > 0) {
+			HIPCHK(c, hipMemsetAsync(c->counters + 2, 0, 16, s));
+			launch_fuse_bid(A, c->dMaps, state, 0, s);
+			launch_fuse_decide(A, c->dMaps, state, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, n_min_views_fuse, thDepth, normalError,
+			                   c->counters, s);
+			launch_fuse_bid(A, c->dMaps, state, 1, s);
+			HIPCHK(c, hipMemcpyAsync(cnt, c->counters, 32, hipMemcpyDeviceToHost, s));
+			HIPCHK(c, hipStreamSynchronize(s));
+			if (cnt[2] == 0 || ++guard > 100000) return fail(c, HCMVS_ERR_HIP, "fuse: no progress in image %u (%llu pixels pending)", A.id, pending);
+			pending -= cnt[2];
+			accepted += cnt[3];
+		}
+		if (total + accepted > capacity) return fail(c, HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity);
+		if (accepted) launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, total, capacity, cX, cN, cB, cV, s);
+		total += accepted;
+	}
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipMemcpyAsync(xyz, cX, total * 12, hipMemcpyDeviceToHost, s));
+	if (normal) HIPCHK(c, hipMemcpyAsync(normal, cN, total * 12, hipMemcpyDeviceToHost, s));
+	if (bgr) HIPCHK(c, hipMemcpyAsync(bgr, cB, total * 3, hipMemcpyDeviceToHost, s));
+	if (n_views) HIPCHK(c, hipMemcpyAsync(n_views, cV, total * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipStreamSynchronize(s));
+	*n_points = total;
+	if (n_depths) *n_depths = depths;
 	return HCMVS_OK;
 }
 

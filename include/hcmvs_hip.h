@@ -124,6 +124,37 @@ int hcmvs_get_stats(hcmvs_ctx* ctx, hcmvs_stats* out);
 int hcmvs_splat_init(hcmvs_ctx* ctx, uint32_t id, const float* points_xyz, int32_t n_points, float* depth,
                      float* normal, float* d_min, float* d_max);
 
+/* ---- filter and fuse: work on the estimated maps registered per view ------------------------------------ */
+
+/* register the maps of view `id` (host buffers are copied).  normal may be NULL.  d_min/d_max: the depth range
+ * FilterDepthMap clips the adjusted depth to (SceneDensify.cpp:3156). */
+int hcmvs_set_depthmap(hcmvs_ctx* ctx, uint32_t id, const float* depth, const float* normal_or_null,
+                       const float* conf, float d_min, float d_max);
+/* same for maps that already live in device memory; d_depth is MUTATED by hcmvs_fuse like the reference does
+ * (SceneDensify.cpp:3447-3449) */
+int hcmvs_set_depthmap_device(hcmvs_ctx* ctx, uint32_t id, float* d_depth, const float* d_normal_or_null,
+                              const float* d_conf, float d_min, float d_max);
+/* read the (possibly mutated) maps back; any pointer may be NULL */
+int hcmvs_get_depthmap(hcmvs_ctx* ctx, uint32_t id, float* depth, float* normal, float* conf);
+/* DepthData::neighbors of view `id`: image ids in decreasing importance (Scene.cpp:545-678), at most 31 for fuse */
+int hcmvs_set_neighbors(hcmvs_ctx* ctx, uint32_t id, const uint32_t* ids, int32_t n);
+
+/* bool DepthMapsData::FilterDepthMap(DepthData&, const IIndexArr&, bool bAdjust) (SceneDensify.cpp:3006-3259).
+ * out_depth / out_conf: w*h host buffers (the reference writes them to filtered.dmap/.cmap).
+ * Fails with HCMVS_ERR_INVALID when there are fewer neighbours than n_min_views (the reference returns false). */
+int hcmvs_filter(hcmvs_ctx* ctx, uint32_t ref_id, const uint32_t* neighbor_ids, int32_t n_neighbors, int32_t adjust,
+                 int32_t n_min_views, int32_t n_min_views_adjust, float depth_diff_threshold, float* out_depth,
+                 float* out_conf, uint64_t* n_processed, uint64_t* n_discarded);
+
+/* void DepthMapsData::FuseDepthMaps(PointCloud&, bool, bool) (SceneDensify.cpp:3265-3495).  order: image ids,
+ * best connected first (SceneDensify.cpp:3302).  Output host buffers hold `capacity` points: xyz 3 f32, normal
+ * 3 f32 or NULL, bgr 3 u8 (B,G,R) or NULL, n_views u32 or NULL.  *n_points / *n_depths are the numbers the
+ * reference logs (SceneDensify.cpp:3461).  Points come out in the reference's order. */
+int hcmvs_fuse(hcmvs_ctx* ctx, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse,
+               float depth_diff_threshold, float normal_diff_deg, float depthweight, float normalweight,
+               uint64_t capacity, float* xyz, float* normal_or_null, uint8_t* bgr_or_null, uint32_t* n_views_or_null,
+               uint64_t* n_points, uint64_t* n_depths);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,19 @@ class Params(C.Structure):
                 ("arith_mode", C.c_int), ("order", C.c_int), ("n_threads", C.c_int), ("median_blur", C.c_int)]
 
 
+class DepthMap(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("K", C.c_double * 9), ("R", C.c_double * 9),
+                ("C", C.c_double * 3), ("depth", C.POINTER(C.c_float)), ("normal", C.POINTER(C.c_float)),
+                ("conf", C.POINTER(C.c_float)), ("bgr", C.POINTER(C.c_uint8)), ("d_min", C.c_float),
+                ("d_max", C.c_float), ("n_neighbors", C.c_int), ("neighbors", C.POINTER(C.c_uint32))]
+
+
+class Cloud(C.Structure):
+    _fields_ = [("n_points", C.c_uint64), ("capacity", C.c_uint64), ("xyz", C.POINTER(C.c_float)),
+                ("normal", C.POINTER(C.c_float)), ("bgr", C.POINTER(C.c_uint8)), ("n_views", C.POINTER(C.c_uint32)),
+                ("n_depths", C.c_uint64)]
+
+
 _lib = None
 
 
@@ -77,6 +90,13 @@ def lib():
         L.hcor_pass_score.argtypes = est_args
         L.hcor_pass_sweep.argtypes = est_args[:5] + [C.c_int] + est_args[5:]
         L.hcor_pass_end.argtypes = [C.POINTER(Params), C.c_int, C.c_int, fp, fp, fp]
+        L.hcor_filter_depthmap.argtypes = [C.POINTER(DepthMap), C.c_uint32, C.POINTER(C.c_uint32), C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_float, fp, fp, C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_uint64)]
+        L.hcor_filter_depthmap.restype = C.c_int
+        L.hcor_fuse_depthmaps.argtypes = [C.POINTER(DepthMap), C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int,
+                                          C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Cloud)]
+        L.hcor_fuse_depthmaps.restype = C.c_int
     return _lib
 
 
@@ -150,3 +170,50 @@ def estimate(views, params, d_min, d_max, depth, normal, gra=None, passes="all",
                          fptr(n), fptr(c), C.byref(ev))
     assert rc == 0
     return d, n, c, ev.value
+
+
+def make_depthmaps(maps):
+    """maps: list of dicts (K,R,C, depth (h,w), normal (h,w,3) or None, conf, bgr or None, d_min, d_max, neighbors).
+    Depth arrays are copied (fusion mutates them); returns (ctypes array, list of the mutable depth copies)."""
+    arr = (DepthMap * len(maps))()
+    keep = []; depths = []
+    for i, m in enumerate(maps):
+        d = np.ascontiguousarray(m["depth"], np.float32).copy(); c = np.ascontiguousarray(m["conf"], np.float32)
+        arr[i].height, arr[i].width = d.shape
+        arr[i].K[:] = list(np.asarray(m["K"], np.float64).ravel()); arr[i].R[:] = list(np.asarray(m["R"], np.float64).ravel())
+        arr[i].C[:] = list(np.asarray(m["C"], np.float64).ravel())
+        arr[i].depth = fptr(d); arr[i].conf = fptr(c); keep += [d, c]; depths.append(d)
+        if m.get("normal") is not None:
+            n = np.ascontiguousarray(m["normal"], np.float32); arr[i].normal = fptr(n); keep.append(n)
+        if m.get("bgr") is not None:
+            b = np.ascontiguousarray(m["bgr"], np.uint8); arr[i].bgr = u8ptr(b); keep.append(b)
+        arr[i].d_min = m.get("d_min", 0.1); arr[i].d_max = m.get("d_max", 1e9)
+        nb = (C.c_uint32 * max(len(m["neighbors"]), 1))(*m["neighbors"])
+        arr[i].neighbors = nb; arr[i].n_neighbors = len(m["neighbors"]); keep.append(nb)
+    arr._keep = keep
+    return arr, depths
+
+
+def filter_depthmap(maps, ref_id, neighbor_ids, adjust=True, n_min_views=2, n_min_views_adjust=1, thr=0.01):
+    arr, _ = make_depthmaps(maps)
+    h, w = maps[ref_id]["depth"].shape
+    d = np.empty((h, w), np.float32); c = np.empty((h, w), np.float32)
+    ids = (C.c_uint32 * len(neighbor_ids))(*neighbor_ids)
+    npr = C.c_uint64(); nd = C.c_uint64()
+    ok = lib().hcor_filter_depthmap(arr, ref_id, ids, len(neighbor_ids), int(adjust), n_min_views, n_min_views_adjust, thr,
+                                    fptr(d), fptr(c), C.byref(npr), C.byref(nd))
+    return ok, d, c, npr.value, nd.value
+
+
+def fuse_depthmaps(maps, order, capacity, n_min_views_fuse=2, thr=0.01, normal_deg=25.0, depthweight=1.0, normalweight=1.0):
+    arr, depths = make_depthmaps(maps)
+    xyz = np.zeros((capacity, 3), np.float32); nrm = np.zeros((capacity, 3), np.float32)
+    bgr = np.zeros((capacity, 3), np.uint8); nv = np.zeros(capacity, np.uint32)
+    cl = Cloud(); cl.capacity = capacity; cl.xyz = fptr(xyz); cl.normal = fptr(nrm); cl.bgr = u8ptr(bgr)
+    cl.n_views = nv.ctypes.data_as(C.POINTER(C.c_uint32))
+    ids = (C.c_uint32 * len(order))(*order)
+    rc = lib().hcor_fuse_depthmaps(arr, len(maps), ids, len(order), n_min_views_fuse, thr, normal_deg, depthweight,
+                                   normalweight, C.byref(cl))
+    assert rc == 0
+    k = cl.n_points
+    return dict(xyz=xyz[:k], normal=nrm[:k], bgr=bgr[:k], n_views=nv[:k], n_points=k, n_depths=cl.n_depths, depths=depths)

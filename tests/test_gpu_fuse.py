@@ -1,0 +1,68 @@
+"""GPU parity of FilterDepthMap / FuseDepthMaps against the CPU oracle through the C-ABI: bit-exact, including
+the order of the fused points and the depth estimates fusion invalidates."""
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fusion_scene import make_maps
+
+pytestmark = pytest.mark.gpu
+binding = importlib.import_module("hc-mvs_amd.binding")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = binding.Context(0)
+    yield c
+    c.close()
+
+
+def upload(ctx, maps):
+    for i, m in enumerate(maps):
+        ctx.upload_view(i, m["gray"], m["K"], m["R"], m["C"], bgr=m["bgr"])
+        ctx.set_depthmap(i, m["depth"], m["normal"], m["conf"], m["d_min"], m["d_max"])
+        ctx.set_neighbors(i, m["neighbors"])
+
+
+@pytest.mark.parametrize("kw", [dict(noise=0.0), dict(noise=0.003, outliers=0.05, holes=0.1),
+                                dict(w=144, h=112, f=130.0, n_views=7, noise=0.002, outliers=0.03)])
+def test_fuse_bit_exact(ctx, kw):
+    maps, order = make_maps(**kw)
+    upload(ctx, maps)
+    want = O.fuse_depthmaps(maps, order, 200000)
+    got = ctx.fuse(order, 200000)
+    assert got["n_points"] == want["n_points"] > 100 and got["n_depths"] == want["n_depths"]
+    assert np.array_equal(got["n_views"], want["n_views"])
+    assert np.array_equal(got["xyz"], want["xyz"])          # same points in the same order
+    assert np.array_equal(got["normal"], want["normal"]) and np.array_equal(got["bgr"], want["bgr"])
+    for i, d in enumerate(want["depths"]):                   # the same estimates were invalidated
+        assert np.array_equal(ctx.get_depthmap(i)[0], d)
+
+
+def test_fuse_options_and_capacity(ctx):
+    maps, order = make_maps(noise=0.002)
+    upload(ctx, maps)
+    want = O.fuse_depthmaps(maps, order, 200000, n_min_views_fuse=3, thr=0.02, normal_deg=15.0, depthweight=0.7, normalweight=1.3)
+    got = ctx.fuse(order, 200000, n_min_views_fuse=3, depth_diff_threshold=0.02, normal_diff_deg=15.0, depthweight=0.7,
+                   normalweight=1.3, with_colors=False)
+    assert got["n_points"] == want["n_points"] and np.array_equal(got["xyz"], want["xyz"]) and got["bgr"] is None
+    upload(ctx, maps)
+    with pytest.raises(binding.HcmvsError) as e:
+        ctx.fuse(order, 10)
+    assert e.value.code == binding.ERR_CAPACITY
+
+
+@pytest.mark.parametrize("adjust", [True, False])
+def test_filter_bit_exact(ctx, adjust):
+    maps, _ = make_maps(w=144, h=112, f=130.0, n_views=6, noise=0.002, outliers=0.06, holes=0.05)
+    upload(ctx, maps)
+    for ref in (0, 3):
+        nb = maps[ref]["neighbors"][:4]
+        ok, d, c, nproc, ndisc = O.filter_depthmap(maps, ref, nb, adjust=adjust)
+        gd, gc, gp, gdisc = ctx.filter(ref, nb, adjust=adjust)
+        assert ok == 1 and (gp, gdisc) == (nproc, ndisc) and 0 < ndisc < nproc
+        assert np.array_equal(gd, d) and np.array_equal(gc, c)
+    with pytest.raises(binding.HcmvsError):
+        ctx.filter(0, maps[0]["neighbors"][:1], adjust=adjust, n_min_views=2)
