@@ -80,6 +80,7 @@ def main():
 
     binding = importlib.import_module("hc-mvs_amd.binding")  # imports torch first: one HIP runtime per process
     synth = importlib.import_module("hc-mvs_amd.synth")
+    D = importlib.import_module("hc-mvs_amd.distributed")
 
     # synthetic scene: every rank gets its own reference image + source views (weak scaling)
     views = synth.make_views(W, H, FOCAL, N_SRC, seed=2 + rank)
@@ -101,7 +102,6 @@ def main():
     HW = H * W
     esz = work.element_size()
     p_depth, p_normal, p_conf = work.data_ptr(), work.data_ptr() + HW * esz, work.data_ptr() + 4 * HW * esz
-    gathered = torch.empty(world * work.numel(), dtype=work.dtype, device=dev) if world > 1 else None
     params = binding.default_params(adapthalfwin=AHW, n_estimation_iters=SWEEPS, it_external=0, n_external_iters=1,
                                     seed=1234)
     src_ids = list(range(1, N_SRC + 1))
@@ -109,8 +109,8 @@ def main():
     def step():
         work.copy_(init)
         ctx.estimate_device(0, src_ids, params, dmin, dmax, p_depth, p_normal, p_conf)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, work)
+        if world > 1:  # the exchange FuseDepthMaps needs: every rank receives every map (20 B/px)
+            D.allgather_maps(work.view(1, -1))
 
     def fence():
         if world > 1:
