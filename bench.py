@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- PatchMatch depth-map estimation throughput on MI355X (BASELINE.json metric).
 
-One "step" = one complete EstimateDepthMap of one reference image (median + init-score pass + 8
-propagate/refine sweeps + end pass; SceneDensify.cpp:758-1072) on BASELINE.json configs[1]:
-1 reference x 8 source views, 1920x1080, 7x7 taps (adapthalfwin 6), 8 sweeps, synthetic pinhole scene.
-Inputs (images, initial maps) are resident in HBM before the timed region starts.
+One "step" = one pass of the hot path over one BATCH of synthetic input: --batch B (default 8) independent units
+of BASELINE.json configs[1] -- 1 reference x 8 source views, 1920x1080, 7x7 taps (adapthalfwin 6), 8 sweeps --
+each a complete EstimateDepthMap (median + init-score pass + 8 propagate/refine sweeps + end pass;
+SceneDensify.cpp:758-1072) of its own synthetic pinhole scene, issued as one hcmvs_estimate_batch_device call
+(the reference likewise overlaps images, SceneDensify.cpp:3699).  Inputs (images, initial maps) are resident in HBM
+before the timed region starts.  The single-unit latency (B = 1) is reported next to it as "single_unit".
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -58,6 +60,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="independent reference images per step and GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -82,35 +85,41 @@ def main():
     synth = importlib.import_module("hc-mvs_amd.synth")
     D = importlib.import_module("hc-mvs_amd.distributed")
 
-    # synthetic scene: every rank gets its own reference image + source views (weak scaling)
-    views = synth.make_views(W, H, FOCAL, N_SRC, seed=2 + rank)
-    pts = synth.sparse_points(views, 2000, seed=5 + rank)
+    # synthetic scenes: every rank gets its own batch of B units (weak scaling); unit b = views 100*b .. 100*b+8
+    B = args.batch
     ctx = binding.Context(local_rank)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
-    d_gray = []
-    for i, v in enumerate(views):
-        t = torch.from_numpy(v["gray"]).to(dev)
-        d_gray.append(t)
-        ctx.set_view_device(i, W, H, t.data_ptr(), v["K"], v["R"], v["C"])
-    # initial maps (SceneDensify.cpp:783-808 splat of the sparse points), resident on the device
-    ctx.shapes[0] = (H, W)
-    d0, n0, dmin, dmax = ctx.splat_init(0, pts)
-    init = torch.cat([torch.from_numpy(d0).reshape(-1), torch.from_numpy(n0).reshape(-1),
-                      torch.zeros(H * W)]).to(dev)
-    work = torch.empty_like(init)
     HW = H * W
-    esz = work.element_size()
-    p_depth, p_normal, p_conf = work.data_ptr(), work.data_ptr() + HW * esz, work.data_ptr() + 4 * HW * esz
     params = binding.default_params(adapthalfwin=AHW, n_estimation_iters=SWEEPS, it_external=0, n_external_iters=1,
                                     seed=1234)
-    src_ids = list(range(1, N_SRC + 1))
+    items, inits, works, keep = [], [], [], []
+    for b_ in range(B):
+        views = synth.make_views(W, H, FOCAL, N_SRC, seed=2 + rank * B + b_)
+        pts = synth.sparse_points(views, 2000, seed=5 + rank * B + b_)
+        slab = torch.from_numpy(np.stack([v["gray"] for v in views])).to(dev)  # one allocation per unit
+        keep.append(slab)
+        for i, v in enumerate(views):
+            ctx.set_view_device(100 * b_ + i, W, H, slab[i].data_ptr(), v["K"], v["R"], v["C"])
+        ctx.shapes[100 * b_] = (H, W)
+        # initial maps (SceneDensify.cpp:783-808 splat of the sparse points), resident on the device
+        d0, n0, dmin, dmax = ctx.splat_init(100 * b_, pts)
+        init = torch.cat([torch.from_numpy(d0).reshape(-1), torch.from_numpy(n0).reshape(-1), torch.zeros(HW)]).to(dev)
+        work = torch.empty_like(init)
+        esz = work.element_size()
+        inits.append(init); works.append(work)
+        items.append(dict(ref_id=100 * b_, src_ids=[100 * b_ + i for i in range(1, N_SRC + 1)], d_min=dmin, d_max=dmax,
+                          d_depth=work.data_ptr(), d_normal=work.data_ptr() + HW * esz, d_conf=work.data_ptr() + 4 * HW * esz,
+                          seed_offset=b_))
+    allwork = torch.stack(works) if world > 1 else None
 
-    def step():
-        work.copy_(init)
-        ctx.estimate_device(0, src_ids, params, dmin, dmax, p_depth, p_normal, p_conf)
+    def step(its=items):
+        for init, work in zip(inits, works):
+            work.copy_(init)
+        ctx.estimate_batch_device(its, params)
         if world > 1:  # the exchange FuseDepthMaps needs: every rank receives every map (20 B/px)
-            D.allgather_maps(work.view(1, -1))
+            allwork.copy_(torch.stack(works))
+            D.allgather_maps(allwork)
 
     def fence():
         if world > 1:
@@ -131,30 +140,38 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     st = ctx.stats()  # of the last step: HIP events recorded on the stream the kernels ran on
+    # single-unit latency, outside the timed region
+    step(items[:1]); torch.cuda.synchronize()
+    t1 = time.perf_counter(); step(items[:1]); torch.cuda.synchronize()
+    single_ms = (time.perf_counter() - t1) * 1e3
 
     if rank == 0:
         P = (W - 14) * (H - 14)
-        gra = ctx.gradient_map(0)[7:H - 7, 7:W - 7]
-        taps_px = np.where(gra > 100, 36, (AHW + 1) ** 2).astype(np.int64)
-        tap_evals_sweeps = int(st.tap_evals) - int(taps_px.sum())  # pass A scores every pixel once
+        taps_a = 0  # pass A scores every pixel of every unit once
+        for b_ in range(B):
+            gra = ctx.gradient_map(100 * b_)[7:H - 7, 7:W - 7]
+            taps_a += int(np.where(gra > 100, 36, (AHW + 1) ** 2).astype(np.int64).sum())
+        tap_evals_sweeps = int(st.tap_evals) - taps_a
         # algorithmic bytes of ONE sweep launch (SURVEY.md 8d tap-gather convention): every bilinear sample
         # counts its 4 texels (16 B) per source view, plus the 24 B of per-pixel state read and 20 B written
-        bytes_sweep = tap_evals_sweeps / SWEEPS * N_SRC * 16.0 + P * (24.0 + 20.0)
+        bytes_sweep = tap_evals_sweeps / SWEEPS * N_SRC * 16.0 + B * P * (24.0 + 20.0)
         achieved = bytes_sweep / (st.ms_sweep_avg * 1e-3) / 1e9
         out = {
             "metric": "PatchMatch Mpix/s (1080p, 8 views, 7x7, 8 iter)",
-            "value": round(world * W * H * args.steps / dt / 1e6, 4),
+            "value": round(world * B * W * H * args.steps / dt / 1e6, 4),
             "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "1 ref x 8 src views per GPU, 1920x1080, 7x7 taps (adapthalfwin 6), 8 sweeps, "
-                                   "it_external 0, full EstimateDepthMap (median + init score + sweeps + end pass)",
-                       "units_per_step": "one reference image per GPU (%d px)" % (W * H),
+            "config": {"workload": "batch of %d independent units per GPU, each 1 ref x 8 src views, 1920x1080, 7x7 taps "
+                                   "(adapthalfwin 6), 8 sweeps, it_external 0, full EstimateDepthMap (median + init score + "
+                                   "sweeps + end pass)" % B,
+                       "units_per_step": "%d reference images per GPU (%d px each)" % (B, W * H), "batch": B,
                        "exchange": "RCCL all-gather of 20 B/px maps per step" if world > 1 else "none",
-                       "evals_per_pixel_sweep": round((st.evals / P - 1) / SWEEPS, 3)},
-            "per_gpu": round(W * H * args.steps / dt / 1e6, 4),
+                       "evals_per_pixel_sweep": round((st.evals / (B * P) - 1) / SWEEPS, 3)},
+            "per_gpu": round(B * W * H * args.steps / dt / 1e6, 4),
+            "single_unit": {"ms": round(single_ms, 2), "Mpix/s": round(W * H / single_ms / 1e3, 3)},
             "kernel_ms": {"score_pass": round(st.ms_score, 3), "sweep_avg": round(st.ms_sweep_avg, 3),
                           "sweeps_total": round(st.ms_sweeps, 3), "end": round(st.ms_end, 3),
                           "estimate_total": round(st.ms_total, 3)},

@@ -31,6 +31,12 @@ class Stats(C.Structure):
                 ("n_sweeps", C.c_int32)]
 
 
+class BatchItem(C.Structure):
+    _fields_ = [("ref_id", C.c_uint32), ("src_ids", C.POINTER(C.c_uint32)), ("n_src", C.c_int32),
+                ("seed_offset", C.c_uint32), ("d_min", C.c_float), ("d_max", C.c_float), ("d_depth", C.c_void_p),
+                ("d_normal", C.c_void_p), ("d_conf", C.c_void_p)]
+
+
 class HcmvsError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("hcmvs error %d: %s" % (code, msg))
@@ -42,7 +48,7 @@ _lib = None
 # every symbol include/hcmvs_hip.h declares
 SYMBOLS = ["hcmvs_default_params", "hcmvs_create", "hcmvs_destroy", "hcmvs_last_error", "hcmvs_set_stream",
            "hcmvs_synchronize", "hcmvs_upload_view", "hcmvs_set_view_device", "hcmvs_release_view",
-           "hcmvs_get_gradient_map", "hcmvs_estimate", "hcmvs_estimate_device", "hcmvs_get_stats",
+           "hcmvs_get_gradient_map", "hcmvs_estimate", "hcmvs_estimate_device", "hcmvs_estimate_batch_device", "hcmvs_get_stats",
            "hcmvs_splat_init", "hcmvs_set_depthmap", "hcmvs_set_depthmap_device", "hcmvs_get_depthmap",
            "hcmvs_set_neighbors", "hcmvs_filter", "hcmvs_fuse"]
 
@@ -79,6 +85,7 @@ def lib():
         L.hcmvs_estimate.argtypes = [vp, C.c_uint32, u32p, C.c_int32, C.POINTER(Params), C.c_float, C.c_float, fp, fp, fp]
         L.hcmvs_estimate_device.argtypes = [vp, C.c_uint32, u32p, C.c_int32, C.POINTER(Params), C.c_float, C.c_float,
                                             vp, vp, vp]
+        L.hcmvs_estimate_batch_device.argtypes = [vp, C.POINTER(BatchItem), C.c_int32, C.POINTER(Params)]
         L.hcmvs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.hcmvs_splat_init.argtypes = [vp, C.c_uint32, fp, C.c_int32, fp, fp, fp, fp]
         u64p = C.POINTER(C.c_uint64)
@@ -198,6 +205,17 @@ class Context:
         self._chk(lib().hcmvs_estimate_device(self._h, ref_id, ids, len(src_ids), C.byref(params), d_min, d_max,
                                               C.c_void_p(d_depth_ptr), C.c_void_p(d_normal_ptr),
                                               C.c_void_p(d_conf_ptr)))
+
+    def estimate_batch_device(self, items, params):
+        """items: list of dicts (ref_id, src_ids, d_min, d_max, d_depth, d_normal, d_conf [device pointers], seed_offset)"""
+        arr = (BatchItem * len(items))()
+        keep = []
+        for i, it in enumerate(items):
+            ids = (C.c_uint32 * len(it["src_ids"]))(*it["src_ids"]); keep.append(ids)
+            arr[i].ref_id = it["ref_id"]; arr[i].src_ids = ids; arr[i].n_src = len(it["src_ids"])
+            arr[i].seed_offset = it.get("seed_offset", 0); arr[i].d_min = it["d_min"]; arr[i].d_max = it["d_max"]
+            arr[i].d_depth = it["d_depth"]; arr[i].d_normal = it["d_normal"]; arr[i].d_conf = it["d_conf"]
+        self._chk(lib().hcmvs_estimate_batch_device(self._h, arr, len(items), C.byref(params)))
 
     def stats(self):
         s = Stats()

@@ -22,6 +22,8 @@ using namespace hcmvs;
 
 namespace {
 
+constexpr int kMaxBatch = 16; // reference images estimated by one call
+
 struct View {
 	int w = 0, h = 0;
 	float* gray = nullptr;   // device
@@ -45,19 +47,23 @@ struct hcmvs_ctx {
 	hipStream_t stream = nullptr;
 	std::string err;
 	std::map<uint32_t, View> views;
-	// working buffers (grown on demand)
+	// working buffers of the batch items (grown on demand)
+	struct Slot {
+		size_t capPixels = 0; float4* dn = nullptr; float* conf = nullptr; float* tmpDepth = nullptr;
+		size_t capRows = 0; int32_t* progress = nullptr;
+		size_t capSlab = 0; char* srcSlab = nullptr; // compact copy of an item's source images when they are > 4 GiB apart
+	};
+	std::vector<Slot> slots;
 	size_t capPixels = 0;
-	float4* dn = nullptr;
-	float* conf = nullptr;
-	float* tmpDepth = nullptr;
-	uint8_t* tmpU8 = nullptr;
+	uint8_t* tmpU8 = nullptr; // gradient-map staging
 	// host-path staging
 	size_t capStage = 0;
 	float *sDepth = nullptr, *sNormal = nullptr, *sConf = nullptr;
-	DevView* dViews = nullptr;
-	DevView hViews[kMaxViews]; // host copy handed to hipMemcpyAsync (must outlive the call)
-	int32_t* sync = nullptr; // [ticket, error, pad..., progress rows]
-	size_t capSyncInts = 0;
+	DevView* dViews = nullptr;           // [kMaxBatch][kMaxViews]
+	std::vector<DevView> hViews;          // host copy handed to hipMemcpyAsync (must outlive the call)
+	EstConst* dItems = nullptr;           // [kMaxBatch]
+	std::vector<EstConst> hItems;
+	int32_t* sync = nullptr;              // [ticket, error, pad...]
 	unsigned long long* evals = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	int lastSweeps = 0;
@@ -67,7 +73,7 @@ struct hcmvs_ctx {
 	DevMap* dMaps = nullptr; size_t capMaps = 0;
 	unsigned long long* counters = nullptr;
 	void* fuseScratch = nullptr; size_t capFuseScratch = 0;
-	int wavesPerRow = 2;
+	int wavesPerRow = 0; // 0 = automatic: 2 waves per row for small batches (latency), 1 when >= 3 images fill the chip
 };
 
 static int fail(hcmvs_ctx* c, int code, const char* fmt, ...) {
@@ -162,14 +168,16 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 	c->stream = c->ownStream;
 	for (auto& e : c->ev)
 		if (hipEventCreate(&e) != hipSuccess) { delete c; return HCMVS_ERR_NO_DEVICE; }
-	if (hipMalloc(&c->dViews, sizeof(DevView) * kMaxViews) != hipSuccess || hipMalloc(&c->evals, 32) != hipSuccess) {
+	c->hViews.resize((size_t)kMaxBatch * kMaxViews); c->hItems.resize(kMaxBatch);
+	if (hipMalloc(&c->dViews, sizeof(DevView) * kMaxViews * kMaxBatch) != hipSuccess || hipMalloc(&c->evals, 32) != hipSuccess ||
+	    hipMalloc(&c->dItems, sizeof(EstConst) * kMaxBatch) != hipSuccess || hipMalloc(&c->sync, 64) != hipSuccess) {
 		delete c;
 		return HCMVS_ERR_NO_DEVICE;
 	}
 	const char* lag = getenv("HCMVS_SWEEP_LAG");
 	if (lag && atoi(lag) >= 1) c->sweepLag = atoi(lag);
-	const char* wpr = getenv("HCMVS_WAVES_PER_ROW"); // tuning knob: 1, 2, 3, 4, 6 or 8 waves cooperate on one image row
-	if (wpr && (atoi(wpr) == 1 || atoi(wpr) == 2 || atoi(wpr) == 3 || atoi(wpr) == 4 || atoi(wpr) == 6 || atoi(wpr) == 8)) c->wavesPerRow = atoi(wpr);
+	const char* wpr = getenv("HCMVS_WAVES_PER_ROW"); // tuning knob: 1, 2, 3 or 4 waves cooperate on one image row
+	if (wpr && (atoi(wpr) == 1 || atoi(wpr) == 2 || atoi(wpr) == 3 || atoi(wpr) == 4)) c->wavesPerRow = atoi(wpr);
 	*out = c;
 	return HCMVS_OK;
 }
@@ -192,8 +200,9 @@ void hcmvs_destroy(hcmvs_ctx* c) {
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	for (auto& kv : c->views) free_view(kv.second);
-	for (void* p : {(void*)c->dn, (void*)c->conf, (void*)c->tmpDepth, (void*)c->tmpU8, (void*)c->sDepth, (void*)c->sNormal,
-	                (void*)c->sConf, (void*)c->dViews, (void*)c->sync, (void*)c->evals, (void*)c->dMaps, (void*)c->counters, c->fuseScratch})
+	for (auto& sl : c->slots) for (void* p : {(void*)sl.dn, (void*)sl.conf, (void*)sl.tmpDepth, (void*)sl.progress, (void*)sl.srcSlab}) if (p) (void)hipFree(p);
+	for (void* p : {(void*)c->tmpU8, (void*)c->sDepth, (void*)c->sNormal, (void*)c->sConf, (void*)c->dViews, (void*)c->dItems, (void*)c->sync,
+	                (void*)c->evals, (void*)c->dMaps, (void*)c->counters, c->fuseScratch})
 		if (p) (void)hipFree(p);
 	for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -261,24 +270,34 @@ int hcmvs_release_view(hcmvs_ctx* c, uint32_t id) {
 	return HCMVS_OK;
 }
 
-static int ensure_work(hcmvs_ctx* c, size_t n, int rows) {
+static int ensure_slot(hcmvs_ctx* c, int i, size_t n, int rows) {
+	if ((int)c->slots.size() <= i) c->slots.resize((size_t)i + 1);
+	hcmvs_ctx::Slot& sl = c->slots[i];
+	if (n > sl.capPixels) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		for (void* p : {(void*)sl.dn, (void*)sl.conf, (void*)sl.tmpDepth}) if (p) (void)hipFree(p);
+		sl.dn = nullptr; sl.conf = nullptr; sl.tmpDepth = nullptr; sl.capPixels = 0;
+		HIPCHK(c, hipMalloc(&sl.dn, n * sizeof(float4)));
+		HIPCHK(c, hipMalloc(&sl.conf, n * sizeof(float)));
+		HIPCHK(c, hipMalloc(&sl.tmpDepth, n * sizeof(float)));
+		sl.capPixels = n;
+	}
+	if ((size_t)rows > sl.capRows) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		if (sl.progress) (void)hipFree(sl.progress);
+		sl.progress = nullptr; sl.capRows = 0;
+		HIPCHK(c, hipMalloc(&sl.progress, (size_t)rows * kProgressStride * sizeof(int32_t)));
+		sl.capRows = (size_t)rows;
+	}
+	return HCMVS_OK;
+}
+static int ensure_u8(hcmvs_ctx* c, size_t n) {
 	if (n > c->capPixels) {
 		HIPCHK(c, hipStreamSynchronize(c->stream));
-		for (void* p : {(void*)c->dn, (void*)c->conf, (void*)c->tmpDepth, (void*)c->tmpU8}) if (p) (void)hipFree(p);
-		c->dn = nullptr; c->conf = nullptr; c->tmpDepth = nullptr; c->tmpU8 = nullptr; c->capPixels = 0;
-		HIPCHK(c, hipMalloc(&c->dn, n * sizeof(float4)));
-		HIPCHK(c, hipMalloc(&c->conf, n * sizeof(float)));
-		HIPCHK(c, hipMalloc(&c->tmpDepth, n * sizeof(float)));
+		if (c->tmpU8) (void)hipFree(c->tmpU8);
+		c->tmpU8 = nullptr; c->capPixels = 0;
 		HIPCHK(c, hipMalloc(&c->tmpU8, n));
 		c->capPixels = n;
-	}
-	const size_t ints = 16 + (size_t)rows * kProgressStride;
-	if (ints > c->capSyncInts) {
-		HIPCHK(c, hipStreamSynchronize(c->stream));
-		if (c->sync) (void)hipFree(c->sync);
-		c->sync = nullptr; c->capSyncInts = 0;
-		HIPCHK(c, hipMalloc(&c->sync, ints * sizeof(int32_t)));
-		c->capSyncInts = ints;
 	}
 	return HCMVS_OK;
 }
@@ -287,7 +306,7 @@ static int ensure_work(hcmvs_ctx* c, size_t n, int rows) {
 static int ensure_gradient(hcmvs_ctx* c, View& v) {
 	if (v.gra) return HCMVS_OK;
 	const int n = v.w * v.h;
-	int rc = ensure_work(c, (size_t)n, v.h);
+	int rc = ensure_u8(c, (size_t)n);
 	if (rc) return rc;
 	HIPCHK(c, hipMalloc(&v.gra, (size_t)n));
 	if (v.bgr) launch_bgr_to_u8(v.bgr, c->tmpU8, n, c->stream);
@@ -309,52 +328,76 @@ int hcmvs_get_gradient_map(hcmvs_ctx* c, uint32_t id, uint8_t* out) {
 	return HCMVS_OK;
 }
 
-int hcmvs_estimate_device(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* src_ids, int32_t n_src, const hcmvs_params* p,
-                          float d_min, float d_max, float* d_depth, float* d_normal, float* d_conf) {
-	if (!c) return HCMVS_ERR_INVALID;
-	if (!src_ids || !p || !d_depth || !d_normal || !d_conf) return fail(c, HCMVS_ERR_INVALID, "estimate: null argument");
+// per-item constants: DepthMap.cpp:386-439, DepthMap.h:412-444
+static int build_item(hcmvs_ctx* c, int slot, const hcmvs_batch_item& it, const hcmvs_params* p, EstConst& k) {
+	if (!it.src_ids || !it.d_depth || !it.d_normal || !it.d_conf) return fail(c, HCMVS_ERR_INVALID, "estimate: null argument");
+	const int n_src = it.n_src;
 	if (n_src < 1 || n_src > HCMVS_MAX_VIEWS) return fail(c, HCMVS_ERR_INVALID, "estimate: n_src %d not in 1..%d", n_src, HCMVS_MAX_VIEWS);
-	if (p->adapthalfwin < 1 || p->adapthalfwin > kHalfWindow) return fail(c, HCMVS_ERR_INVALID, "estimate: adapthalfwin %d not in 1..7", p->adapthalfwin);
-	if (p->n_estimation_iters < 0 || p->n_random_iters < 0 || p->n_random_iters > 20)
-		return fail(c, HCMVS_ERR_INVALID, "estimate: bad iteration counts");
-	if (!(d_min > 0.f) || !(d_max > d_min)) return fail(c, HCMVS_ERR_INVALID, "estimate: bad depth range [%g,%g)", d_min, d_max);
-	auto rit = c->views.find(ref_id);
-	if (rit == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "estimate: unknown reference view %u", ref_id);
+	if (!(it.d_min > 0.f) || !(it.d_max > it.d_min)) return fail(c, HCMVS_ERR_INVALID, "estimate: bad depth range [%g,%g)", it.d_min, it.d_max);
+	auto rit = c->views.find(it.ref_id);
+	if (rit == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "estimate: unknown reference view %u", it.ref_id);
 	View& ref = rit->second;
-	HIPCHK(c, hipSetDevice(c->device));
-	int rc = ensure_work(c, (size_t)ref.w * ref.h, ref.h);
+	int rc = ensure_slot(c, slot, (size_t)ref.w * ref.h, ref.h);
 	if (rc) return rc;
 	rc = ensure_gradient(c, ref);
 	if (rc) return rc;
-
-	// per-call constants: DepthMap.cpp:386-439, DepthMap.h:412-444
-	EstConst k;
 	memset(&k, 0, sizeof k);
 	k.W = ref.w; k.H = ref.h; k.V = n_src;
 	k.adapthalfwin = p->adapthalfwin; k.nRandomIters = p->n_random_iters; k.itExternal = p->it_external;
 	k.propHalfwin = p->propagate_halfwin; k.propStep = p->propagate_step;
-	k.ref = ref.gray; k.gra = ref.gra; k.views = c->dViews;
+	k.ref = ref.gray; k.gra = ref.gra; k.views = c->dViews + (size_t)slot * kMaxViews;
 	double Hr[9];
 	mat3_inv(ref.K, Hr);
 	for (int i = 0; i < 9; ++i) k.Hr[i] = (float)Hr[i];
 	k.ifx = 1.0 / ref.K[0]; k.ify = 1.0 / ref.K[4]; k.cx = ref.K[2]; k.cy = ref.K[5];
-	DevView* hv = c->hViews;
-	memset(hv, 0, sizeof c->hViews);
+	DevView* hv = c->hViews.data() + (size_t)slot * kMaxViews;
+	memset(hv, 0, sizeof(DevView) * kMaxViews);
+	uintptr_t lo = ~(uintptr_t)0, hi = 0;
 	for (int v = 0; v < n_src; ++v) {
-		auto sit = c->views.find(src_ids[v]);
-		if (sit == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "estimate: unknown source view %u", src_ids[v]);
+		auto sit = c->views.find(it.src_ids[v]);
+		if (sit == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "estimate: unknown source view %u", it.src_ids[v]);
 		const View& s = sit->second;
-		double KR[9], Hl[9];
+		double KR[9], Hl[9], A[9];
 		mat3_mul(s.K, s.R, KR);
 		mat3_mul_bt(KR, ref.R, Hl);
 		const double dC[3] = {ref.C[0] - s.C[0], ref.C[1] - s.C[1], ref.C[2] - s.C[2]};
-		double A[9];
 		for (int i = 0; i < 3; ++i) hv[v].Hm[i] = (float)(KR[i * 3] * dC[0] + KR[i * 3 + 1] * dC[1] + KR[i * 3 + 2] * dC[2]);
 		mat3_mul(Hl, Hr, A);
 		for (int i = 0; i < 9; ++i) hv[v].A[i] = (float)A[i];
-		hv[v].img = s.gray; hv[v].w = s.w; hv[v].h = s.h;
+		hv[v].w = s.w; hv[v].h = s.h;
+		const uintptr_t b = (uintptr_t)s.gray, e = b + (size_t)s.w * s.h * 4;
+		if (b < lo) lo = b;
+		if (e > hi) hi = e;
 	}
-	k.dMin = d_min; k.dMax = d_max; k.dMinSqr = sqrtf(d_min); k.dMaxSqr = sqrtf(d_max);
+	// 32-bit texel offsets from one scalar base: the source views of one item must lie within a 4 GiB window.
+	// When the caller's images are further apart they are first copied (device to device, a few tens of MB) into a
+	// compact slab owned by the context.
+	if (hi - lo < 0xFFFF0000ull) {
+		k.imgBase = (const char*)lo;
+		for (int v = 0; v < n_src; ++v) hv[v].byteOff = (uint32_t)((uintptr_t)c->views.find(it.src_ids[v])->second.gray - lo);
+	} else {
+		size_t total = 0;
+		for (int v = 0; v < n_src; ++v) { const View& s = c->views.find(it.src_ids[v])->second; total += ((size_t)s.w * s.h * 4 + 255) & ~(size_t)255; }
+		if (total >= 0xFFFF0000ull) return fail(c, HCMVS_ERR_INVALID, "estimate: the source images of one item exceed 4 GiB");
+		hcmvs_ctx::Slot& sl = c->slots[slot];
+		if (total > sl.capSlab) {
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			if (sl.srcSlab) (void)hipFree(sl.srcSlab);
+			sl.srcSlab = nullptr; sl.capSlab = 0;
+			HIPCHK(c, hipMalloc(&sl.srcSlab, total));
+			sl.capSlab = total;
+		}
+		size_t off = 0;
+		for (int v = 0; v < n_src; ++v) {
+			const View& s = c->views.find(it.src_ids[v])->second;
+			const size_t bytes = (size_t)s.w * s.h * 4;
+			HIPCHK(c, hipMemcpyAsync(sl.srcSlab + off, s.gray, bytes, hipMemcpyDeviceToDevice, c->stream));
+			hv[v].byteOff = (uint32_t)off;
+			off += (bytes + 255) & ~(size_t)255;
+		}
+		k.imgBase = sl.srcSlab;
+	}
+	k.dMin = it.d_min; k.dMax = it.d_max; k.dMinSqr = sqrtf(it.d_min); k.dMaxSqr = sqrtf(it.d_max);
 	k.smoothBonusDepth = 1.f - p->random_smooth_bonus;
 	k.smoothBonusNormal = (1.f - p->random_smooth_bonus) * 0.96f;
 	k.smoothSigmaDepth = -1.f / (2.f * (p->random_smooth_depth * p->random_smooth_depth));
@@ -368,36 +411,72 @@ int hcmvs_estimate_device(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* src_ids
 	k.thKeep = p->ncc_threshold_keep;
 	k.depthRatio = p->random_depth_ratio;
 	k.pfScale = 1.f - p->photometric_flow;
-	k.seed = p->seed;
-	k.dn = c->dn; k.conf = c->conf;
+	k.seed = p->seed + it.seed_offset;
+	k.dn = c->slots[slot].dn; k.conf = c->slots[slot].conf; k.progress = c->slots[slot].progress;
+	return HCMVS_OK;
+}
 
+int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int32_t n_items, const hcmvs_params* p) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!items || !p) return fail(c, HCMVS_ERR_INVALID, "estimate: null argument");
+	if (n_items < 1 || n_items > kMaxBatch) return fail(c, HCMVS_ERR_INVALID, "estimate: batch size %d not in 1..%d", n_items, kMaxBatch);
+	if (p->adapthalfwin < 1 || p->adapthalfwin > kHalfWindow) return fail(c, HCMVS_ERR_INVALID, "estimate: adapthalfwin %d not in 1..7", p->adapthalfwin);
+	if (p->n_estimation_iters < 0 || p->n_random_iters < 0 || p->n_random_iters > 20)
+		return fail(c, HCMVS_ERR_INVALID, "estimate: bad iteration counts");
+	HIPCHK(c, hipSetDevice(c->device));
+	int maxRows = 0, totalRows = 0;
+	for (int i = 0; i < n_items; ++i) {
+		if (items[i].n_src != items[0].n_src) return fail(c, HCMVS_ERR_INVALID, "estimate: all items of a batch must use the same number of source views");
+		int rc = build_item(c, i, items[i], p, c->hItems[i]);
+		if (rc) return rc;
+		const int rows = c->hItems[i].H - 2 * kHalfWindow;
+		if (rows > maxRows) maxRows = rows;
+		totalRows += rows;
+	}
 	hipStream_t s = c->stream;
-	// the previous call's copy of the view table must not be overwritten while in use: same stream => ordered
-	HIPCHK(c, hipMemcpyAsync(c->dViews, hv, sizeof(DevView) * n_src, hipMemcpyHostToDevice, s));
+	// same stream => the previous call's kernels are done with these tables before the copies land
+	HIPCHK(c, hipMemcpyAsync(c->dViews, c->hViews.data(), sizeof(DevView) * kMaxViews * n_items, hipMemcpyHostToDevice, s));
+	HIPCHK(c, hipMemcpyAsync(c->dItems, c->hItems.data(), sizeof(EstConst) * n_items, hipMemcpyHostToDevice, s));
 	HIPCHK(c, hipMemsetAsync(c->evals, 0, 32, s));
+	HIPCHK(c, hipMemsetAsync(c->sync, 0, 64, s));
 
 	HIPCHK(c, hipEventRecord(c->ev[0], s));
-	const float* depthIn = d_depth;
-	if (p->median_blur) { // SceneDensify.cpp:859
-		launch_median3(d_depth, c->tmpDepth, ref.w, ref.h, s);
-		depthIn = c->tmpDepth;
+	for (int i = 0; i < n_items; ++i) {
+		const EstConst& k = c->hItems[i];
+		const float* depthIn = items[i].d_depth;
+		if (p->median_blur) { // SceneDensify.cpp:859
+			launch_median3(items[i].d_depth, c->slots[i].tmpDepth, k.W, k.H, s);
+			depthIn = c->slots[i].tmpDepth;
+		}
+		launch_score_pass(k, depthIn, items[i].d_normal, c->evals, s);
 	}
-	launch_score_pass(k, depthIn, d_normal, c->evals, s);
 	HIPCHK(c, hipEventRecord(c->ev[1], s));
-	const int rows = ref.h - 2 * kHalfWindow;
 	SweepSync sy;
-	sy.ticket = c->sync; sy.error = c->sync + 1; sy.progress = c->sync + 16; sy.evals = c->evals;
+	sy.ticket = c->sync; sy.error = c->sync + 1; sy.evals = c->evals;
 	for (int iter = 0; iter < p->n_estimation_iters; ++iter) {
-		HIPCHK(c, hipMemsetAsync(c->sync, 0, (16 + (size_t)rows * kProgressStride) * sizeof(int32_t), s));
-		launch_sweep(k, sy, iter, c->sweepLag, c->wavesPerRow, s);
+		HIPCHK(c, hipMemsetAsync(c->sync, 0, 4, s)); // the ticket; the error word stays sticky
+		for (int i = 0; i < n_items; ++i)
+			HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * kHalfWindow) * kProgressStride * sizeof(int32_t), s));
+		launch_sweep(c->dItems, n_items, maxRows, totalRows, items[0].n_src, sy, iter, c->sweepLag,
+		             c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : 2), s);
 	}
 	HIPCHK(c, hipEventRecord(c->ev[2], s));
-	launch_end_pass(k, p->it_external == p->n_external_iters - 1 ? 1 : 0, d_depth, d_normal, d_conf, s);
+	for (int i = 0; i < n_items; ++i)
+		launch_end_pass(c->hItems[i], p->it_external == p->n_external_iters - 1 ? 1 : 0, items[i].d_depth, items[i].d_normal, items[i].d_conf, s);
 	HIPCHK(c, hipEventRecord(c->ev[3], s));
 	HIPCHK(c, hipGetLastError());
 	c->lastSweeps = p->n_estimation_iters;
 	c->haveStats = true;
 	return HCMVS_OK;
+}
+
+int hcmvs_estimate_device(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* src_ids, int32_t n_src, const hcmvs_params* p,
+                          float d_min, float d_max, float* d_depth, float* d_normal, float* d_conf) {
+	hcmvs_batch_item it;
+	memset(&it, 0, sizeof it);
+	it.ref_id = ref_id; it.src_ids = src_ids; it.n_src = n_src; it.d_min = d_min; it.d_max = d_max;
+	it.d_depth = d_depth; it.d_normal = d_normal; it.d_conf = d_conf; it.seed_offset = 0;
+	return hcmvs_estimate_batch_device(c, &it, 1, p);
 }
 
 int hcmvs_get_stats(hcmvs_ctx* c, hcmvs_stats* out) {

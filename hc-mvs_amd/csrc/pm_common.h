@@ -16,7 +16,7 @@ constexpr int kProgressStride = 16; // ints between the progress words of consec
 
 // per source view constants, one lane group reads its own view's entry (DepthMap.h:412-444 ViewData)
 struct DevView {
-	const float* img;
+	uint32_t byteOff; // image start relative to EstConst::imgBase
 	int32_t w, h;
 	float A[9];  // Hl * Hr = Kj Rj Ri^T Ki^-1 (computed in double on the host, held as float)
 	float Hm[3]; // Kj Rj (Ci - Cj)
@@ -29,6 +29,7 @@ struct EstConst {
 	const float* ref;
 	const uint8_t* gra;
 	const DevView* views;
+	const char* imgBase;    // lowest source-image address of this call (32-bit offsets from here)
 	float Hr[9];            // Ki^-1 (double on the host, held as float)
 	double cx, cy, ifx, ify; // reference principal point and 1/focal (Camera.h:299-312)
 	float dMin, dMax, dMinSqr, dMaxSqr;
@@ -40,11 +41,11 @@ struct EstConst {
 	// working state: (depth, nx, ny, nz) per pixel + score per pixel
 	float4* dn;
 	float* conf;
+	int32_t* progress; // [rows * kProgressStride] pixels finished per logical row of this image (sweeps)
 };
 
 struct SweepSync {
-	int32_t* progress; // [rows * kProgressStride] pixels finished per logical row
-	int32_t* ticket;   // next logical row to hand out
+	int32_t* ticket;   // next (row, image) pair to hand out
 	int32_t* error;    // set non-zero when a worker times out
 	unsigned long long* evals;  // [0] ScorePixel calls of the sequential algorithm, [1] evaluations issued (incl. speculative), [2] patch taps of [0]
 };
@@ -56,7 +57,8 @@ void launch_gradient_map(const uint8_t* g8, uint8_t* gra, int W, int H, hipStrea
 void launch_median3(const float* in, float* out, int W, int H, hipStream_t s);
 void launch_score_pass(const EstConst& c, const float* depthIn, const float* normalIn, unsigned long long* evals,
                        hipStream_t s);
-void launch_sweep(const EstConst& c, const SweepSync& sync, int iter, int lag, int wavesPerRow, hipStream_t s);
+void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int lag,
+                  int wavesPerRow, hipStream_t s);
 void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s);
 
 } // namespace hcmvs

@@ -143,8 +143,8 @@ struct LaneCtx {
 	static constexpr int MAXM = 64 / S; // taps per lane
 	int lane, view, seg;
 	bool vact;        // lane's view group exists
-	gcfptr img;       // my source view
-	int iw;
+	unsigned imgOff;  // byte offset of my source view from EstConst::imgBase (all views of a call lie within 4 GiB)
+	int iw, ixmax, iymax; // row pitch in pixels; largest top-left texel column / row of a bilinear footprint
 	float wmax, hmax; // inside-with-border-1 limits of my view
 	float A[9], Hm[3];
 	unsigned long long groupMask;
@@ -157,7 +157,7 @@ __device__ __forceinline__ void lane_init(const EstConst& c, LaneCtx<S>& L) {
 	L.seg = L.lane % S;
 	L.vact = L.view < c.V;
 	const DevView* dv = &c.views[L.vact ? L.view : 0]; // idle groups mirror view 0 (results masked)
-	L.img = (gcfptr)dv->img; L.iw = dv->w;
+	L.imgOff = dv->byteOff; L.iw = dv->w; L.ixmax = dv->w - 2; L.iymax = dv->h - 2;
 	L.wmax = (float)(dv->w - 2); L.hmax = (float)(dv->h - 2);
 #pragma unroll
 	for (int i = 0; i < 9; ++i) L.A[i] = dv->A[i];
@@ -170,7 +170,7 @@ template <int S>
 struct Patch { // DepthMap.h:202-212 WeightedPatchFix, spread over the lanes of a group
 	static constexpr int MAXM = 64 / S;
 	float w[MAXM], tw[MAXM];
-	float sumW, normSq0;
+	float sumW, invSumW, normSq0;
 	int x, y, a;
 };
 
@@ -263,6 +263,7 @@ __device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& 
 		sa = fmaf(P.tw[m], t, sa);
 	}
 	P.sumW = sw;
+	P.invSumW = 1.0f / sw;
 	P.normSq0 = group_sum<S>(sa);
 	P.x = x; P.y = y; P.a = a;
 }
@@ -282,119 +283,170 @@ struct PixelGeom {
 	float pn0, pn1, pn2, pd;  // smoothness plane (DepthMap.cpp:1730-1738)
 };
 
-// DepthMap.cpp:987-1046 ScorePixel over DepthMap.cpp:522-616 ScorePixelImage, all views at once.
-// corrMask: slots whose corrected normal is already in effect for this hypothesis.
-template <int S>
-__device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const Close& C,
-                                             unsigned long long corrMask, const PixelGeom& G, float depth, float n0,
-                                             float n1, float n2) {
+// DepthMap.cpp:987-1046 ScorePixel over DepthMap.cpp:522-616 ScorePixelImage, all views at once, for NH
+// hypotheses in ONE instruction stream: the NH evaluations are independent, so writing every phase as a loop over
+// them lets the scheduler overlap one hypothesis' dependent chains and load latency with the other's arithmetic.
+// smoothF: product of the plane-smoothness factors of the hypothesis (DepthMap.cpp:607-615), see smooth_pass().
+template <int S, int NH>
+__device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, float v0, float v1,
+                                            const float (&smoothF)[NH], const float (&depth)[NH], const float (&n0)[NH],
+                                            const float (&n1)[NH], const float (&n2)[NH], float (&out)[NH]) {
 	constexpr int MAXM = 64 / S;
-	// smoothness factor of my slot (DepthMap.cpp:607-615); slot k is lane k
-	float f = 1.f;
-	if ((C.closeMask >> L.lane) & 1ull) {
-		const bool corr = (corrMask >> L.lane) & 1ull;
-		const float c0 = corr ? C.k0 : C.n0, c1 = corr ? C.k1 : C.n1, c2 = corr ? C.k2 : C.n2;
-		const float dist = dot3(G.pn0, G.pn1, G.pn2, C.X0, C.X1, C.X2) + G.pd;
-		const float fd = pm_expf(HC_SQ(dist / depth) * c.smoothSigmaDepth);
-		float ca = dot3(n0, n1, n2, c0, c1, c2) / sqrtf(dot3(n0, n1, n2, n0, n1, n2) * dot3(c0, c1, c2, c0, c1, c2));
-		ca = ca < -1.f ? -1.f : (ca > 1.f ? 1.f : ca);
-		const float ang = pm_acosf(ca);
-		const float fn = pm_expf(HC_SQ(ang) * c.smoothSigmaNormal);
-		f = (1.f - c.smoothBonusDepth * fd) * (1.f - c.smoothBonusNormal * fn);
-	}
 	// homography of my view (DepthMap.h:565-574), association H = A + Hm (Hr^T n)^T / (n.X0 d)
-	float H[9];
-	{
-		const float nx0 = fmaf(n2, 1.0f, fmaf(n1, G.v1, n0 * G.v0));
-		const float inv = 1.0f / (nx0 * depth);
+	float H[NH][9];
+#pragma unroll
+	for (int h = 0; h < NH; ++h) {
+		const float nx0 = fmaf(n2[h], 1.0f, fmaf(n1[h], v1, n0[h] * v0));
+		const float inv = 1.0f / (nx0 * depth[h]);
 		float q[3];
 #pragma unroll
-		for (int j = 0; j < 3; ++j) q[j] = fmaf(n2, c.Hr[6 + j], fmaf(n1, c.Hr[3 + j], n0 * c.Hr[j])) * inv;
+		for (int j = 0; j < 3; ++j) q[j] = fmaf(n2[h], c.Hr[6 + j], fmaf(n1[h], c.Hr[3 + j], n0[h] * c.Hr[j])) * inv;
 #pragma unroll
 		for (int i = 0; i < 3; ++i)
 #pragma unroll
-			for (int j = 0; j < 3; ++j) H[i * 3 + j] = fmaf(L.Hm[i], q[j], L.A[i * 3 + j]);
+			for (int j = 0; j < 3; ++j) H[h][i * 3 + j] = fmaf(L.Hm[i], q[j], L.A[i * 3 + j]);
 	}
-	// three straight-line phases so that all 2*MAXM row loads of an evaluation are in flight together:
-	// (1) warp every tap, (2) issue the loads, (3) interpolate + accumulate.  Out-of-image taps only raise
-	// `bad`; their loads go to offset 0.
-	float Xx[MAXM], Xy[MAXM], Xz[MAXM], iz[MAXM];
+	// (1) warp every tap, (2) issue all loads, (3) interpolate + accumulate.  The inside-the-image test
+	// (Types.h:1633-1635) is done once per hypothesis on the min/max of the warped coordinates; texel addresses are
+	// clamped into the image, so taps that fall outside read valid memory and only raise `bad`.
+	float fx[NH][MAXM], fy[NH][MAXM];
+	unsigned off[NH][MAXM];
+	bool bad[NH];
 #pragma unroll
-	for (int m = 0; m < MAXM; ++m) {
-		int ti, tj;
-		tap_offset<S>(P.a, L.seg, m, ti, tj);
-		const float px = (float)(P.x + tj), py = (float)(P.y + ti);
-		Xx[m] = fmaf(H[0], px, fmaf(H[1], py, H[2]));
-		Xy[m] = fmaf(H[3], px, fmaf(H[4], py, H[5]));
-		Xz[m] = fmaf(H[6], px, fmaf(H[7], py, H[8]));
-	}
-	// perspective divide: ONE IEEE reciprocal per group of up to four taps (1/z_i = (1/prod z) * prod_{j!=i} z_j)
-	if constexpr (MAXM >= 4) {
+	for (int h = 0; h < NH; ++h) {
+		float Xx[MAXM], Xy[MAXM], Xz[MAXM], iz[MAXM];
+		// a segment walks down one patch column: the column term of the warp is hoisted (S >= 8)
+		int ti0, tj0;
+		tap_offset<S>(P.a, L.seg, 0, ti0, tj0);
+		const float px0 = (float)(P.x + tj0);
+		const float bx = fmaf(H[h][0], px0, H[h][2]), by = fmaf(H[h][3], px0, H[h][5]), bz = fmaf(H[h][6], px0, H[h][8]);
 #pragma unroll
-		for (int g = 0; g < MAXM; g += 4) {
-			const float p01 = Xz[g] * Xz[g + 1], p23 = Xz[g + 2] * Xz[g + 3];
-			const float r = 1.0f / (p01 * p23);
-			const float r01 = r * p23, r23 = r * p01;
-			iz[g] = r01 * Xz[g + 1]; iz[g + 1] = r01 * Xz[g];
-			iz[g + 2] = r23 * Xz[g + 3]; iz[g + 3] = r23 * Xz[g + 2];
+		for (int m = 0; m < MAXM; ++m) {
+			int ti, tj;
+			tap_offset<S>(P.a, L.seg, m, ti, tj);
+			const float py = (float)(P.y + ti);
+			if constexpr (S >= 8) {
+				Xx[m] = fmaf(H[h][1], py, bx); Xy[m] = fmaf(H[h][4], py, by); Xz[m] = fmaf(H[h][7], py, bz);
+			} else { // S == 4: a segment covers two columns
+				const float px = (float)(P.x + tj);
+				Xx[m] = fmaf(H[h][1], py, fmaf(H[h][0], px, H[h][2]));
+				Xy[m] = fmaf(H[h][4], py, fmaf(H[h][3], px, H[h][5]));
+				Xz[m] = fmaf(H[h][7], py, fmaf(H[h][6], px, H[h][8]));
+			}
 		}
-	} else if constexpr (MAXM == 2) {
-		const float r = 1.0f / (Xz[0] * Xz[1]);
-		iz[0] = r * Xz[1]; iz[1] = r * Xz[0];
-	} else {
-		iz[0] = 1.0f / Xz[0];
-	}
-	float fx[MAXM], fy[MAXM];
-	int off[MAXM];
-	bool bad = false;
+		bool nan = false;
+		// perspective divide: ONE IEEE reciprocal per group of up to four taps (1/z_i = (1/prod z) * prod_{j!=i} z_j)
+		if constexpr (MAXM >= 4) {
 #pragma unroll
-	for (int m = 0; m < MAXM; ++m) {
-		const float qx = Xx[m] * iz[m], qy = Xy[m] * iz[m];
-		const bool inside = qx >= 1.f && qy >= 1.f && qx <= L.wmax && qy <= L.hmax; // Types.h:1633-1635
-		bad = bad || !inside;
-		const int lx = (int)qx, ly = (int)qy;
-		fx[m] = qx - (float)lx;
-		fy[m] = qy - (float)ly;
-		off[m] = inside ? __mul24(ly, L.iw) + lx : 0;
-	}
-	float2 top[MAXM], bot[MAXM];
+			for (int g = 0; g < MAXM; g += 4) {
+				const float p01 = Xz[g] * Xz[g + 1], p23 = Xz[g + 2] * Xz[g + 3];
+				const float r = 1.0f / (p01 * p23);
+				nan = nan || !(fabsf(r) < __builtin_huge_valf()); // a zero / non-finite denominator poisons the group
+				const float r01 = r * p23, r23 = r * p01;
+				iz[g] = r01 * Xz[g + 1]; iz[g + 1] = r01 * Xz[g];
+				iz[g + 2] = r23 * Xz[g + 3]; iz[g + 3] = r23 * Xz[g + 2];
+			}
+		} else if constexpr (MAXM == 2) {
+			const float r = 1.0f / (Xz[0] * Xz[1]);
+			nan = nan || !(fabsf(r) < __builtin_huge_valf());
+			iz[0] = r * Xz[1]; iz[1] = r * Xz[0];
+		} else {
+			iz[0] = 1.0f / Xz[0];
+			nan = nan || !(fabsf(iz[0]) < __builtin_huge_valf());
+		}
+		float qxlo = __builtin_huge_valf(), qxhi = -__builtin_huge_valf(), qylo = __builtin_huge_valf(), qyhi = -__builtin_huge_valf();
 #pragma unroll
-	for (int m = 0; m < MAXM; ++m) {
-		gcfptr r0 = L.img + off[m];
-		gcfptr r1 = r0 + L.iw;
-		top[m] = make_float2(r0[0], r0[1]);
-		bot[m] = make_float2(r1[0], r1[1]);
+		for (int m = 0; m < MAXM; ++m) {
+			const float qx = Xx[m] * iz[m], qy = Xy[m] * iz[m];
+			qxlo = fminf(qxlo, qx); qxhi = fmaxf(qxhi, qx); qylo = fminf(qylo, qy); qyhi = fmaxf(qyhi, qy);
+			int lx = (int)qx, ly = (int)qy;
+			fx[h][m] = qx - floorf(qx);
+			fy[h][m] = qy - floorf(qy);
+			lx = lx < 0 ? 0 : (lx > L.ixmax ? L.ixmax : lx);
+			ly = ly < 0 ? 0 : (ly > L.iymax ? L.iymax : ly);
+			off[h][m] = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 2);
+		}
+		bad[h] = nan || !(qxlo >= 1.f && qylo >= 1.f && qxhi <= L.wmax && qyhi <= L.hmax);
 	}
-	float sum = 0.f, sumSq = 0.f, num = 0.f;
+	float2 top[NH][MAXM], bot[NH][MAXM];
+	const char* __restrict__ imgBase = c.imgBase;
+	const unsigned pitch = (unsigned)L.iw << 2;
 #pragma unroll
-	for (int m = 0; m < MAXM; ++m) {
-		// bilinear sample (Types.inl:2250-2258) in lerp form
-		const float t = fmaf(fx[m], top[m].y - top[m].x, top[m].x);
-		const float b = fmaf(fx[m], bot[m].y - bot[m].x, bot[m].x);
-		const float val = fmaf(fy[m], b - t, t);
-		const float vw = val * P.w[m];
-		sum = sum + vw;
-		sumSq = fmaf(val, vw, sumSq);
-		num = fmaf(val, P.tw[m], num);
+	for (int h = 0; h < NH; ++h)
+#pragma unroll
+		for (int m = 0; m < MAXM; ++m) {
+#if defined(HCMVS_ABL) && HCMVS_ABL == 1 /* diagnostic ablation: no gather loads (results are wrong) */
+			const float fake = (float)(off[h][m] & 255u) * (1.f / 255.f);
+			top[h][m] = make_float2(fake, fake * 0.9f);
+			bot[h][m] = make_float2(fake * 0.8f, fake * 0.7f);
+#else
+			top[h][m] = *(const float2*)(imgBase + off[h][m]);
+			bot[h][m] = *(const float2*)(imgBase + (off[h][m] + pitch));
+#endif
+		}
+	float sum[NH], sumSq[NH], num[NH];
+#pragma unroll
+	for (int h = 0; h < NH; ++h) {
+		float a = 0.f, b2 = 0.f, cnum = 0.f;
+#pragma unroll
+		for (int m = 0; m < MAXM; ++m) {
+			// bilinear sample (Types.inl:2250-2258) in lerp form
+			const float t = fmaf(fx[h][m], top[h][m].y - top[h][m].x, top[h][m].x);
+			const float b = fmaf(fx[h][m], bot[h][m].y - bot[h][m].x, bot[h][m].x);
+			const float val = fmaf(fy[h][m], b - t, t);
+			const float vw = val * P.w[m];
+			a = a + vw;
+			b2 = fmaf(val, vw, b2);
+			cnum = fmaf(val, P.tw[m], cnum);
+		}
+		sum[h] = a; sumSq[h] = b2; num[h] = cnum;
 	}
-	const bool viewBad = (__ballot(bad) & L.groupMask) != 0ull;
-	sum = group_sum<S>(sum); sumSq = group_sum<S>(sumSq); num = group_sum<S>(num);
-	const float normSq1 = sumSq - HC_SQ(sum) / P.sumW;
-	const float nrmSq = P.normSq0 * normSq1;
-	float ncc = num / sqrtf(nrmSq);
-	ncc = ncc < -1.f ? -1.f : (ncc > 1.f ? 1.f : ncc);
-	float s = 1.f - ncc;
-	for (unsigned long long mk = C.closeMask; mk;) {
-		const int k = __builtin_ctzll(mk);
-		mk &= mk - 1ull;
-		s *= rlf(f, k);
+	bool viewBad[NH];
+#pragma unroll
+	for (int h = 0; h < NH; ++h) {
+		viewBad[h] = (__ballot(bad[h]) & L.groupMask) != 0ull;
+		sum[h] = group_sum<S>(sum[h]); sumSq[h] = group_sum<S>(sumSq[h]); num[h] = group_sum<S>(num[h]);
 	}
-	s = c.pfScale * s;
-	if (viewBad || !(nrmSq > 0.f)) s = c.thRobust;
-	float m1 = L.vact ? s : __builtin_huge_valf(), m2 = __builtin_huge_valf();
-	min2_across<S>(m1, m2);
-	if (c.V <= 1) return m1;
-	return m2 >= c.thRobust ? m1 : (m1 + m2) / 2.f;
+	float m1[NH], m2[NH];
+#pragma unroll
+	for (int h = 0; h < NH; ++h) {
+		const float normSq1 = sumSq[h] - HC_SQ(sum[h]) * P.invSumW;
+		const float nrmSq = P.normSq0 * normSq1;
+		float ncc = num[h] / sqrtf(nrmSq);
+		ncc = ncc < -1.f ? -1.f : (ncc > 1.f ? 1.f : ncc);
+		float s = (1.f - ncc) * smoothF[h];
+		s = c.pfScale * s;
+		if (viewBad[h] || !(nrmSq > 0.f)) s = c.thRobust;
+		m1[h] = L.vact ? s : __builtin_huge_valf();
+		m2[h] = __builtin_huge_valf();
+	}
+#pragma unroll
+	for (int h = 0; h < NH; ++h) min2_across<S>(m1[h], m2[h]);
+#pragma unroll
+	for (int h = 0; h < NH; ++h) out[h] = c.V <= 1 ? m1[h] : (m2[h] >= c.thRobust ? m1[h] : (m1[h] + m2[h]) / 2.f);
+}
+template <int S>
+__device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, float v0, float v1,
+                                             float smoothF, float depth, float n0, float n1, float n2) {
+	const float f[1] = {smoothF}, d[1] = {depth}, a0[1] = {n0}, a1[1] = {n1}, a2[1] = {n2};
+	float o[1];
+	score_multi<S, 1>(c, L, P, v0, v1, f, d, a0, a1, a2, o);
+	return o[0];
+}
+
+// score the hypotheses listed in `idx[0..n)` (indices into the lane-held hypothesis arrays hd/h0/h1/h2, lane t =
+// hypothesis t; smoothness factor of hypothesis idx[i] in lane fLane[i]); lane idx[i] of the result gets the score
+template <int S>
+__device__ __forceinline__ float score_list(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, float v0, float v1, float F,
+                                            float hd, float h0, float h1, float h2, const int* idx, const int* fLane, int n,
+                                            float mine, unsigned& issued) {
+	for (int i = 0; i < n; ++i) {
+		const int ta = idx[i];
+		const float sc = score_pixel<S>(c, L, P, v0, v1, rlf(F, fLane[i]), rlf(hd, ta), rlf(h0, ta), rlf(h1, ta), rlf(h2, ta));
+		++issued;
+		if (L.lane == ta) mine = sc;
+	}
+	return mine;
 }
 
 // Util.inl:614-626
@@ -466,6 +518,41 @@ __device__ __forceinline__ void pixel_geom(const EstConst& c, int x, int y, Pixe
 	G.pn0 = G.pn1 = G.pn2 = G.pd = 0.f;
 }
 
+// Plane-smoothness factors (DepthMap.cpp:607-615) of up to EIGHT hypotheses in one lane-parallel pass:
+// lane = g*8 + j handles hypothesis g and neighbour slot (chunk*8 + j).  The per-slot factors
+// (1 - bD e^{sD (dist/d)^2}) (1 - bN e^{sN acos^2}) are multiplied by a butterfly inside each 8-lane group (slots
+// without a neighbour contribute exactly 1), chunk after chunk.  hd..hpd: the lane's own group's hypothesis
+// (depth, normal, plane normal, plane offset); limit: last slot whose corrected normal is already in effect.
+__device__ __forceinline__ float smooth_pass(const EstConst& c, const Close& C, int lane, float hd, float h0, float h1, float h2,
+                                             float hp0, float hp1, float hp2, float hpd, int limit) {
+	float F = 1.f;
+	if (C.closeMask == 0ull) return F;
+	const int nChunks = (64 - __builtin_clzll(C.closeMask) + 7) >> 3;
+	const int j = lane & 7;
+	for (int ch = 0; ch < nChunks; ++ch) {
+		const int slot = ch * 8 + j;
+		const float X0 = __shfl(C.X0, slot, 64), X1 = __shfl(C.X1, slot, 64), X2 = __shfl(C.X2, slot, 64);
+		const float o0 = __shfl(C.n0, slot, 64), o1 = __shfl(C.n1, slot, 64), o2 = __shfl(C.n2, slot, 64);
+		const float k0 = __shfl(C.k0, slot, 64), k1 = __shfl(C.k1, slot, 64), k2 = __shfl(C.k2, slot, 64);
+		const bool valid = (C.closeMask >> slot) & 1ull;
+		const bool corr = ((C.eligMask >> slot) & 1ull) && slot <= limit;
+		const float c0 = corr ? k0 : o0, c1 = corr ? k1 : o1, c2 = corr ? k2 : o2;
+		const float dist = dot3(hp0, hp1, hp2, X0, X1, X2) + hpd; // Planef::Distance
+		const float fd = pm_expf(HC_SQ(dist / hd) * c.smoothSigmaDepth);
+		float ca = dot3(h0, h1, h2, c0, c1, c2) / sqrtf(dot3(h0, h1, h2, h0, h1, h2) * dot3(c0, c1, c2, c0, c1, c2)); // Util.inl:417-420
+		ca = ca < -1.f ? -1.f : (ca > 1.f ? 1.f : ca);
+		const float ang = pm_acosf(ca);
+		const float fn = pm_expf(HC_SQ(ang) * c.smoothSigmaNormal);
+		float f = (1.f - c.smoothBonusDepth * fd) * (1.f - c.smoothBonusNormal * fn);
+		f = valid ? f : 1.f;
+		f = f * lane_xor<1>(f);
+		f = f * lane_xor<2>(f);
+		f = f * lane_xor<4>(f);
+		F = ch == 0 ? f : F * f;
+	}
+	return F;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // sweep: NW waves cooperate on one image row.  Every wave carries the complete (identical) pixel state;
 // in each round wave w scores hypothesis number w of the batch and the scores are exchanged through LDS,
@@ -478,22 +565,10 @@ constexpr int kHist = 16; // ring of the row's own latest results (neighbours be
 
 template <int NW>
 struct RowShared {
-	float ex[2][NW][8]; // per round parity, per wave: score, depth, n0, n1, n2, p0, p1, pad
+	float sc[2][32];   // per round parity: score of hypothesis t (propagation candidate or trial number)
 	float hist[kHist][6];
 	int row;
 };
-
-template <int NW>
-__device__ __forceinline__ void exchange(RowShared<NW>& sh, int par, int wv, int lane, float sc, float d, float n0,
-                                         float n1, float n2, float p0, float p1) {
-	if (NW > 1) {
-		if (lane == 0) {
-			float* e = sh.ex[par][wv];
-			e[0] = sc; e[1] = d; e[2] = n0; e[3] = n1; e[4] = n2; e[5] = p0; e[6] = p1;
-		}
-		__syncthreads();
-	}
-}
 
 __device__ __forceinline__ int wait_progress(int32_t* word, int need, int32_t* err) {
 	int v;
@@ -513,7 +588,7 @@ __device__ __forceinline__ int wait_progress(int32_t* word, int need, int32_t* e
 	return v;
 }
 
-// state of one row worker that lives across pixels: the software pipeline of memory accesses
+// state of one row worker that lives across pixels
 template <int S>
 struct RowPipe {
 	uint8_t tx1;      // gradient-map byte of the next column (kept raw so that nothing waits on the load)
@@ -589,8 +664,22 @@ __device__ __forceinline__ void prefetch_up(const EstConst& c, PixIn<S>& in) {
 	}
 }
 
-// DepthMap.cpp:1050-1501 ProcessPixel for logical column q of the row, pixel (x,y).  `in` holds the
-// inputs (complete); `pp` is the row pipeline (prefetch of column q+1, progress polls, deferred publish).
+// scores of hypotheses [0, n) held in lane t; each wave evaluated [lo, hi) -> everybody gets all of them
+template <int NW>
+__device__ __forceinline__ float share_scores(RowShared<NW>& sh, int& par, int lane, int lo, int hi, float mine) {
+	if (NW == 1) return mine;
+	if (lane >= lo && lane < hi) sh.sc[par][lane] = mine;
+	__syncthreads();
+	const float all = sh.sc[par][lane & 31];
+	par ^= 1;
+	return all;
+}
+
+// DepthMap.cpp:1050-1501 ProcessPixel for logical column q of the row, pixel (x,y).
+// Per phase the hypotheses are generated lane-parallel (lane t = hypothesis t) by every wave, the smoothness
+// factors of a wave's share come from one smooth_pass, the share is scored hypothesis by hypothesis, the scores are
+// exchanged through LDS and every wave replays the reference's sequential accept logic (DepthMap.cpp:1425, 1455,
+// 1484).  Refinement trials depend on earlier accepts: after an accepted trial the later ones are regenerated.
 template <int S, int NW>
 __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S>& L, RowShared<NW>& sh, int& par, int wv,
                                               int x, int y, int q, int iter, const PixIn<S>& in, const Patch<S>& P,
@@ -603,11 +692,11 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 	Close C;
 	const int nx = in.nx, ny = in.ny;
 	C.d = in.ndn.x; C.n0 = in.ndn.y; C.n1 = in.ndn.z; C.n2 = in.ndn.w; C.conf = in.nconf; C.nx = nx; C.ny = ny;
-	C.kd = 0.f; C.k0 = C.k1 = C.k2 = 0.f;
 	if (in.slot && in.back > 0 && in.back <= q) { // finished by this row earlier in this sweep: the row ring has it
 		const float* hrec = sh.hist[(q - in.back) & (kHist - 1)];
 		C.d = hrec[0]; C.n0 = hrec[1]; C.n1 = hrec[2]; C.n2 = hrec[3]; C.conf = hrec[4];
 	}
+	C.kd = C.d; C.k0 = C.n0; C.k1 = C.n1; C.k2 = C.n2;
 	const bool closeV = in.slot && C.d > 0.f;
 	C.closeMask = __ballot(closeV);
 	{ // Cast<float>(camera.TransformPointI2C(Point3(nx, ndepth))), Camera.h:306-312
@@ -621,7 +710,6 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 	C.eligMask = __ballot(elig);
 	if (elig) {
 		C.kd = interpolate_pixel(c, G, nx, ny, C.d, C.n0, C.n1, C.n2);
-		C.k0 = C.n0; C.k1 = C.n1; C.k2 = C.n2;
 		correct_normal(G, C.k0, C.k1, C.k2);
 	}
 
@@ -631,170 +719,151 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 	init_plane(G, depth, n0, n1, n2);
 	STAMP(2)
 
-	// ---- propagation, DepthMap.cpp:1406-1440: candidate j sees slots <= j corrected ----
+	// ---- one state machine for the three kinds of hypothesis rounds (a single inlined scorer keeps the code small) ----
+	//   PROP   propagation candidates, DepthMap.cpp:1406-1440: candidate i (slot order) sees slots <= its own corrected
+	//   RAND   completely random hypotheses, DepthMap.cpp:1448-1465 (independent of the estimate: a batch is exact)
+	//   REFINE perturbations of the current estimate, DepthMap.cpp:1466-1501 (after an accept the later trials are redone)
+	enum { PH_PROP, PH_PICK, PH_RAND, PH_REFINE, PH_DONE };
+	const int nc = __builtin_popcountll(C.eligMask);
+	int candSlot = 0; // lane i <- slot of the i-th candidate
 	{
-		unsigned long long rest = C.eligMask;
-		while (rest) {
-			int slots[NW];
-			unsigned long long corr[NW];
-			int nb = 0;
-#pragma unroll
-			for (int w = 0; w < NW; ++w) {
-				slots[w] = -1; corr[w] = 0ull;
-				if (rest) {
-					const int k = __builtin_ctzll(rest);
-					rest &= rest - 1ull;
-					slots[w] = k;
-					corr[w] = C.eligMask & ((2ull << k) - 1ull);
-					nb = w + 1;
-				}
-			}
-			int myk = -1;
-			unsigned long long myCorr = 0ull;
-#pragma unroll
-			for (int w = 0; w < NW; ++w) if (w == wv) { myk = slots[w]; myCorr = corr[w]; }
-			float sc = __builtin_huge_valf();
-			if (myk >= 0) {
-				const float kd = rlf(C.kd, myk), k0 = rlf(C.k0, myk), k1 = rlf(C.k1, myk), k2 = rlf(C.k2, myk);
-				PixelGeom Gc = G;
-				init_plane(Gc, kd, k0, k1, k2);
-				sc = score_pixel<S>(c, L, P, C, myCorr, Gc, kd, k0, k1, k2);
-				++issued;
-			}
-			STAMP(3)
-			exchange<NW>(sh, par, wv, lane, sc, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
-			STAMP(4)
-#pragma unroll
-			for (int w = 0; w < NW; ++w) {
-				if (w < nb) {
-					const float nconf = NW > 1 ? sh.ex[par][w][0] : sc;
-					const int k = slots[w];
-					++evals;
-					if (conf > nconf) { conf = nconf; depth = rlf(C.kd, k); n0 = rlf(C.k0, k); n1 = rlf(C.k1, k); n2 = rlf(C.k2, k); }
-					if (w == nb - 1) init_plane(G, rlf(C.kd, k), rlf(C.k0, k), rlf(C.k1, k), rlf(C.k2, k)); // plane of the last candidate stays
-				}
-			}
-			par ^= 1;
-		}
+		int i = 0;
+		for (unsigned long long mk = C.eligMask; mk; mk &= mk - 1ull, ++i)
+			if (lane == i) candSlot = __builtin_ctzll(mk);
 	}
-	const unsigned long long allCorr = C.eligMask;
-	STAMP(5)
-
-	// ---- pipeline hook 1: publish the previous column, start the next column's loads, refresh progress ----
-	{
-		if (wv == 0 && pp.pendingPub > 0) {
-			// the stores of the previous column were issued a whole scoring round ago: this wait is free
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (lane == 0) __hip_atomic_store(pp.myWord, pp.pendingPub, __ATOMIC_RELAXED, HC_SCOPE);
-			pp.pendingPub = 0;
-		}
-		if (pp.r > 0) pp.poll = __hip_atomic_load(pp.upWord, __ATOMIC_RELAXED, HC_SCOPE);
-	}
-
-	STAMP(6)
-	// ---- refinement, DepthMap.cpp:1442-1501 ----
+	// candidate i's estimate, brought from lane candSlot(i) to lane i
+	const float qd = __shfl(C.kd, candSlot, 64), q0 = __shfl(C.k0, candSlot, 64), q1 = __shfl(C.k1, candSlot, 64), q2 = __shfl(C.k2, candSlot, 64);
 	const uint32_t rk = rand_key(c.seed, (uint32_t)idx, (uint32_t)c.itExternal * 64u + 1u + (uint32_t)iter);
 	const int nR = c.nRandomIters;
+	int phase = nc > 0 ? PH_PROP : PH_PICK;
+	int cb = 0, t0 = 0;
 	unsigned idxScaleRange = 0;
-	bool done = false;
-	bool hook2 = false;
+	float scaleRange = 1.f, depthRange = 0.f, p0 = 0.f, p1 = 0.f;
+	bool hooked = false;
 	for (;;) {
-		if (conf <= c.thConfSmall) idxScaleRange = 2;
-		else if (conf <= c.thConfBig) idxScaleRange = 1;
-		else if (conf >= c.thConfRand) {
-			// completely random hypotheses: independent of the current estimate, batches are exact
+		if (phase == PH_PICK) { // the RefineIters label, DepthMap.cpp:1443-1448
+			if (!hooked) {
+				// pipeline hook: publish the previous column (its stores were issued a whole scoring round ago, so this
+				// wait is free) and refresh the progress of the row above with an asynchronous poll
+				hooked = true;
+				STAMP(5)
+				if (wv == 0 && pp.pendingPub > 0) {
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					if (lane == 0) __hip_atomic_store(pp.myWord, pp.pendingPub, __ATOMIC_RELAXED, HC_SCOPE);
+					pp.pendingPub = 0;
+				}
+				if (pp.r > 0) pp.poll = __hip_atomic_load(pp.upWord, __ATOMIC_RELAXED, HC_SCOPE);
+				STAMP(6)
+			}
+			if (conf <= c.thConfSmall) idxScaleRange = 2;
+			else if (conf <= c.thConfBig) idxScaleRange = 1;
+			if (conf > c.thConfBig && conf >= c.thConfRand) {
+				phase = PH_RAND;
+			} else {
+				phase = PH_REFINE;
+				scaleRange = 1.f / (float)(1u << idxScaleRange);
+				depthRange = depth * c.depthRatio;
+				p0 = pm_atan2f(n1, n0); p1 = pm_acosf(n2); // Normal2Dir
+				t0 = 0;
+			}
+		}
+		// ---- hypotheses of this round, lane t = hypothesis t ----
+		float hd = 0.f, h0 = 0.f, h1 = 0.f, h2 = -1.f, hq0 = 0.f, hq1 = 0.f;
+		int hlimit = 63, r0, r1;
+		bool hv = false, planeOwn = true;
+		if (phase == PH_PROP) {
+			r0 = cb; r1 = cb + 8 * NW < nc ? cb + 8 * NW : nc;
+			hd = qd; h0 = q0; h1 = q1; h2 = q2; hlimit = candSlot;
+			hv = lane >= r0 && lane < r1;
+		} else if (phase == PH_RAND) {
+			r0 = 0; r1 = nR; planeOwn = false; // the smoothness plane is whatever the propagation left (DepthMap.cpp:1450-1463)
+			if (lane < nR) {
+				hd = random_depth(c, rand_unit(rk, 3u * lane));
+				random_normal(G, rand_unit(rk, 3u * lane + 1u), rand_unit(rk, 3u * lane + 2u), h0, h1, h2);
+				hv = true;
+			}
+		} else {
+			r0 = t0; r1 = nR;
+			if (lane >= t0 && lane < nR) {
+				const uint32_t cbase = 64u + 3u * lane;
+				hd = depth + (depthRange * scaleRange) * (2.f * rand_unit(rk, cbase) - 1.f);
+				if (c.dMin <= hd && hd < c.dMax) {
+					hq0 = p0 + (c.angle1Range * scaleRange) * (2.f * rand_unit(rk, cbase + 1u) - 1.f);
+					hq1 = p1 + (c.angle2Range * scaleRange) * (2.f * rand_unit(rk, cbase + 2u) - 1.f);
+					dir2normal(hq0, hq1, h0, h1, h2);
+					hv = !(dot3(h0, h1, h2, G.v0, G.v1, 1.f) >= 0.f); // out-of-range depth / back-facing normal: not scored
+				}
+			}
+		}
+		const unsigned long long vmask = __ballot(hv);
+		// ---- my share of the round: one smoothness pass per eight hypotheses, then the scorer ----
+		const int cnt = r1 - r0, per = (cnt + NW - 1) / NW, lo = r0 + wv * per, hi = (lo + per < r1 ? lo + per : r1);
+		float mine = __builtin_huge_valf();
+		for (int base = lo; base < hi; base += 8) {
+			const int g = base + (lane >> 3);
+			const int src = g < r1 ? g : r0;
+			const float gd = __shfl(hd, src, 64), g0 = __shfl(h0, src, 64), g1 = __shfl(h1, src, 64), g2 = __shfl(h2, src, 64);
+			const int glimit = __shfl(hlimit, src, 64);
+			const float gp0 = planeOwn ? g0 : G.pn0, gp1 = planeOwn ? g1 : G.pn1, gp2 = planeOwn ? g2 : G.pn2;
+			const float gpd = planeOwn ? -gd * dot3(g0, g1, g2, G.v0, G.v1, 1.f) : G.pd; // InitPlane
+#if defined(HCMVS_ABL) && HCMVS_ABL == 2 /* diagnostic ablation: no smoothness pass */
+			const float F = 1.f + 0.f * (gd + g0 + g1 + g2 + gp0 + gp1 + gp2 + gpd + (float)glimit);
+#else
+			const float F = smooth_pass(c, C, lane, gd, g0, g1, g2, gp0, gp1, gp2, gpd, glimit);
+#endif
+			const int top = base + 8 < hi ? base + 8 : hi;
+			int idxs[8], fl[8], nv = 0;
+			for (int t = base; t < top; ++t) {
+				if (!((vmask >> t) & 1ull)) continue;
+				idxs[nv] = t; fl[nv] = (t - base) * 8; ++nv;
+			}
+			mine = score_list<S>(c, L, P, G.v0, G.v1, F, hd, h0, h1, h2, idxs, fl, nv, mine, issued);
+		}
+		STAMP(7)
+		const float all = share_scores<NW>(sh, par, lane, lo, hi, mine);
+		STAMP(8)
+		// ---- every wave replays the sequential accept logic ----
+		if (phase == PH_PROP) {
+			for (int i = r0; i < r1; ++i) {
+				const float nconf = rlf(all, i);
+				++evals;
+				if (conf > nconf) { conf = nconf; depth = rlf(hd, i); n0 = rlf(h0, i); n1 = rlf(h1, i); n2 = rlf(h2, i); }
+				if (i == nc - 1) init_plane(G, rlf(hd, i), rlf(h0, i), rlf(h1, i), rlf(h2, i)); // the last candidate's plane stays
+			}
+			cb = r1;
+			if (cb >= nc) phase = PH_PICK;
+		} else if (phase == PH_RAND) {
 			bool again = false;
-			for (int t0 = 0; t0 < nR && !again; t0 += NW) {
-				const int t = t0 + wv;
-				float sc = __builtin_huge_valf(), nd = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
-				if (t < nR) {
-					nd = random_depth(c, rand_unit(rk, 3u * t));
-					random_normal(G, rand_unit(rk, 3u * t + 1u), rand_unit(rk, 3u * t + 2u), r0, r1, r2);
-					sc = score_pixel<S>(c, L, P, C, allCorr, G, nd, r0, r1, r2);
-					++issued;
-				}
-				STAMP(7)
-				exchange<NW>(sh, par, wv, lane, sc, nd, r0, r1, r2, 0.f, 0.f);
-				STAMP(8)
-#pragma unroll
-				for (int w = 0; w < NW; ++w) {
-					if (t0 + w < nR && !again) {
-						const float* e = sh.ex[par][w];
-						const float nconf = NW > 1 ? e[0] : sc;
-						++evals;
-						if (conf > nconf) {
-							conf = nconf;
-							if (NW > 1) { depth = e[1]; n0 = e[2]; n1 = e[3]; n2 = e[4]; }
-							else { depth = nd; n0 = r0; n1 = r1; n2 = r2; }
-							if (conf < c.thConfRand) again = true;
-						}
-					}
-				}
-				par ^= 1;
-			}
-			if (again) continue;
-			done = true;
-		}
-		break;
-	}
-	if (!done) {
-		float scaleRange = 1.f / (float)(1u << idxScaleRange);
-		const float depthRange = depth * c.depthRatio;
-		float p0 = pm_atan2f(n1, n0), p1 = pm_acosf(n2); // Normal2Dir
-		int t0 = 0;
-		while (t0 < nR) {
-			const int t = t0 + wv;
-			float sc = __builtin_huge_valf(), nd = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f, np0 = 0.f, np1 = 0.f;
-			if (t < nR) {
-				const uint32_t cb = 64u + 3u * t;
-				nd = depth + (depthRange * scaleRange) * (2.f * rand_unit(rk, cb) - 1.f);
-				if (c.dMin <= nd && nd < c.dMax) {
-					np0 = p0 + (c.angle1Range * scaleRange) * (2.f * rand_unit(rk, cb + 1u) - 1.f);
-					np1 = p1 + (c.angle2Range * scaleRange) * (2.f * rand_unit(rk, cb + 2u) - 1.f);
-					dir2normal(np0, np1, r0, r1, r2);
-					if (!(dot3(r0, r1, r2, G.v0, G.v1, 1.f) >= 0.f)) {
-						PixelGeom Gc = G;
-						init_plane(Gc, nd, r0, r1, r2);
-						sc = score_pixel<S>(c, L, P, C, allCorr, Gc, nd, r0, r1, r2);
-						++issued;
-					}
+			for (int t = 0; t < nR && !again; ++t) {
+				const float nconf = rlf(all, t);
+				++evals;
+				if (conf > nconf) {
+					conf = nconf; depth = rlf(hd, t); n0 = rlf(h0, t); n1 = rlf(h1, t); n2 = rlf(h2, t);
+					if (conf < c.thConfRand) again = true;
 				}
 			}
-			STAMP(7)
-			exchange<NW>(sh, par, wv, lane, sc, nd, r0, r1, r2, np0, np1);
-			STAMP(8)
-			if (!hook2) { // pipeline hook 2: the poll issued at hook 1 has landed by now
-				hook2 = true;
-				if (pp.r > 0) {
-					if (pp.poll > pp.known) pp.known = pp.poll;
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-					pp.poll = __hip_atomic_load(pp.upWord, __ATOMIC_RELAXED, HC_SCOPE);
+			phase = again ? PH_PICK : PH_DONE;
+		} else {
+			int tnext = nR;
+			for (int t = t0; t < nR; ++t) {
+				if (!((vmask >> t) & 1ull)) continue;
+				const float nconf = rlf(all, t);
+				++evals; // the sequential algorithm scores exactly the valid trials it reaches
+				if (conf > nconf) {
+					conf = nconf; depth = rlf(hd, t); n0 = rlf(h0, t); n1 = rlf(h1, t); n2 = rlf(h2, t);
+					p0 = rlf(hq0, t); p1 = rlf(hq1, t);
+					++idxScaleRange;
+					scaleRange = 1.f / (float)(1u << idxScaleRange);
+					tnext = t + 1; // later trials used the old estimate: regenerate them
+					break;
 				}
 			}
-			bool accepted = false;
-			int tnext = t0 + NW;
-#pragma unroll
-			for (int w = 0; w < NW; ++w) {
-				if (t0 + w < nR && !accepted) {
-					const float* e = sh.ex[par][w];
-					const float nconf = NW > 1 ? e[0] : sc;
-					if (nconf < __builtin_huge_valf()) ++evals; // the sequential algorithm scores only valid trials
-					if (conf > nconf) {
-						conf = nconf;
-						if (NW > 1) { depth = e[1]; n0 = e[2]; n1 = e[3]; n2 = e[4]; p0 = e[5]; p1 = e[6]; }
-						else { depth = nd; n0 = r0; n1 = r1; n2 = r2; p0 = np0; p1 = np1; }
-						++idxScaleRange;
-						scaleRange = 1.f / (float)(1u << idxScaleRange);
-						accepted = true; // later trials of this batch used the old estimate: re-issue them
-						tnext = t0 + w + 1;
-					}
-				}
-			}
-			par ^= 1;
 			t0 = tnext;
+			if (t0 >= nR) phase = PH_DONE;
 		}
+		if (phase == PH_DONE) break;
 	}
-	if (pp.r > 0 && pp.poll > pp.known) pp.known = pp.poll; // consume the latest poll
+	if (pp.r > 0 && pp.poll > pp.known) pp.known = pp.poll; // consume the poll issued after the propagation phase
 	if (lane == 0) {
 		float* hrec = sh.hist[q & (kHist - 1)];
 		hrec[0] = depth; hrec[1] = n0; hrec[2] = n1; hrec[3] = n2; hrec[4] = conf;
@@ -810,31 +879,38 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 // ------------------------------------------------------------------------------------------------------
 // sweep kernel: persistent row workers (SceneDensify.cpp:677-686 EstimateDepthMapTmp)
 
+// One launch sweeps a BATCH of independent reference images: ticket t -> (row t / nItems of image t % nItems), so the
+// rows of every image are still handed out in dependence order while the images fill each other's wavefront ramps.
 template <int S, int NW>
-__global__ __launch_bounds__(64 * NW) void sweep_kernel(EstConst c, SweepSync sy, int iter, int lag) {
+__global__ __launch_bounds__(64 * NW) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
+                                                        int iter, int lag) {
 	__shared__ RowShared<NW> sh;
-	LaneCtx<S> L;
-	lane_init<S>(c, L);
 	const int wv = threadIdx.x >> 6;
 	const bool rev = (iter & 1) != 0; // dir = RB2LT on odd iterations, DepthMap.cpp:418
-	const int nrows = c.H - 2 * kHalfWindow, ncols = c.W - 2 * kHalfWindow;
 	unsigned evals = 0, issued = 0;
 	unsigned long long taps = 0; // patch taps of the sequential algorithm's evaluations (per source view)
 	int par = 0;
 	STAMP_DECL
 	RowPipe<S> pp;
-	pp.err = sy.error; pp.ncols = ncols; pp.rev = rev;
+	pp.err = sy.error; pp.rev = rev;
 	for (;;) {
-		// rows are handed out in dependency order: whoever holds row r-1 is already running
+		// rows are handed out in dependency order: whoever holds row r-1 of an image is already running
 		if (NW > 1) __syncthreads(); // everyone is done with the previous row's shared state
 		if (threadIdx.x == 0) sh.row = atomicAdd(sy.ticket, 1);
 		if (NW > 1) __syncthreads();
-		const int r = __builtin_amdgcn_readfirstlane(sh.row);
-		if (r >= nrows) break;
+		const int t = __builtin_amdgcn_readfirstlane(sh.row);
+		if (t >= maxRows * nItems) break;
+		const int r = t / nItems;
+		const EstConst c = items[t - r * nItems];
+		const int nrows = c.H - 2 * kHalfWindow, ncols = c.W - 2 * kHalfWindow;
+		if (r >= nrows) continue; // a smaller image of the batch
+		LaneCtx<S> L;
+		lane_init<S>(c, L);
+		pp.ncols = ncols;
 		const int y = rev ? c.H - 1 - kHalfWindow - r : kHalfWindow + r;
 		pp.r = r; pp.y = y;
-		pp.upWord = sy.progress + (size_t)(r > 0 ? r - 1 : 0) * kProgressStride;
-		pp.myWord = sy.progress + (size_t)r * kProgressStride;
+		pp.upWord = c.progress + (size_t)(r > 0 ? r - 1 : 0) * kProgressStride;
+		pp.myWord = c.progress + (size_t)r * kProgressStride;
 		pp.known = r > 0 ? 0 : 0x7fffffff; // columns the previous logical row has finished
 		pp.poll = 0; pp.pendingPub = 0; pp.fail = false;
 		if (r > 0) {
@@ -869,13 +945,13 @@ __global__ __launch_bounds__(64 * NW) void sweep_kernel(EstConst c, SweepSync sy
 		if (pp.fail) break;
 		if (wv == 0 && pp.pendingPub > 0) { // last column of the row
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (L.lane == 0) __hip_atomic_store(pp.myWord, pp.pendingPub, __ATOMIC_RELAXED, HC_SCOPE);
+			if ((threadIdx.x & 63) == 0) __hip_atomic_store(pp.myWord, pp.pendingPub, __ATOMIC_RELAXED, HC_SCOPE);
 			pp.pendingPub = 0;
 		}
 	}
 	STAMP(10)
 	STAMP_FLUSH
-	if (L.lane == 0) {
+	if ((threadIdx.x & 63) == 0) {
 		if (wv == 0 && evals) { atomicAdd(sy.evals, (unsigned long long)evals); atomicAdd(sy.evals + 2, taps); }
 		if (issued) atomicAdd(sy.evals + 1, (unsigned long long)issued);
 	}
@@ -921,9 +997,6 @@ __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long lo
 		fill_patch<S>(c, L, x, y, in, P);
 		PixelGeom G;
 		pixel_geom(c, x, y, G);
-		Close C;
-		C.closeMask = 0ull; C.eligMask = 0ull;
-		C.d = C.n0 = C.n1 = C.n2 = C.kd = C.k0 = C.k1 = C.k2 = C.X0 = C.X1 = C.X2 = C.conf = 0.f; C.nx = C.ny = 0;
 		const float4 cur = c.dn[idx];
 		float d = cur.x, n0 = cur.y, n1 = cur.z, n2 = cur.w;
 		if (!(c.dMin <= d && d < c.dMax)) {
@@ -932,7 +1005,7 @@ __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long lo
 		} else if (dot3(n0, n1, n2, G.v0, G.v1, 1.f) >= 0.f) {
 			random_normal(G, rand_unit(rk, 1u), rand_unit(rk, 2u), n0, n1, n2);
 		}
-		const float s = score_pixel<S>(c, L, P, C, 0ull, G, d, n0, n1, n2);
+		const float s = score_pixel<S>(c, L, P, G.v0, G.v1, 1.f, d, n0, n1, n2);
 		++evals;
 		taps += (unsigned)((P.a + 1) * (P.a + 1));
 		if (L.lane == 0) {
@@ -1060,28 +1133,27 @@ void launch_score_pass(const EstConst& c, const float* depthIn, const float* nor
 }
 
 template <int NW>
-static void launch_sweep_nw(const EstConst& c, const SweepSync& sync, int iter, int lag, hipStream_t s) {
-	const int nrows = c.H - 2 * kHalfWindow;
+static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int lag,
+                            hipStream_t s) {
 	// one workgroup per row; rows beyond the resident set are picked up through the ticket
-	int grid = nrows < 8192 ? nrows : 8192;
+	int grid = totalRows < 8192 ? totalRows : 8192;
 	if (grid < 1) return;
 	const dim3 g(grid), b(64 * NW);
-	switch (segments_for(c.V)) {
-	case 64: hipLaunchKernelGGL((sweep_kernel<64, NW>), g, b, 0, s, c, sync, iter, lag); break;
-	case 32: hipLaunchKernelGGL((sweep_kernel<32, NW>), g, b, 0, s, c, sync, iter, lag); break;
-	case 16: hipLaunchKernelGGL((sweep_kernel<16, NW>), g, b, 0, s, c, sync, iter, lag); break;
-	case 8: hipLaunchKernelGGL((sweep_kernel<8, NW>), g, b, 0, s, c, sync, iter, lag); break;
-	default: hipLaunchKernelGGL((sweep_kernel<4, NW>), g, b, 0, s, c, sync, iter, lag); break;
+	switch (segments_for(V)) {
+	case 64: hipLaunchKernelGGL((sweep_kernel<64, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag); break;
+	case 32: hipLaunchKernelGGL((sweep_kernel<32, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag); break;
+	case 16: hipLaunchKernelGGL((sweep_kernel<16, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag); break;
+	case 8: hipLaunchKernelGGL((sweep_kernel<8, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag); break;
+	default: hipLaunchKernelGGL((sweep_kernel<4, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag); break;
 	}
 }
-void launch_sweep(const EstConst& c, const SweepSync& sync, int iter, int lag, int wavesPerRow, hipStream_t s) {
+void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int lag,
+                  int wavesPerRow, hipStream_t s) {
 	switch (wavesPerRow) {
-	case 1: launch_sweep_nw<1>(c, sync, iter, lag, s); break;
-	case 2: launch_sweep_nw<2>(c, sync, iter, lag, s); break;
-	case 3: launch_sweep_nw<3>(c, sync, iter, lag, s); break;
-	case 6: launch_sweep_nw<6>(c, sync, iter, lag, s); break;
-	case 8: launch_sweep_nw<8>(c, sync, iter, lag, s); break;
-	default: launch_sweep_nw<4>(c, sync, iter, lag, s); break;
+	case 1: launch_sweep_nw<1>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, s); break;
+	case 3: launch_sweep_nw<3>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, s); break;
+	case 4: launch_sweep_nw<4>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, s); break;
+	default: launch_sweep_nw<2>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, s); break;
 	}
 }
 

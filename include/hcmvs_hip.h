@@ -116,7 +116,20 @@ int hcmvs_estimate(hcmvs_ctx* ctx, uint32_t ref_id, const uint32_t* src_ids, int
 int hcmvs_estimate_device(hcmvs_ctx* ctx, uint32_t ref_id, const uint32_t* src_ids, int32_t n_src,
                           const hcmvs_params* params, float d_min, float d_max, float* d_depth, float* d_normal,
                           float* d_conf);
-/* synchronises, then reports counters/timings of the last estimate */
+/* A batch of independent EstimateDepthMap calls (different reference images, the same options and number of
+ * source views) in ONE set of launches: the sweep kernel interleaves the rows of all items, so the images fill each
+ * other's wavefront ramps (the reference overlaps images with two worker threads, SceneDensify.cpp:3699).
+ * Every item produces exactly the maps hcmvs_estimate_device would produce for it with seed + seed_offset. */
+typedef struct {
+	uint32_t ref_id;
+	const uint32_t* src_ids;
+	int32_t n_src;
+	uint32_t seed_offset;  /* added to params->seed for this item */
+	float d_min, d_max;
+	float *d_depth, *d_normal, *d_conf; /* DEVICE in/out maps of this item */
+} hcmvs_batch_item;
+int hcmvs_estimate_batch_device(hcmvs_ctx* ctx, const hcmvs_batch_item* items, int32_t n_items, const hcmvs_params* params);
+/* synchronises, then reports counters/timings of the last estimate (summed over the items of a batch) */
 int hcmvs_get_stats(hcmvs_ctx* ctx, hcmvs_stats* out);
 
 /* SceneDensify.cpp:783-808: splat n_points sparse world points (xyz f32) seen by view `id` as 5x5 blocks

@@ -331,6 +331,7 @@ typedef struct {
 	float cDepth[HCOR_MAX_NEIGHBORS];
 	float cNormal[HCOR_MAX_NEIGHBORS][3];
 	float cX[HCOR_MAX_NEIGHBORS][3];
+	int cSlot[HCOR_MAX_NEIGHBORS]; /* position in the candidate list (= lane of the slot on the device) */
 	float planeN[3], planeD;
 } pix_state;
 
@@ -557,9 +558,15 @@ static float score_view_dev(const est_ctx* c, const pix_state* ps, int v, float 
 			vv[m] = dev_tap(S, a, s, m, &ti, &tj);
 			kk[m] = ti * nside + tj;
 			const float px = (float)(ps->x - a + 2 * tj), py = (float)(ps->y - a + 2 * ti);
-			Xx[m] = fmaf(H[0], px, fmaf(H[1], py, H[2]));
-			Xy[m] = fmaf(H[3], px, fmaf(H[4], py, H[5]));
-			Xz[m] = fmaf(H[6], px, fmaf(H[7], py, H[8]));
+			if (S >= 8) { /* a segment walks down one patch column: the column term is formed first */
+				Xx[m] = fmaf(H[1], py, fmaf(H[0], px, H[2]));
+				Xy[m] = fmaf(H[4], py, fmaf(H[3], px, H[5]));
+				Xz[m] = fmaf(H[7], py, fmaf(H[6], px, H[8]));
+			} else {
+				Xx[m] = fmaf(H[1], py, fmaf(H[0], px, H[2]));
+				Xy[m] = fmaf(H[4], py, fmaf(H[3], px, H[5]));
+				Xz[m] = fmaf(H[7], py, fmaf(H[6], px, H[8]));
+			}
 		}
 		if (MAXM >= 4) { /* one IEEE reciprocal per group of four taps */
 			for (int g = 0; g < MAXM; g += 4) {
@@ -591,7 +598,7 @@ static float score_view_dev(const est_ctx* c, const pix_state* ps, int v, float 
 	}
 	if (!ok) return c->thRobust;
 	const float sum = butterfly_sum(p0, S), sumSq = butterfly_sum(p1, S), num = butterfly_sum(p2, S);
-	const float normSq1 = sumSq - SQ(sum) / ps->sumW;
+	const float normSq1 = sumSq - SQ(sum) * (1.0f / ps->sumW);
 	const float nrmSq = ps->normSq0 * normSq1;
 	if (!(nrmSq > 0.f)) return c->thRobust;
 	float ncc = num / sqrtf(nrmSq);
@@ -604,7 +611,23 @@ static float score_view_dev(const est_ctx* c, const pix_state* ps, int v, float 
 /* DM.cpp:987-1046 (DENSE_AGGNCC_MINMEAN) */
 static float score_pixel(est_ctx* c, const pix_state* ps, float depth, const float* normal) {
 	float sf[HCOR_MAX_NEIGHBORS];
-	const int nsf = smooth_factors(c, ps, depth, normal, sf);
+	int nsf = smooth_factors(c, ps, depth, normal, sf);
+	if (c->p.arith_mode == HCOR_ARITH_DEVICE) {
+		/* device association: the factors are multiplied by a butterfly over 8-slot chunks (slots without a
+		 * neighbour count as 1), chunk after chunk, and the score is multiplied once by the product */
+		float bySlot[HCOR_MAX_NEIGHBORS];
+		int top = 0;
+		for (int k = 0; k < HCOR_MAX_NEIGHBORS; ++k) bySlot[k] = 1.f;
+		for (int k = 0; k < nsf; ++k) { bySlot[ps->cSlot[k]] = sf[k]; if (ps->cSlot[k] + 1 > top) top = ps->cSlot[k] + 1; }
+		float F = 1.f;
+		for (int ch = 0; ch * 8 < top; ++ch) {
+			const float* f = bySlot + ch * 8;
+			const float t = ((f[0] * f[1]) * (f[2] * f[3])) * ((f[4] * f[5]) * (f[6] * f[7]));
+			F = ch == 0 ? t : F * t;
+		}
+		sf[0] = F;
+		nsf = 1;
+	}
 	float s0 = FLT_MAX, s1 = FLT_MAX; /* two smallest */
 	for (int v = 0; v < c->V; ++v) {
 		const float s = c->p.arith_mode == HCOR_ARITH_DEVICE ? score_view_dev(c, ps, v, depth, normal, sf, nsf)
@@ -761,9 +784,10 @@ static void score_one(est_ctx* c, int x, int y, float* depth, float* normal, flo
 	conf[idx] = score_pixel(c, &ps, d, n);
 }
 
-static void add_close(const est_ctx* c, pix_state* ps, int nx, int ny, float nd, const float* nmap) {
+static void add_close(const est_ctx* c, pix_state* ps, int nx, int ny, float nd, const float* nmap, int slot) {
 	const hcor_view* ref = c->ref;
 	const int k = ps->nClose++;
+	ps->cSlot[k] = slot;
 	const int nidx = ny * ref->width + nx;
 	ps->cDepth[k] = nd;
 	ps->cNormal[k][0] = nmap[3 * nidx]; ps->cNormal[k][1] = nmap[3 * nidx + 1]; ps->cNormal[k][2] = nmap[3 * nidx + 2];
@@ -813,7 +837,7 @@ static void process_pixel(est_ctx* c, int x, int y, int iter, float* depthMap, f
 			const float nd = depthMap[cy[k] * W + cx[k]];
 			if (nd > 0) {
 				nbx[nNb] = cx[k]; nby[nNb] = cy[k]; nbc[nNb] = ps.nClose; ++nNb;
-				add_close(c, &ps, cx[k], cy[k], nd, normalMap);
+				add_close(c, &ps, cx[k], cy[k], nd, normalMap, k);
 			}
 		}
 	} else {
@@ -828,7 +852,7 @@ static void process_pixel(est_ctx* c, int x, int y, int iter, float* depthMap, f
 			const float nd = depthMap[py[k] * W + px[k]];
 			if (nd > 0) {
 				if (q < 2) { nbx[nNb] = px[k]; nby[nNb] = py[k]; nbc[nNb] = ps.nClose; ++nNb; }
-				add_close(c, &ps, px[k], py[k], nd, normalMap);
+				add_close(c, &ps, px[k], py[k], nd, normalMap, q);
 			}
 		}
 	}

@@ -3,6 +3,7 @@ import importlib, sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 binding = importlib.import_module("hc-mvs_amd.binding")
+if os.environ.get("HCMVS_LIB"): binding.LIB_PATH = binding.LIB_PATH.replace("libhcmvs_hip.so", os.environ["HCMVS_LIB"])
 synth = importlib.import_module("hc-mvs_amd.synth")
 W, H, F, V, I = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 t = time.time()

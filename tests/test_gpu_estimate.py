@@ -114,3 +114,36 @@ def test_errors_are_reported(ctx):
     pg.adapthalfwin = 9
     with pytest.raises(binding.HcmvsError):
         ctx.estimate(0, [1], pg, dmin, dmax, d0, n0)
+
+
+def test_batch_of_reference_images_bit_exact(ctx):
+    """hcmvs_estimate_batch_device: rows of several reference images interleaved in one sweep launch; every item must
+    equal its own single estimate (and therefore the oracle) bit for bit, with different image sizes in one batch."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    scenes = [_scene(112, 88, 100.0, 3, seed=31), _scene(96, 120, 100.0, 3, seed=32), _scene(112, 88, 100.0, 3, seed=33)]
+    items, keep, wants = [], [], []
+    vid = 0
+    for si, (views, pts) in enumerate(scenes):
+        ids = list(range(vid, vid + len(views)))
+        for i, v in zip(ids, views):
+            ctx.upload_view(i, v["gray"], v["K"], v["R"], v["C"])
+        vid += len(views)
+        ref = ids[si % len(ids)]                      # a different view of each scene is the reference
+        srcs = [i for i in ids if i != ref]
+        d0, n0, dmin, dmax = ctx.splat_init(ref, pts)
+        pg, po = _params(adapthalfwin=6, n_estimation_iters=3, seed=500)
+        po.seed = 500 + 7 * si
+        ordered = [views[ref - ids[0]]] + [views[i - ids[0]] for i in srcs]
+        wants.append(O.estimate(ordered, po, dmin, dmax, d0, n0))
+        td = torch.from_numpy(d0).to(dev); tn = torch.from_numpy(n0).to(dev); tc = torch.zeros_like(td)
+        keep.append((td, tn, tc))
+        items.append(dict(ref_id=ref, src_ids=srcs, d_min=dmin, d_max=dmax, d_depth=td.data_ptr(), d_normal=tn.data_ptr(),
+                          d_conf=tc.data_ptr(), seed_offset=7 * si))
+    torch.cuda.synchronize()
+    ctx.estimate_batch_device(items, pg)
+    ctx.synchronize()
+    st = ctx.stats()
+    assert st.evals == sum(w[3] for w in wants)
+    for (td, tn, tc), w in zip(keep, wants):
+        _compare((td.cpu().numpy(), tn.cpu().numpy(), tc.cpu().numpy()), w[:3])
