@@ -170,6 +170,8 @@ template <int S>
 struct Patch { // DepthMap.h:202-212 WeightedPatchFix, spread over the lanes of a group
 	static constexpr int MAXM = 64 / S;
 	float w[MAXM], tw[MAXM];
+	float py[MAXM];   // image row of the lane's m-th tap
+	float px0;        // image column of the lane's first tap (S >= 8: of all its taps)
 	float sumW, invSumW, normSq0;
 	int x, y, a;
 };
@@ -246,6 +248,8 @@ __device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& 
 	for (int m = 0; m < MAXM; ++m) {
 		int i, j;
 		const bool valid = tap_offset<S>(a, L.seg, m, i, j);
+		P.py[m] = (float)(y + i);
+		if (m == 0) P.px0 = (float)(x + j);
 		const float wColor = HC_SQ(in.I[m] - in.center) * sigmaColor;
 		const float wSpatial = (float)(HC_SQ(j) + HC_SQ(i)) * sigmaSpatial;
 		const float w = pm_expf(wColor + wSpatial);
@@ -315,19 +319,17 @@ __device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>&
 #pragma unroll
 	for (int h = 0; h < NH; ++h) {
 		float Xx[MAXM], Xy[MAXM], Xz[MAXM], iz[MAXM];
-		// a segment walks down one patch column: the column term of the warp is hoisted (S >= 8)
-		int ti0, tj0;
-		tap_offset<S>(P.a, L.seg, 0, ti0, tj0);
-		const float px0 = (float)(P.x + tj0);
-		const float bx = fmaf(H[h][0], px0, H[h][2]), by = fmaf(H[h][3], px0, H[h][5]), bz = fmaf(H[h][6], px0, H[h][8]);
+		// a segment walks down one patch column: the column term of the warp is hoisted (S >= 8).  Steps past the
+		// patch repeat the last row (zero weights), so they change neither the sums nor the inside test.
+		const float bx = fmaf(H[h][0], P.px0, H[h][2]), by = fmaf(H[h][3], P.px0, H[h][5]), bz = fmaf(H[h][6], P.px0, H[h][8]);
 #pragma unroll
 		for (int m = 0; m < MAXM; ++m) {
-			int ti, tj;
-			tap_offset<S>(P.a, L.seg, m, ti, tj);
-			const float py = (float)(P.y + ti);
+			const float py = P.py[m];
 			if constexpr (S >= 8) {
 				Xx[m] = fmaf(H[h][1], py, bx); Xy[m] = fmaf(H[h][4], py, by); Xz[m] = fmaf(H[h][7], py, bz);
 			} else { // S == 4: a segment covers two columns
+				int ti, tj;
+				tap_offset<S>(P.a, L.seg, m, ti, tj);
 				const float px = (float)(P.x + tj);
 				Xx[m] = fmaf(H[h][1], py, fmaf(H[h][0], px, H[h][2]));
 				Xy[m] = fmaf(H[h][4], py, fmaf(H[h][3], px, H[h][5]));
@@ -360,10 +362,10 @@ __device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>&
 			const float qx = Xx[m] * iz[m], qy = Xy[m] * iz[m];
 			qxlo = fminf(qxlo, qx); qxhi = fmaxf(qxhi, qx); qylo = fminf(qylo, qy); qyhi = fmaxf(qyhi, qy);
 			int lx = (int)qx, ly = (int)qy;
-			fx[h][m] = qx - floorf(qx);
-			fy[h][m] = qy - floorf(qy);
-			lx = lx < 0 ? 0 : (lx > L.ixmax ? L.ixmax : lx);
-			ly = ly < 0 ? 0 : (ly > L.iymax ? L.iymax : ly);
+			fx[h][m] = __builtin_amdgcn_fractf(qx);
+			fy[h][m] = __builtin_amdgcn_fractf(qy);
+			lx = max(0, min(lx, L.ixmax));
+			ly = max(0, min(ly, L.iymax));
 			off[h][m] = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 2);
 		}
 		bad[h] = nan || !(qxlo >= 1.f && qylo >= 1.f && qxhi <= L.wmax && qyhi <= L.hmax);
@@ -539,7 +541,7 @@ __device__ __forceinline__ float smooth_pass(const EstConst& c, const Close& C, 
 		const float c0 = corr ? k0 : o0, c1 = corr ? k1 : o1, c2 = corr ? k2 : o2;
 		const float dist = dot3(hp0, hp1, hp2, X0, X1, X2) + hpd; // Planef::Distance
 		const float fd = pm_expf(HC_SQ(dist / hd) * c.smoothSigmaDepth);
-		float ca = dot3(h0, h1, h2, c0, c1, c2) / sqrtf(dot3(h0, h1, h2, h0, h1, h2) * dot3(c0, c1, c2, c0, c1, c2)); // Util.inl:417-420
+		float ca = dot3(h0, h1, h2, c0, c1, c2); // Util.inl:417-420 for unit normals (every normal on this path is unit)
 		ca = ca < -1.f ? -1.f : (ca > 1.f ? 1.f : ca);
 		const float ang = pm_acosf(ca);
 		const float fn = pm_expf(HC_SQ(ang) * c.smoothSigmaNormal);
@@ -1019,6 +1021,29 @@ __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long lo
 		atomicAdd(evalsOut + 2, taps);
 	}
 }
+
+#ifdef HCMVS_COUNT
+// instruction-count probes (never built into the library): the scorer and the smoothness pass in isolation
+template <int S>
+__global__ void probe_score_kernel(EstConst c, Patch<S> P, float F, float d, float n0, float n1, float n2, float* out) {
+	LaneCtx<S> L;
+	lane_init<S>(c, L);
+	out[threadIdx.x] = score_pixel<S>(c, L, P, 0.1f, 0.2f, F, d, n0, n1, n2);
+}
+template __global__ void probe_score_kernel<8>(EstConst, Patch<8>, float, float, float, float, float, float*);
+__global__ void probe_smooth_kernel(EstConst c, Close C, float* out) {
+	out[threadIdx.x] = smooth_pass(c, C, threadIdx.x & 63, out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], 63);
+}
+template <int S>
+__global__ void probe_patch_kernel(EstConst c, PixIn<S> in, Patch<S>* out) {
+	LaneCtx<S> L;
+	lane_init<S>(c, L);
+	Patch<S> P;
+	fill_patch<S>(c, L, 100, 100, in, P);
+	out[threadIdx.x] = P;
+}
+template __global__ void probe_patch_kernel<8>(EstConst, PixIn<8>, Patch<8>*);
+#endif
 
 // SceneDensify.cpp:688-744 EndDepthMapTmp (finalPass) or plain export of the working state
 __global__ void end_kernel(EstConst c, int finalPass, float* depth, float* normal, float* conf) {

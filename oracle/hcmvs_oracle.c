@@ -476,7 +476,8 @@ static int smooth_factors(const est_ctx* c, const pix_state* ps, float depth, co
 		const float fd = c->mt->expf_(SQ(dist / depth) * c->smoothSigmaDepth);
 		/* Util.inl:417-420 ComputeAngle */
 		const float* nb = ps->cNormal[k];
-		float ca = dot3f(normal, nb) / sqrtf(dot3f(normal, normal) * dot3f(nb, nb));
+		float ca = c->p.arith_mode == HCOR_ARITH_DEVICE ? dot3f(normal, nb) /* unit normals: no re-normalisation */
+		                                                : dot3f(normal, nb) / sqrtf(dot3f(normal, normal) * dot3f(nb, nb));
 		ca = ca < -1.f ? -1.f : (ca > 1.f ? 1.f : ca);
 		const float ang = c->mt->acosf_(ca);
 		const float fn = c->mt->expf_(SQ(ang) * c->smoothSigmaNormal);
@@ -558,15 +559,9 @@ static float score_view_dev(const est_ctx* c, const pix_state* ps, int v, float 
 			vv[m] = dev_tap(S, a, s, m, &ti, &tj);
 			kk[m] = ti * nside + tj;
 			const float px = (float)(ps->x - a + 2 * tj), py = (float)(ps->y - a + 2 * ti);
-			if (S >= 8) { /* a segment walks down one patch column: the column term is formed first */
-				Xx[m] = fmaf(H[1], py, fmaf(H[0], px, H[2]));
-				Xy[m] = fmaf(H[4], py, fmaf(H[3], px, H[5]));
-				Xz[m] = fmaf(H[7], py, fmaf(H[6], px, H[8]));
-			} else {
-				Xx[m] = fmaf(H[1], py, fmaf(H[0], px, H[2]));
-				Xy[m] = fmaf(H[4], py, fmaf(H[3], px, H[5]));
-				Xz[m] = fmaf(H[7], py, fmaf(H[6], px, H[8]));
-			}
+			Xx[m] = fmaf(H[1], py, fmaf(H[0], px, H[2])); /* the column term is formed first */
+			Xy[m] = fmaf(H[4], py, fmaf(H[3], px, H[5]));
+			Xz[m] = fmaf(H[7], py, fmaf(H[6], px, H[8])); /* steps past the patch repeat the clamped tap */
 		}
 		if (MAXM >= 4) { /* one IEEE reciprocal per group of four taps */
 			for (int g = 0; g < MAXM; g += 4) {

@@ -34,12 +34,12 @@
 
 static inline float pm_bits2f(uint32_t b) { float f; memcpy(&f, &b, sizeof f); return f; }
 
-/* e^x, x float.  Results below 2^-126 flush to 0 (inputs below -87) */
+/* e^x, x float.  Results below 2^-126 flush to 0 (inputs below -87).  Straight-line: out-of-range inputs are
+ * clamped for the evaluation and fixed up by selects at the end. */
 static inline float pm_expf(float x) {
-	if (!(x > -87.0f)) return (x != x) ? x : 0.0f;
-	if (x > 88.0f) return INFINITY;
-	const float kf = floorf(fmaf(x, PM_INVLN2_F, 0.5f));
-	float r = fmaf(-kf, PM_LN2_HI_F, x);
+	const float xc = fminf(fmaxf(x, -87.0f), 88.0f);
+	const float kf = floorf(fmaf(xc, PM_INVLN2_F, 0.5f));
+	float r = fmaf(-kf, PM_LN2_HI_F, xc);
 	r = fmaf(-kf, PM_LN2_LO_F, r); /* |r| <= 0.3466 */
 	float p = 1.0f / 5040.0f;
 	p = fmaf(p, r, 1.0f / 720.0f);
@@ -49,7 +49,10 @@ static inline float pm_expf(float x) {
 	p = fmaf(p, r, 0.5f);
 	p = fmaf(p, r, 1.0f);
 	p = fmaf(p, r, 1.0f);
-	return p * pm_bits2f((uint32_t)((int)kf + 127) << 23);
+	float e = p * pm_bits2f((uint32_t)((int)kf + 127) << 23);
+	e = x > -87.0f ? e : 0.0f;
+	e = x > 88.0f ? INFINITY : e;
+	return x != x ? x : e;
 }
 
 /* sin and cos of a float angle, |x| < ~100 */
@@ -92,21 +95,19 @@ static inline float pm_asin_r(float z) {
 	p = fmaf(p, z, 0x1.555554p-3f);
 	return p;
 }
-/* acos(x); |x| >= 1 clamps to the end points (libm returns NaN beyond them) */
+/* acos(x); |x| >= 1 clamps to the end points (libm returns NaN beyond them).  Straight-line: one polynomial
+ * evaluation serves both the |x| <= 0.5 and the |x| > 0.5 form. */
 static inline float pm_acosf(float x) {
-	if (x != x) return x;
 	const float ax = fabsf(x);
-	if (ax >= 1.0f) return x > 0.0f ? 0.0f : PM_PI_F;
-	if (ax <= 0.5f) {
-		const float z = x * x;
-		const float a = fmaf(x * z, pm_asin_r(z), x); /* asin(x) */
-		return (PM_PIO2_F - a) + PM_PIO2_LO_F;
-	}
-	const float z = (1.0f - ax) * 0.5f;
-	const float s = sqrtf(z);
-	const float t = fmaf(s * z, pm_asin_r(z), s); /* asin(sqrt(z)) = acos(ax)/2 */
-	if (x > 0.0f) return 2.0f * t;
-	return (PM_PI_F - 2.0f * t) + PM_PI_LO_F;
+	const int small = ax <= 0.5f;
+	const float z = small ? x * x : (1.0f - ax) * 0.5f;
+	const float s = small ? x : sqrtf(z);
+	const float t = fmaf(s * z, pm_asin_r(z), s); /* asin(x) resp. asin(sqrt(z)) = acos(|x|)/2 */
+	const float a_small = (PM_PIO2_F - t) + PM_PIO2_LO_F;
+	const float a_big = x > 0.0f ? 2.0f * t : (PM_PI_F - 2.0f * t) + PM_PI_LO_F;
+	float a = small ? a_small : a_big;
+	a = ax >= 1.0f ? (x > 0.0f ? 0.0f : PM_PI_F) : a;
+	return x != x ? x : a;
 }
 
 /* atan2(y, x) */
