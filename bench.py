@@ -55,6 +55,17 @@ def cpu_baseline(n_threads):
             "sample": "960x540 synthetic scene, 8 source views, 7x7 taps, 8 sweeps, one full estimate (%.1f s)" % dt}
 
 
+def pmc_traffic(batch):
+    """HBM bytes per sweep launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes of this same
+    command (profiles/r01_pmc_hbm.json, made by tests/prof_bench.sh + profiles/summarize_pmc.py); PMC counters
+    cannot be collected from inside the process, so the value is null for any other batch size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
+            return json.load(f).get("sweep_kernel_batch%d_hbm_bytes_per_launch" % batch)
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,7 +188,7 @@ def main():
                           "estimate_total": round(st.ms_total, 3)},
             "roofline": {"kernel": "sweep_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None,
+                         "traffic": pmc_traffic(B),
                          "algorithmic_bytes_per_launch": int(bytes_sweep),
                          "avg_launch_ms": round(st.ms_sweep_avg, 3)},
         }

@@ -1,0 +1,475 @@
+/*
+ * hc-mvs_amd/host/DensifyPointCloud.cpp -- command-line driver with the reference's DensifyPointCloud interface
+ * (frame_main/apps/DensifyPointCloud/DensifyPointCloud.cpp:71-198, 373-449) on top of the C-ABI of
+ * include/hcmvs_hip.h.  It reads an `.mvs` scene (MVSI v5, Interface.h:363-619) and the images it names, selects the
+ * source views of every image the way Scene::SelectNeighborViews / FilterNeighborViews / InitViews do
+ * (Scene.cpp:545-678, SceneDensify.cpp:336-397), runs the PatchMatch estimate for the requested outer iterations
+ * (Scene::DenseReconstruction, SceneDensify.cpp:3532-3574, 3684), writes raw 'DR' depth maps
+ * (DepthMap.cpp:2781-2846), fuses them (SceneDensify.cpp:3265-3495) and saves `<out>.ply` + `<out>.mvs`
+ * (DensifyPointCloud.cpp:447-449).
+ *
+ * Deliberately narrower than the reference ("defined subset"): images are read from binary
+ * PPM/PGM files (no PNG/JPEG codecs here); resolution levels halve the image with a box filter (== cv::resize
+ * INTER_AREA for integer factors); the initial maps are splatted from the sparse points (nMinViewsTrustPoint < 2
+ * branch); optical flow, semantic priors, view spread, gap interpolation and SGM modes are not available and the
+ * corresponding flags are accepted and ignored with a note.
+ */
+#include "../../include/hcmvs_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Options { // DensifyPointCloud.cpp:139-198 (defaults from there)
+	std::string input, output, workdir;
+	int resolutionLevel = 1, numberViews = 5, numberViewsFuse = 2, fusionMode = 0, verbosity = 2;
+	int estimationIters = 1, estimationItersExternal = 4, adaptHalfWin = 5, propagateHalfWin = 1, propagateStep = 4;
+	float photometricFlow = 0.5f, depthweight = 1.f, normalweight = 1.f;
+	int device = 0, batch = 8;
+	uint32_t seed = 1234;
+};
+
+struct Camera { double K[9], R[9], C[3]; };
+struct ImageData {
+	std::string name;
+	uint32_t id = 0;
+	int w = 0, h = 0;
+	Camera cam;
+	std::vector<uint8_t> bgr;   // working-resolution colour image (B,G,R)
+	std::vector<float> gray;    // Types.inl:2354-2400 toGray, normalised
+	bool valid = false;
+	std::vector<uint32_t> points;               // sparse points seen (>= 2 views), Scene.cpp:568-569
+	struct Nb { uint32_t id; uint32_t points; float scale, angle, area, score; };
+	std::vector<Nb> neighbors;                  // Scene.cpp:640-650, sorted by score
+	std::vector<uint32_t> srcs;                 // SceneDensify.cpp:362-367
+	float dMin = 0, dMax = 0;
+	float *dDepth = nullptr, *dNormal = nullptr, *dConf = nullptr; // device maps
+};
+struct Vertex { float X[3]; std::vector<std::pair<uint32_t, float>> views; };
+
+// ---- .mvs (Interface.h:316-354 archive primitives) ----------------------------------------------------------------
+struct Reader {
+	std::ifstream f;
+	template <typename T> T get() { T v; f.read((char*)&v, sizeof v); return v; }
+	std::string str() { uint64_t n = get<uint64_t>(); std::string s(n, '\0'); if (n) f.read(&s[0], (std::streamsize)n); return s; }
+	void mat(double* m, int n) { f.read((char*)m, sizeof(double) * n); }
+};
+struct MvsCamera { std::string name; uint32_t w, h; double K[9], R[9], C[3]; };
+struct MvsPose { double R[9], C[3]; };
+struct MvsPlatform { std::string name; std::vector<MvsCamera> cams; std::vector<MvsPose> poses; };
+struct MvsImage { std::string name; uint32_t platformID, cameraID, poseID, ID; };
+
+bool load_mvs(const std::string& path, std::vector<MvsPlatform>& platforms, std::vector<MvsImage>& images, std::vector<Vertex>& verts) {
+	Reader r;
+	r.f.open(path, std::ios::binary);
+	if (!r.f) return false;
+	char magic[4];
+	r.f.read(magic, 4);
+	if (strncmp(magic, "MVSI", 4) != 0) return false;
+	const uint32_t ver = r.get<uint32_t>();
+	r.get<uint32_t>();
+	if (ver < 3 || ver > 5) { fprintf(stderr, "error: unsupported MVSI version %u\n", ver); return false; }
+	platforms.resize(r.get<uint64_t>());
+	for (auto& p : platforms) {
+		p.name = r.str();
+		p.cams.resize(r.get<uint64_t>());
+		for (auto& c : p.cams) {
+			c.name = r.str();
+			if (ver > 3) r.str(); // bandName
+			c.w = r.get<uint32_t>(); c.h = r.get<uint32_t>();
+			r.mat(c.K, 9); r.mat(c.R, 9); r.mat(c.C, 3);
+		}
+		p.poses.resize(r.get<uint64_t>());
+		for (auto& q : p.poses) { r.mat(q.R, 9); r.mat(q.C, 3); }
+	}
+	images.resize(r.get<uint64_t>());
+	for (auto& im : images) {
+		im.name = r.str();
+		if (ver > 4) r.str(); // maskName
+		im.platformID = r.get<uint32_t>(); im.cameraID = r.get<uint32_t>(); im.poseID = r.get<uint32_t>();
+		im.ID = r.get<uint32_t>();
+	}
+	verts.resize(r.get<uint64_t>());
+	for (auto& v : verts) {
+		r.f.read((char*)v.X, 12);
+		v.views.resize(r.get<uint64_t>());
+		for (auto& w : v.views) { w.first = r.get<uint32_t>(); w.second = r.get<float>(); }
+	}
+	return (bool)r.f;
+}
+
+struct Writer {
+	std::ofstream f;
+	template <typename T> void put(const T& v) { f.write((const char*)&v, sizeof v); }
+	void str(const std::string& s) { put<uint64_t>(s.size()); f.write(s.data(), (std::streamsize)s.size()); }
+};
+bool save_mvs(const std::string& path, const std::vector<MvsPlatform>& platforms, const std::vector<MvsImage>& images,
+              const std::vector<float>& xyz, const std::vector<float>& normals, const std::vector<uint8_t>& bgr) {
+	Writer w;
+	w.f.open(path, std::ios::binary);
+	if (!w.f) return false;
+	w.f.write("MVSI", 4); w.put<uint32_t>(5); w.put<uint32_t>(0);
+	w.put<uint64_t>(platforms.size());
+	for (const auto& p : platforms) {
+		w.str(p.name);
+		w.put<uint64_t>(p.cams.size());
+		for (const auto& c : p.cams) {
+			w.str(c.name); w.str("");
+			w.put(c.w); w.put(c.h);
+			w.f.write((const char*)c.K, 72); w.f.write((const char*)c.R, 72); w.f.write((const char*)c.C, 24);
+		}
+		w.put<uint64_t>(p.poses.size());
+		for (const auto& q : p.poses) { w.f.write((const char*)q.R, 72); w.f.write((const char*)q.C, 24); }
+	}
+	w.put<uint64_t>(images.size());
+	for (const auto& im : images) { w.str(im.name); w.str(""); w.put(im.platformID); w.put(im.cameraID); w.put(im.poseID); w.put(im.ID); }
+	const uint64_t n = xyz.size() / 3;
+	w.put<uint64_t>(n);
+	for (uint64_t i = 0; i < n; ++i) { w.f.write((const char*)&xyz[3 * i], 12); w.put<uint64_t>(0); }
+	w.put<uint64_t>(normals.size() / 3); w.f.write((const char*)normals.data(), (std::streamsize)normals.size() * 4);
+	w.put<uint64_t>(bgr.size() / 3); w.f.write((const char*)bgr.data(), (std::streamsize)bgr.size());
+	for (int i = 0; i < 3; ++i) w.put<uint64_t>(0);
+	const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+	w.f.write((const char*)eye, sizeof eye);
+	return (bool)w.f;
+}
+
+// ---- images --------------------------------------------------------------------------------------------------------
+bool load_pnm(const std::string& path, int& w, int& h, std::vector<uint8_t>& bgr) {
+	std::ifstream f(path, std::ios::binary);
+	if (!f) return false;
+	std::string magic;
+	f >> magic;
+	if (magic != "P5" && magic != "P6") return false;
+	auto next = [&]() { int v = 0; for (;;) { f >> std::ws; if (f.peek() == '#') { std::string l; std::getline(f, l); } else break; } f >> v; return v; };
+	w = next(); h = next();
+	const int maxv = next();
+	f.get();
+	if (w <= 0 || h <= 0 || maxv != 255) return false;
+	const int ch = magic == "P6" ? 3 : 1;
+	std::vector<uint8_t> raw((size_t)w * h * ch);
+	f.read((char*)raw.data(), (std::streamsize)raw.size());
+	if (!f) return false;
+	bgr.resize((size_t)w * h * 3);
+	for (size_t i = 0; i < (size_t)w * h; ++i) {
+		if (ch == 3) { bgr[3 * i] = raw[3 * i + 2]; bgr[3 * i + 1] = raw[3 * i + 1]; bgr[3 * i + 2] = raw[3 * i]; }
+		else bgr[3 * i] = bgr[3 * i + 1] = bgr[3 * i + 2] = raw[i];
+	}
+	return true;
+}
+// halve with a 2x2 box filter (cv::resize INTER_AREA for an integer factor), rounding like saturate_cast
+void halve(int& w, int& h, std::vector<uint8_t>& bgr) {
+	const int nw = w / 2, nh = h / 2;
+	std::vector<uint8_t> out((size_t)nw * nh * 3);
+	for (int y = 0; y < nh; ++y)
+		for (int x = 0; x < nw; ++x)
+			for (int c = 0; c < 3; ++c) {
+				const int s = bgr[3 * ((size_t)(2 * y) * w + 2 * x) + c] + bgr[3 * ((size_t)(2 * y) * w + 2 * x + 1) + c] +
+				              bgr[3 * ((size_t)(2 * y + 1) * w + 2 * x) + c] + bgr[3 * ((size_t)(2 * y + 1) * w + 2 * x + 1) + c];
+				out[3 * ((size_t)y * nw + x) + c] = (uint8_t)((s + 2) >> 2);
+			}
+	w = nw; h = nh; bgr.swap(out);
+}
+
+// ---- camera helpers (Camera.h) -------------------------------------------------------------------------------------
+void mat3mul(const double* a, const double* b, double* c) {
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += a[i * 3 + k] * b[k * 3 + j]; c[i * 3 + j] = s; }
+}
+void w2c(const Camera& c, const float* X, double* o) {
+	const double d[3] = {X[0] - c.C[0], X[1] - c.C[1], X[2] - c.C[2]};
+	for (int i = 0; i < 3; ++i) o[i] = c.R[i * 3] * d[0] + c.R[i * 3 + 1] * d[1] + c.R[i * 3 + 2] * d[2];
+}
+bool project(const Camera& c, const float* X, float& u, float& v, double& z) {
+	double p[3];
+	w2c(c, X, p);
+	z = p[2];
+	if (p[2] <= 0) return false;
+	u = (float)(c.K[2] + c.K[0] * p[0] / p[2]); v = (float)(c.K[5] + c.K[4] * p[1] / p[2]);
+	return true;
+}
+
+// Scene.cpp:545-661 SelectNeighborViews + Scene.cpp:665-678 FilterNeighborViews (defaults DepthMap.cpp:69-143)
+bool select_views(std::vector<ImageData>& images, const std::vector<Vertex>& verts, uint32_t ID, int nMaxViews, int numberViews) {
+	ImageData& A = images[ID];
+	const float fOptimAngle = 10.f * 3.14159265f / 180.f, fMinAngle = 3.f * 3.14159265f / 180.f, fMaxAngle = 65.f * 3.14159265f / 180.f;
+	struct Score { float score = 0, avgScale = 0, avgAngle = 0; uint32_t points = 0; };
+	std::vector<Score> scores(images.size());
+	for (uint32_t idx = 0; idx < verts.size(); ++idx) {
+		const Vertex& v = verts[idx];
+		bool seen = false;
+		for (const auto& w : v.views) if (w.first == ID) { seen = true; break; }
+		if (!seen) continue;
+		if (v.views.size() >= 2) A.points.push_back(idx);
+		double pc[3];
+		w2c(A.cam, v.X, pc);
+		const float V1[3] = {(float)(A.cam.C[0] - v.X[0]), (float)(A.cam.C[1] - v.X[1]), (float)(A.cam.C[2] - v.X[2])};
+		const float fp1 = (float)(A.cam.K[0] / pc[2]); // Footprint, Scene.cpp:531-539
+		for (const auto& w : v.views) {
+			if (w.first == ID || w.first >= images.size() || !images[w.first].valid) continue;
+			const ImageData& B = images[w.first];
+			const float V2[3] = {(float)(B.cam.C[0] - v.X[0]), (float)(B.cam.C[1] - v.X[1]), (float)(B.cam.C[2] - v.X[2])};
+			float ca = (V1[0] * V2[0] + V1[1] * V2[1] + V1[2] * V2[2]) /
+			           std::sqrt((V1[0] * V1[0] + V1[1] * V1[1] + V1[2] * V1[2]) * (V2[0] * V2[0] + V2[1] * V2[1] + V2[2] * V2[2]));
+			ca = std::min(1.f, std::max(-1.f, ca));
+			const float ang = std::acos(ca);
+			const float wAngle = std::min(std::pow(ang / fOptimAngle, 1.5f), 1.f);
+			double pb[3];
+			w2c(B.cam, v.X, pb);
+			const float r = fp1 / (float)(B.cam.K[0] / pb[2]);
+			const float wScale = r > 1.6f ? (1.6f / r) * (1.6f / r) : (r >= 1.f ? 1.f : r * r);
+			Score& s = scores[w.first];
+			s.score += wAngle * wScale; s.avgScale += r; s.avgAngle += ang; ++s.points;
+		}
+	}
+	for (uint32_t IDB = 0; IDB < images.size(); ++IDB) {
+		const Score& s = scores[IDB];
+		if (!images[IDB].valid || s.points < 3) continue;
+		const ImageData& B = images[IDB];
+		bool grid[16][16] = {};
+		int n = 0;
+		for (uint32_t idx : A.points) {
+			const Vertex& v = verts[idx];
+			bool inB = false;
+			for (const auto& w : v.views) if (w.first == IDB) { inB = true; break; }
+			if (!inB) continue;
+			float ua, va, ub, vb; double za, zb;
+			if (!project(A.cam, v.X, ua, va, za) || !project(B.cam, v.X, ub, vb, zb)) continue;
+			if (ua < 0 || va < 0 || ua >= A.w || va >= A.h || ub < 0 || vb < 0 || ub >= B.w || vb >= B.h) continue;
+			grid[std::min(15, (int)(ua / A.w * 16))][std::min(15, (int)(va / A.h * 16))] = true; // Util.inl:711-730
+			++n;
+		}
+		if (!n) continue;
+		int cells = 0;
+		for (auto& row : grid) for (bool c : row) cells += c;
+		ImageData::Nb nb{IDB, s.points, s.avgScale / s.points, s.avgAngle / s.points, cells / 256.f, 0.f};
+		nb.score = s.score * nb.area;
+		A.neighbors.push_back(nb);
+	}
+	std::stable_sort(A.neighbors.begin(), A.neighbors.end(), [](const ImageData::Nb& a, const ImageData::Nb& b) { return a.score > b.score; });
+	if (A.points.size() <= 3 || A.neighbors.size() < (size_t)std::min<int>(2, (int)images.size() - 1)) return false;
+	std::vector<ImageData::Nb> kept;
+	for (const auto& nb : A.neighbors)
+		if (!(nb.area < 0.01f) && nb.scale >= 0.2f && nb.scale < 3.2f && nb.angle >= fMinAngle && nb.angle < fMaxAngle) kept.push_back(nb);
+	if ((int)kept.size() > nMaxViews) kept.resize(nMaxViews);
+	A.neighbors.swap(kept);
+	if (A.neighbors.empty()) return false;
+	// SceneDensify.cpp:362-367: neighbours in score order while #images <= number-views and score >= best * 0.03
+	const float fMinScore = A.neighbors[0].score * (0.3f * 0.1f);
+	for (const auto& nb : A.neighbors) {
+		if ((numberViews && (int)A.srcs.size() + 1 > numberViews) || nb.score < fMinScore) break;
+		if (std::fabs(nb.scale - 1.f) >= 0.15f) continue; // would need the rescaled-neighbour path (DepthMap.h:233-238)
+		A.srcs.push_back(nb.id);
+	}
+	return !A.srcs.empty();
+}
+
+bool save_dmap(const std::string& path, const ImageData& im, const std::vector<float>& d, const std::vector<float>& n, const std::vector<float>& c) {
+	std::ofstream f(path + ".tmp", std::ios::binary); // atomic like DepthData::Save (DepthMap.cpp:253-286)
+	if (!f) return false;
+	struct __attribute__((packed)) Hdr { uint16_t name; uint8_t type, pad; uint32_t iw, ih, dw, dh; float dMin, dMax; } h;
+	h.name = 0x5244; h.type = 7; h.pad = 0; h.iw = h.dw = (uint32_t)im.w; h.ih = h.dh = (uint32_t)im.h; h.dMin = im.dMin; h.dMax = im.dMax;
+	f.write((const char*)&h, 28);
+	const uint16_t nl = (uint16_t)im.name.size();
+	f.write((const char*)&nl, 2); f.write(im.name.data(), nl);
+	const uint32_t nids = 1 + (uint32_t)im.srcs.size();
+	f.write((const char*)&nids, 4); f.write((const char*)&im.id, 4); f.write((const char*)im.srcs.data(), (std::streamsize)im.srcs.size() * 4);
+	f.write((const char*)im.cam.K, 72); f.write((const char*)im.cam.R, 72); f.write((const char*)im.cam.C, 24);
+	f.write((const char*)d.data(), (std::streamsize)d.size() * 4); f.write((const char*)n.data(), (std::streamsize)n.size() * 4);
+	f.write((const char*)c.data(), (std::streamsize)c.size() * 4);
+	f.close();
+	return std::rename((path + ".tmp").c_str(), path.c_str()) == 0;
+}
+bool save_ply(const std::string& path, const std::vector<float>& xyz, const std::vector<float>& nrm, const std::vector<uint8_t>& bgr) {
+	std::ofstream f(path, std::ios::binary); // PointCloud.cpp:189-240
+	if (!f) return false;
+	const size_t n = xyz.size() / 3;
+	f << "ply\nformat binary_little_endian 1.0\nelement vertex " << n << "\nproperty float x\nproperty float y\nproperty float z\n"
+	  << "property float nx\nproperty float ny\nproperty float nz\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n";
+	for (size_t i = 0; i < n; ++i) {
+		f.write((const char*)&xyz[3 * i], 12); f.write((const char*)&nrm[3 * i], 12);
+		const uint8_t rgb[3] = {bgr[3 * i + 2], bgr[3 * i + 1], bgr[3 * i]};
+		f.write((const char*)rgb, 3);
+	}
+	return (bool)f;
+}
+
+std::string dirname_of(const std::string& p) { const size_t k = p.find_last_of('/'); return k == std::string::npos ? "." : p.substr(0, k); }
+
+} // namespace
+
+#define CHK(call) do { const int rc_ = (call); if (rc_ != HCMVS_OK) { fprintf(stderr, "error: %s -> %d (%s)\n", #call, rc_, hcmvs_last_error(ctx)); return EXIT_FAILURE; } } while (0)
+#define HIPOK(call) do { if ((call) != hipSuccess) { fprintf(stderr, "error: %s failed\n", #call); return EXIT_FAILURE; } } while (0)
+
+int main(int argc, char** argv) {
+	Options o;
+	std::map<std::string, std::string> kv;
+	for (int i = 1; i < argc; ++i) {
+		std::string a = argv[i], val;
+		const size_t eq = a.find('=');
+		if (eq != std::string::npos) { val = a.substr(eq + 1); a = a.substr(0, eq); }
+		else if (i + 1 < argc && argv[i + 1][0] != '-') val = argv[++i];
+		kv[a] = val;
+	}
+	auto geti = [&](const char* k, int& v) { if (kv.count(k)) v = atoi(kv[k].c_str()); };
+	auto getf = [&](const char* k, float& v) { if (kv.count(k)) v = (float)atof(kv[k].c_str()); };
+	for (const char* k : {"-i", "--input-file"}) if (kv.count(k)) o.input = kv[k];
+	for (const char* k : {"-o", "--output-file"}) if (kv.count(k)) o.output = kv[k];
+	for (const char* k : {"-w", "--working-folder"}) if (kv.count(k)) o.workdir = kv[k];
+	geti("-v", o.verbosity); geti("--verbosity", o.verbosity);
+	geti("--resolution-level", o.resolutionLevel); geti("--number-views", o.numberViews); geti("--number-views-fuse", o.numberViewsFuse);
+	geti("--fusion-mode", o.fusionMode); geti("--n-EstimationIters", o.estimationIters);
+	geti("--n-EstimationIters-external", o.estimationItersExternal); geti("--n-adapthalfwin", o.adaptHalfWin);
+	geti("--n-propagatehalfwin", o.propagateHalfWin); geti("--n-propagatestep", o.propagateStep);
+	getf("--n-photometric_flow", o.photometricFlow); getf("--depthweight", o.depthweight); getf("--normalweight", o.normalweight);
+	geti("--device", o.device); geti("--batch", o.batch);
+	if (kv.count("--seed")) o.seed = (uint32_t)strtoul(kv["--seed"].c_str(), nullptr, 10);
+	for (const char* k : {"--n-opticalflow", "--n-viewspread", "--use-semantic", "--n-nOptimize", "--n-usegeoconsistency", "--n-usepartconsistency"})
+		if (kv.count(k) && atoi(kv[k].c_str()) != 0 && o.verbosity > 1)
+			fprintf(stderr, "note: %s is not available in this build (defined subset); treated as 0\n", k);
+	if (o.input.empty()) {
+		fprintf(stderr, "usage: DensifyPointCloud -i scene.mvs [-o out.mvs] [-w dir] [--resolution-level n] [--number-views n] "
+		                "[--n-EstimationIters n] [--n-EstimationIters-external n] [--n-adapthalfwin n] [--fusion-mode 0|1] ...\n");
+		return EXIT_FAILURE;
+	}
+	if (o.fusionMode < 0) { fprintf(stderr, "error: SGM fusion modes are not available\n"); return EXIT_FAILURE; }
+	if (o.workdir.empty()) o.workdir = dirname_of(o.input);
+	if (o.output.empty()) o.output = o.input.substr(0, o.input.rfind('.')) + "_dense.mvs";
+	if (o.batch < 1) o.batch = 1;
+	if (o.batch > 16) o.batch = 16;
+
+	std::vector<MvsPlatform> platforms; std::vector<MvsImage> mimages; std::vector<Vertex> verts;
+	if (!load_mvs(o.input, platforms, mimages, verts)) { fprintf(stderr, "error: can not load '%s'\n", o.input.c_str()); return EXIT_FAILURE; }
+	std::vector<ImageData> images(mimages.size());
+	unsigned nValid = 0;
+	for (size_t i = 0; i < mimages.size(); ++i) {
+		ImageData& im = images[i];
+		im.name = mimages[i].name; im.id = (uint32_t)i;
+		if (mimages[i].poseID == 0xFFFFFFFFu || mimages[i].platformID >= platforms.size()) continue; // uncalibrated
+		const MvsPlatform& p = platforms[mimages[i].platformID];
+		const MvsCamera& c = p.cams[mimages[i].cameraID];
+		const MvsPose& q = p.poses[mimages[i].poseID];
+		std::string path = im.name[0] == '/' ? im.name : dirname_of(o.input) + "/" + im.name;
+		if (!load_pnm(path, im.w, im.h, im.bgr)) { fprintf(stderr, "error: failed loading image '%s' (binary PPM/PGM expected)\n", path.c_str()); return EXIT_FAILURE; }
+		for (int l = 0; l < o.resolutionLevel && std::min(im.w, im.h) / 2 >= 64; ++l) halve(im.w, im.h, im.bgr);
+		// Interface.h:451-459 pose composition; K rescaled to the working resolution (Scene.cpp:83-91, Camera.h:167-180)
+		mat3mul(c.R, q.R, im.cam.R);
+		for (int k = 0; k < 3; ++k) im.cam.C[k] = q.R[0 * 3 + k] * c.C[0] + q.R[1 * 3 + k] * c.C[1] + q.R[2 * 3 + k] * c.C[2] + q.C[k];
+		// Scene.cpp:83-91 + Camera.h:167-180 (GetK): K normalised by max(w,h) of the camera, scaled to the working size
+		const double s = (double)std::max(im.w, im.h) / (c.w && c.h ? (double)std::max(c.w, c.h) : 1.0);
+		memcpy(im.cam.K, c.K, sizeof im.cam.K);
+		im.cam.K[1] = 0;
+		im.cam.K[0] *= s; im.cam.K[4] *= s;
+		if (c.K[2] == 0 && c.K[5] == 0) { im.cam.K[2] = 0.5 * (im.w - 1); im.cam.K[5] = 0.5 * (im.h - 1); }
+		else { im.cam.K[2] *= s; im.cam.K[5] *= s; }
+		im.gray.resize((size_t)im.w * im.h);
+		for (size_t k = 0; k < im.gray.size(); ++k)
+			im.gray[k] = (0.114f * im.bgr[3 * k] + 0.587f * im.bgr[3 * k + 1] + 0.299f * im.bgr[3 * k + 2]) / 255.f;
+		im.valid = true;
+		++nValid;
+	}
+	if (o.verbosity > 1) printf("Scene loaded: %zu images (%u calibrated), %zu sparse points\n", images.size(), nValid, verts.size());
+
+	hcmvs_ctx* ctx = nullptr;
+	if (hcmvs_create(o.device, &ctx) != HCMVS_OK) { fprintf(stderr, "error: no usable MI355X device (there is no CPU path)\n"); return EXIT_FAILURE; }
+	std::vector<uint32_t> todo;
+	for (auto& im : images) {
+		if (!im.valid) continue;
+		CHK(hcmvs_upload_view(ctx, im.id, im.w, im.h, im.gray.data(), im.bgr.data(), im.cam.K, im.cam.R, im.cam.C));
+		if (!select_views(images, verts, im.id, 12, o.numberViews)) {
+			if (o.verbosity > 1) printf("Reference image %3u has not enough images in view\n", im.id);
+			continue;
+		}
+		todo.push_back(im.id);
+		if (o.verbosity > 2) { printf("Reference image %3u paired with %zu views:", im.id, im.srcs.size()); for (uint32_t s : im.srcs) printf(" %u", s); printf("\n"); }
+	}
+	hcmvs_params prm;
+	hcmvs_default_params(&prm);
+	prm.adapthalfwin = o.adaptHalfWin; prm.n_estimation_iters = o.estimationIters; prm.n_external_iters = o.estimationItersExternal;
+	prm.propagate_halfwin = o.propagateHalfWin; prm.propagate_step = o.propagateStep; prm.photometric_flow = o.photometricFlow; prm.seed = o.seed;
+
+	// initial maps: splat of the sparse points (SceneDensify.cpp:783-808), kept on the device between outer iterations
+	for (uint32_t id : todo) {
+		ImageData& im = images[id];
+		std::vector<float> pts;
+		for (uint32_t idx : im.points) { pts.push_back(verts[idx].X[0]); pts.push_back(verts[idx].X[1]); pts.push_back(verts[idx].X[2]); }
+		const size_t n = (size_t)im.w * im.h;
+		std::vector<float> d(n), nn(3 * n, 0.f);
+		CHK(hcmvs_splat_init(ctx, id, pts.data(), (int32_t)im.points.size(), d.data(), nn.data(), &im.dMin, &im.dMax));
+		HIPOK(hipMalloc(&im.dDepth, n * 4)); HIPOK(hipMalloc(&im.dNormal, n * 12)); HIPOK(hipMalloc(&im.dConf, n * 4));
+		HIPOK(hipMemcpy(im.dDepth, d.data(), n * 4, hipMemcpyHostToDevice)); HIPOK(hipMemcpy(im.dNormal, nn.data(), n * 12, hipMemcpyHostToDevice));
+		HIPOK(hipMemset(im.dConf, 0, n * 4));
+	}
+	// outer iterations over all images (SceneDensify.cpp:3684), images of equal source count batched per launch
+	for (int it = 0; it < o.estimationItersExternal; ++it) {
+		prm.it_external = it;
+		std::map<size_t, std::vector<uint32_t>> byV;
+		for (uint32_t id : todo) byV[images[id].srcs.size()].push_back(id);
+		for (auto& g : byV)
+			for (size_t b0 = 0; b0 < g.second.size(); b0 += (size_t)o.batch) {
+				std::vector<hcmvs_batch_item> items;
+				for (size_t b = b0; b < std::min(g.second.size(), b0 + (size_t)o.batch); ++b) {
+					ImageData& im = images[g.second[b]];
+					hcmvs_batch_item itx;
+					itx.ref_id = im.id; itx.src_ids = im.srcs.data(); itx.n_src = (int32_t)im.srcs.size(); itx.seed_offset = im.id;
+					itx.d_min = im.dMin; itx.d_max = im.dMax; itx.d_depth = im.dDepth; itx.d_normal = im.dNormal; itx.d_conf = im.dConf;
+					items.push_back(itx);
+				}
+				CHK(hcmvs_estimate_batch_device(ctx, items.data(), (int32_t)items.size(), &prm));
+				hcmvs_stats st;
+				CHK(hcmvs_get_stats(ctx, &st));
+				if (o.verbosity > 2)
+					for (const auto& itx : items)
+						printf("Depth-map for image %3u estimated using %2d images: %dx%d (outer iteration %d, batch %.0f ms)\n", itx.ref_id,
+						       itx.n_src, images[itx.ref_id].w, images[itx.ref_id].h, it, st.ms_total);
+			}
+	}
+	// save the depth maps (raw 'DR'), register them for fusion
+	uint64_t capacity = 0;
+	for (uint32_t id : todo) {
+		ImageData& im = images[id];
+		const size_t n = (size_t)im.w * im.h;
+		std::vector<float> d(n), nn(3 * n), c(n);
+		HIPOK(hipMemcpy(d.data(), im.dDepth, n * 4, hipMemcpyDeviceToHost)); HIPOK(hipMemcpy(nn.data(), im.dNormal, n * 12, hipMemcpyDeviceToHost));
+		HIPOK(hipMemcpy(c.data(), im.dConf, n * 4, hipMemcpyDeviceToHost));
+		char nm[64];
+		snprintf(nm, sizeof nm, "/depth%04u.dmap", id);
+		if (!save_dmap(o.workdir + nm, im, d, nn, c)) { fprintf(stderr, "error: can not write '%s%s'\n", o.workdir.c_str(), nm); return EXIT_FAILURE; }
+		CHK(hcmvs_set_depthmap_device(ctx, id, im.dDepth, im.dNormal, im.dConf, im.dMin, im.dMax));
+		std::vector<uint32_t> nb;
+		for (const auto& x : im.neighbors) if (std::find(todo.begin(), todo.end(), x.id) != todo.end()) nb.push_back(x.id);
+		if (nb.size() > 31) nb.resize(31);
+		CHK(hcmvs_set_neighbors(ctx, id, nb.data(), (int32_t)nb.size()));
+		capacity += (uint64_t)(n / 2);
+	}
+	if (o.fusionMode == 1 || todo.empty()) { hcmvs_destroy(ctx); return EXIT_SUCCESS; }
+	// fuse: best connected images first (SceneDensify.cpp:3285-3302)
+	std::vector<uint32_t> order(todo);
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return images[a].neighbors.size() > images[b].neighbors.size(); });
+	std::vector<float> xyz(capacity * 3), nrm(capacity * 3); std::vector<uint8_t> bgr(capacity * 3); std::vector<uint32_t> nviews(capacity);
+	uint64_t nPoints = 0, nDepths = 0;
+	CHK(hcmvs_fuse(ctx, order.data(), (int32_t)order.size(), std::min<int>(o.numberViewsFuse, (int)images.size()), 0.01f, 25.f, o.depthweight,
+	               o.normalweight, capacity, xyz.data(), nrm.data(), bgr.data(), nviews.data(), &nPoints, &nDepths));
+	xyz.resize(nPoints * 3); nrm.resize(nPoints * 3); bgr.resize(nPoints * 3);
+	if (o.verbosity > 1)
+		printf("Depth-maps fused and filtered: %zu depth-maps, %llu depths, %llu points (%d%%)\n", order.size(), (unsigned long long)nDepths,
+		       (unsigned long long)nPoints, nDepths ? (int)std::lround(100.0 * nPoints / nDepths) : 0);
+	const std::string base = o.output.substr(0, o.output.rfind('.'));
+	if (!save_mvs(o.output, platforms, mimages, xyz, nrm, bgr) || !save_ply(base + ".ply", xyz, nrm, bgr)) {
+		fprintf(stderr, "error: can not write the output files\n");
+		return EXIT_FAILURE;
+	}
+	for (auto& im : images) for (float* p : {im.dDepth, im.dNormal, im.dConf}) if (p) (void)hipFree(p);
+	hcmvs_destroy(ctx);
+	return EXIT_SUCCESS;
+}
