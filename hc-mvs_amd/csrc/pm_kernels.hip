@@ -9,19 +9,22 @@
  *   ScoreDepthMapTmp / EstimateDepthMapTmp / EndDepthMapTmp   SceneDensify.cpp:649-744
  *
  * How it is mapped to CDNA4 (not a translation of the reference's pthread loop):
- *   - ONE WAVEFRONT PER IMAGE ROW.  The reference sweeps pixels sequentially (Gauss-Seidel): a pixel must
- *     see its left/up neighbours already updated and its right/down neighbours not yet updated.  Rows
- *     advancing left-to-right with row y one pixel behind row y-1 satisfy exactly that dependence, so all
- *     rows run concurrently as persistent waves that hand results down through HBM/L2 with agent-scope
- *     (sc1) stores + a per-row progress word.  The maps are identical to the sequential sweep.
- *   - INSIDE A WAVE the 64 lanes are (view group) x (tap segment): lane = view*S + seg.  Each lane warps
- *     and bilinearly samples its ~T*T/S taps of its own source view, partial sums are combined with an
- *     xor butterfly inside the group, the per-view ZNCC epilogue runs lane-parallel over views and the
- *     "two best views" selection is a second butterfly across groups.  No LDS, no block barriers.
- *   - Rows are handed out by an atomic ticket in dependency order, so a waiting wave always waits on a
- *     wave that is already running: no deadlock for any grid size or dispatch order.  Every spin is bounded.
+ *   - ONE PERSISTENT WORKER (NW waves, one workgroup) PER IMAGE ROW.  The reference sweeps pixels sequentially
+ *     (Gauss-Seidel): a pixel must see its left/up neighbours already updated and its right/down neighbours not
+ *     yet updated.  Rows advancing left-to-right with row y one pixel behind row y-1 satisfy exactly that
+ *     dependence, so all rows run concurrently and hand results down through L2 with agent-scope (sc1) stores
+ *     + a per-row progress word.  The maps are identical to the sequential sweep.  The rows of several
+ *     independent reference images share one launch (ticket t -> row t / nItems of item t % nItems) so the ramp
+ *     of one image's wavefront is filled by the others.
+ *   - INSIDE A WAVE the 64 lanes are (view group) x (tap segment): lane = view*S + seg.  A segment owns one
+ *     patch column and walks down its rows; partial sums are combined with DPP butterflies inside the group, the
+ *     per-view ZNCC epilogue runs lane-parallel over views and the "two best views" selection is a second
+ *     butterfly across groups.  Hypothesis generation and the plane-smoothness terms are lane-parallel too.
+ *     LDS holds only the row's own recent results (hist ring) and, for NW > 1, the 32-byte score exchange.
+ *   - Rows are handed out by an atomic ticket in dependency order, so a waiting worker always waits on one
+ *     that is already running: no deadlock for any grid size or dispatch order.  Every spin is bounded.
  *
- * Arithmetic is an explicitly specified IEEE sequence (explicit fmaf, one IEEE reciprocal per tap,
+ * Arithmetic is an explicitly specified IEEE sequence (explicit fmaf, one IEEE reciprocal per four taps,
  * pm_math.h transcendental functions); compile with -ffp-contract=off.
  */
 #include "pm_common.h"
