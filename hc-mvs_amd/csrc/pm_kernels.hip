@@ -76,26 +76,34 @@ __device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, fl
 	return a0 * b0 + a1 * b1 + a2 * b2;
 }
 
+// Every pointer held in an EstConst addresses device global memory.  Where the struct is read from memory (batched
+// sweep) the compiler only sees generic pointers and would emit flat_* instructions with 64-bit VGPR addresses; the
+// explicit global address space keeps them global_* (scalar base + 32-bit offset).
+#define HC_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ HC_GLOBAL T* as_global(T* p) { return (HC_GLOBAL T*)p; }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // agent-scope (sc1) accesses for everything another row's wave may have written in this launch
 __device__ __forceinline__ float4 load_dn(const float4* p) {
-	unsigned long long* q = (unsigned long long*)p;
+	HC_GLOBAL unsigned long long* q = (HC_GLOBAL unsigned long long*)p;
 	const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, HC_SCOPE);
 	const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, HC_SCOPE);
 	return make_float4(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)), __uint_as_float((uint32_t)b),
 	                   __uint_as_float((uint32_t)(b >> 32)));
 }
 __device__ __forceinline__ void store_dn(float4* p, float d, float n0, float n1, float n2) {
-	unsigned long long* q = (unsigned long long*)p;
+	HC_GLOBAL unsigned long long* q = (HC_GLOBAL unsigned long long*)p;
 	__hip_atomic_store(q, (unsigned long long)__float_as_uint(d) | ((unsigned long long)__float_as_uint(n0) << 32),
 	                   __ATOMIC_RELAXED, HC_SCOPE);
 	__hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(n1) | ((unsigned long long)__float_as_uint(n2) << 32),
 	                   __ATOMIC_RELAXED, HC_SCOPE);
 }
 __device__ __forceinline__ float load_f(const float* p) {
-	return __uint_as_float(__hip_atomic_load((uint32_t*)p, __ATOMIC_RELAXED, HC_SCOPE));
+	return __uint_as_float(__hip_atomic_load((HC_GLOBAL uint32_t*)p, __ATOMIC_RELAXED, HC_SCOPE));
 }
 __device__ __forceinline__ void store_f(float* p, float v) {
-	__hip_atomic_store((uint32_t*)p, __float_as_uint(v), __ATOMIC_RELAXED, HC_SCOPE);
+	__hip_atomic_store((HC_GLOBAL uint32_t*)p, __float_as_uint(v), __ATOMIC_RELAXED, HC_SCOPE);
 }
 
 __device__ __forceinline__ float rlf(float v, int lane) { // value of a (wave-uniform index) lane
@@ -149,7 +157,6 @@ struct LaneCtx {
 	unsigned imgOff;  // byte offset of my source view from EstConst::imgBase (all views of a call lie within 4 GiB)
 	int iw, ixmax, iymax; // row pitch in pixels; largest top-left texel column / row of a bilinear footprint
 	float wmax, hmax; // inside-with-border-1 limits of my view
-	float A[9], Hm[3];
 	unsigned long long groupMask;
 };
 
@@ -159,24 +166,113 @@ __device__ __forceinline__ void lane_init(const EstConst& c, LaneCtx<S>& L) {
 	L.view = L.lane / S;
 	L.seg = L.lane % S;
 	L.vact = L.view < c.V;
-	const DevView* dv = &c.views[L.vact ? L.view : 0]; // idle groups mirror view 0 (results masked)
+	const HC_GLOBAL DevView* dv = as_global(c.views) + (L.vact ? L.view : 0); // idle groups mirror view 0 (results masked)
 	L.imgOff = dv->byteOff; L.iw = dv->w; L.ixmax = dv->w - 2; L.iymax = dv->h - 2;
 	L.wmax = (float)(dv->w - 2); L.hmax = (float)(dv->h - 2);
-#pragma unroll
-	for (int i = 0; i < 9; ++i) L.A[i] = dv->A[i];
-#pragma unroll
-	for (int i = 0; i < 3; ++i) L.Hm[i] = dv->Hm[i];
 	L.groupMask = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (L.view * S);
 }
 
 template <int S>
 struct Patch { // DepthMap.h:202-212 WeightedPatchFix, spread over the lanes of a group
 	static constexpr int MAXM = 64 / S;
-	float w[MAXM], tw[MAXM];
-	float py[MAXM];   // image row of the lane's m-th tap
 	float px0;        // image column of the lane's first tap (S >= 8: of all its taps)
 	float sumW, invSumW, normSq0;
 	int x, y, a;
+};
+
+// Where the scorer's per-lane tables live between evaluations: the per-tap arrays of the patch (image row py, weight
+// w, centred weighted reference texel tw; DepthMap.h:202-212) and the homography constants of the lane's view
+// (DepthMap.h:412-444).  The init-score pass keeps them in registers; the sweep parks them in LDS, because there
+// the state of the pixel's hypothesis rounds is live across every evaluation and registers decide the occupancy.
+template <int S>
+struct RegStore {
+	static constexpr int MAXM = 64 / S;
+	float A[9], Hm[3];
+	float py[MAXM], w[MAXM], tw[MAXM];
+	__device__ __forceinline__ void put_view(const HC_GLOBAL DevView* dv, int) {
+#pragma unroll
+		for (int i = 0; i < 9; ++i) A[i] = dv->A[i];
+#pragma unroll
+		for (int i = 0; i < 3; ++i) Hm[i] = dv->Hm[i];
+	}
+	__device__ __forceinline__ void put_patch(const float (&py_)[MAXM], const float (&w_)[MAXM], const float (&tw_)[MAXM]) {
+#pragma unroll
+		for (int m = 0; m < MAXM; ++m) { py[m] = py_[m]; w[m] = w_[m]; tw[m] = tw_[m]; }
+	}
+	__device__ __forceinline__ void get_view(float (&A_)[9], float (&Hm_)[3]) const {
+#pragma unroll
+		for (int i = 0; i < 9; ++i) A_[i] = A[i];
+#pragma unroll
+		for (int i = 0; i < 3; ++i) Hm_[i] = Hm[i];
+	}
+	__device__ __forceinline__ void get_py(float (&o)[MAXM]) const {
+#pragma unroll
+		for (int m = 0; m < MAXM; ++m) o[m] = py[m];
+	}
+	__device__ __forceinline__ void get_w(float (&w_)[MAXM], float (&tw_)[MAXM]) const {
+#pragma unroll
+		for (int m = 0; m < MAXM; ++m) { w_[m] = w[m]; tw_[m] = tw[m]; }
+	}
+};
+template <int S>
+struct WavePark { // LDS of one wave of a row worker
+	static constexpr int MAXM = 64 / S;
+	float4 vh[64 / S][3];     // per view group: A[0..8], Hm[0..2]
+	float pw[3 * MAXM][64];   // py | w | tw, see LdsStore
+	float cl[9][64];          // smoothness neighbours, slot k at [.][k]: X0 X1 X2 | n0 n1 n2 | k0 k1 k2 (see Close)
+};
+template <int S>
+struct LdsStore {
+	static constexpr int MAXM = 64 / S;
+	static constexpr bool V4 = MAXM % 4 == 0; // 16-byte LDS accesses when a lane holds whole groups of four taps
+	WavePark<S>* pk;
+	int lane, view;
+	__device__ __forceinline__ void put_view(const HC_GLOBAL DevView* dv, int seg) {
+		if (seg == 0) {
+			pk->vh[view][0] = make_float4(dv->A[0], dv->A[1], dv->A[2], dv->A[3]);
+			pk->vh[view][1] = make_float4(dv->A[4], dv->A[5], dv->A[6], dv->A[7]);
+			pk->vh[view][2] = make_float4(dv->A[8], dv->Hm[0], dv->Hm[1], dv->Hm[2]);
+		}
+	}
+	__device__ __forceinline__ void put_arr(int base, const float (&v)[MAXM]) {
+		if constexpr (V4) {
+			float4* q = (float4*)&pk->pw[0][0];
+#pragma unroll
+			for (int k = 0; k < MAXM / 4; ++k) q[(base / 4 + k) * 64 + lane] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+		} else {
+#pragma unroll
+			for (int m = 0; m < MAXM; ++m) pk->pw[base + m][lane] = v[m];
+		}
+	}
+	__device__ __forceinline__ void get_arr(int base, int ol, float (&v)[MAXM]) const {
+		if constexpr (V4) {
+			const float4* q = (const float4*)&pk->pw[0][0];
+#pragma unroll
+			for (int k = 0; k < MAXM / 4; ++k) {
+				const float4 t = q[(base / 4 + k) * 64 + ol];
+				v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+			}
+		} else {
+#pragma unroll
+			for (int m = 0; m < MAXM; ++m) v[m] = pk->pw[base + m][ol];
+		}
+	}
+	__device__ __forceinline__ void put_patch(const float (&py_)[MAXM], const float (&w_)[MAXM], const float (&tw_)[MAXM]) {
+		put_arr(0, py_); put_arr(MAXM, w_); put_arr(2 * MAXM, tw_);
+	}
+	// the index is laundered so that the reads stay inside the evaluation (hoisting them would undo the parking)
+	__device__ __forceinline__ int opaque(int v) const { asm volatile("" : "+v"(v)); return v; }
+	__device__ __forceinline__ void get_view(float (&A_)[9], float (&Hm_)[3]) const {
+		const int ov = opaque(view);
+		const float4 a = pk->vh[ov][0], b = pk->vh[ov][1], cc = pk->vh[ov][2];
+		A_[0] = a.x; A_[1] = a.y; A_[2] = a.z; A_[3] = a.w; A_[4] = b.x; A_[5] = b.y; A_[6] = b.z; A_[7] = b.w; A_[8] = cc.x;
+		Hm_[0] = cc.y; Hm_[1] = cc.z; Hm_[2] = cc.w;
+	}
+	__device__ __forceinline__ void get_py(float (&o)[MAXM]) const { get_arr(0, opaque(lane), o); }
+	__device__ __forceinline__ void get_w(float (&w_)[MAXM], float (&tw_)[MAXM]) const {
+		const int ol = opaque(lane);
+		get_arr(MAXM, ol, w_); get_arr(2 * MAXM, ol, tw_);
+	}
 };
 
 // everything one pixel reads from memory; the sweep loads it one pixel ahead (software pipeline)
@@ -240,9 +336,10 @@ __device__ __forceinline__ void load_patch_inputs(const EstConst& c, const LaneC
 
 // DepthMap.cpp:450-519 FillPixelPatch + DepthMap.h:537-548 GetWeight.
 // Lanes whose tap index is past the patch repeat the last tap with zero weights: they add exactly +0.
-template <int S>
-__device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& L, int x, int y, const PixIn<S>& in, Patch<S>& P) {
+template <int S, class ST>
+__device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& L, int x, int y, const PixIn<S>& in, Patch<S>& P, ST& st) {
 	constexpr int MAXM = 64 / S;
+	float Pw[MAXM], Ptw[MAXM], Ppy[MAXM];
 	const int a = patch_halfwin(c, in.tx);
 	const float sigmaColor = -1.f / (2.f * HC_SQ(0.2f));
 	const float sigmaSpatial = -1.f / (2.f * (float)HC_SQ(a));
@@ -251,14 +348,14 @@ __device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& 
 	for (int m = 0; m < MAXM; ++m) {
 		int i, j;
 		const bool valid = tap_offset<S>(a, L.seg, m, i, j);
-		P.py[m] = (float)(y + i);
+		Ppy[m] = (float)(y + i);
 		if (m == 0) P.px0 = (float)(x + j);
 		const float wColor = HC_SQ(in.I[m] - in.center) * sigmaColor;
 		const float wSpatial = (float)(HC_SQ(j) + HC_SQ(i)) * sigmaSpatial;
 		const float w = pm_expf(wColor + wSpatial);
-		P.w[m] = valid ? w : 0.f;
-		sa = fmaf(in.I[m], P.w[m], sa);
-		sb = sb + P.w[m];
+		Pw[m] = valid ? w : 0.f;
+		sa = fmaf(in.I[m], Pw[m], sa);
+		sb = sb + Pw[m];
 	}
 	const float swi = group_sum<S>(sa), sw = group_sum<S>(sb);
 	const float tm = swi / sw;
@@ -266,13 +363,14 @@ __device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& 
 #pragma unroll
 	for (int m = 0; m < MAXM; ++m) {
 		const float t = in.I[m] - tm;
-		P.tw[m] = P.w[m] * t;
-		sa = fmaf(P.tw[m], t, sa);
+		Ptw[m] = Pw[m] * t;
+		sa = fmaf(Ptw[m], t, sa);
 	}
 	P.sumW = sw;
 	P.invSumW = 1.0f / sw;
 	P.normSq0 = group_sum<S>(sa);
 	P.x = x; P.y = y; P.a = a;
+	st.put_patch(Ppy, Pw, Ptw);
 }
 
 // smoothness neighbours (DepthMap.h:376-382 NeighborEstimate): slot k lives in lane k
@@ -294,13 +392,16 @@ struct PixelGeom {
 // hypotheses in ONE instruction stream: the NH evaluations are independent, so writing every phase as a loop over
 // them lets the scheduler overlap one hypothesis' dependent chains and load latency with the other's arithmetic.
 // smoothF: product of the plane-smoothness factors of the hypothesis (DepthMap.cpp:607-615), see smooth_pass().
-template <int S, int NH>
-__device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, float v0, float v1,
+template <int S, int NH, class ST>
+__device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const ST& st, float v0, float v1,
                                             const float (&smoothF)[NH], const float (&depth)[NH], const float (&n0)[NH],
                                             const float (&n1)[NH], const float (&n2)[NH], float (&out)[NH]) {
 	constexpr int MAXM = 64 / S;
 	// homography of my view (DepthMap.h:565-574), association H = A + Hm (Hr^T n)^T / (n.X0 d)
 	float H[NH][9];
+	float vA[9], vHm[3], Ppy[MAXM];
+	st.get_view(vA, vHm);
+	st.get_py(Ppy);
 #pragma unroll
 	for (int h = 0; h < NH; ++h) {
 		const float nx0 = fmaf(n2[h], 1.0f, fmaf(n1[h], v1, n0[h] * v0));
@@ -311,7 +412,7 @@ __device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>&
 #pragma unroll
 		for (int i = 0; i < 3; ++i)
 #pragma unroll
-			for (int j = 0; j < 3; ++j) H[h][i * 3 + j] = fmaf(L.Hm[i], q[j], L.A[i * 3 + j]);
+			for (int j = 0; j < 3; ++j) H[h][i * 3 + j] = fmaf(vHm[i], q[j], vA[i * 3 + j]);
 	}
 	// (1) warp every tap, (2) issue all loads, (3) interpolate + accumulate.  The inside-the-image test
 	// (Types.h:1633-1635) is done once per hypothesis on the min/max of the warped coordinates; texel addresses are
@@ -327,7 +428,7 @@ __device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>&
 		const float bx = fmaf(H[h][0], P.px0, H[h][2]), by = fmaf(H[h][3], P.px0, H[h][5]), bz = fmaf(H[h][6], P.px0, H[h][8]);
 #pragma unroll
 		for (int m = 0; m < MAXM; ++m) {
-			const float py = P.py[m];
+			const float py = Ppy[m];
 			if constexpr (S >= 8) {
 				Xx[m] = fmaf(H[h][1], py, bx); Xy[m] = fmaf(H[h][4], py, by); Xz[m] = fmaf(H[h][7], py, bz);
 			} else { // S == 4: a segment covers two columns
@@ -364,17 +465,17 @@ __device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>&
 		for (int m = 0; m < MAXM; ++m) {
 			const float qx = Xx[m] * iz[m], qy = Xy[m] * iz[m];
 			qxlo = fminf(qxlo, qx); qxhi = fmaxf(qxhi, qx); qylo = fminf(qylo, qy); qyhi = fmaxf(qyhi, qy);
-			int lx = (int)qx, ly = (int)qy;
+			// top-left texel clamped into the image (one v_med3_f32 each; same integer as clamping after the
+			// conversion, and a NaN gives 0)
+			const int lx = (int)__builtin_amdgcn_fmed3f(qx, 0.f, L.wmax), ly = (int)__builtin_amdgcn_fmed3f(qy, 0.f, L.hmax);
 			fx[h][m] = __builtin_amdgcn_fractf(qx);
 			fy[h][m] = __builtin_amdgcn_fractf(qy);
-			lx = max(0, min(lx, L.ixmax));
-			ly = max(0, min(ly, L.iymax));
 			off[h][m] = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 2);
 		}
 		bad[h] = nan || !(qxlo >= 1.f && qylo >= 1.f && qxhi <= L.wmax && qyhi <= L.hmax);
 	}
 	float2 top[NH][MAXM], bot[NH][MAXM];
-	const char* __restrict__ imgBase = c.imgBase;
+	const HC_GLOBAL char* imgBase = as_global(c.imgBase);
 	const unsigned pitch = (unsigned)L.iw << 2;
 #pragma unroll
 	for (int h = 0; h < NH; ++h)
@@ -385,11 +486,15 @@ __device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>&
 			top[h][m] = make_float2(fake, fake * 0.9f);
 			bot[h][m] = make_float2(fake * 0.8f, fake * 0.7f);
 #else
-			top[h][m] = *(const float2*)(imgBase + off[h][m]);
-			bot[h][m] = *(const float2*)(imgBase + (off[h][m] + pitch));
+			const f32x2 tv = *(const HC_GLOBAL f32x2*)(imgBase + off[h][m]);
+			const f32x2 bv = *(const HC_GLOBAL f32x2*)(imgBase + (off[h][m] + pitch));
+			top[h][m] = make_float2(tv.x, tv.y);
+			bot[h][m] = make_float2(bv.x, bv.y);
 #endif
 		}
 	float sum[NH], sumSq[NH], num[NH];
+	float Pw[MAXM], Ptw[MAXM];
+	st.get_w(Pw, Ptw);
 #pragma unroll
 	for (int h = 0; h < NH; ++h) {
 		float a = 0.f, b2 = 0.f, cnum = 0.f;
@@ -399,10 +504,10 @@ __device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>&
 			const float t = fmaf(fx[h][m], top[h][m].y - top[h][m].x, top[h][m].x);
 			const float b = fmaf(fx[h][m], bot[h][m].y - bot[h][m].x, bot[h][m].x);
 			const float val = fmaf(fy[h][m], b - t, t);
-			const float vw = val * P.w[m];
+			const float vw = val * Pw[m];
 			a = a + vw;
 			b2 = fmaf(val, vw, b2);
-			cnum = fmaf(val, P.tw[m], cnum);
+			cnum = fmaf(val, Ptw[m], cnum);
 		}
 		sum[h] = a; sumSq[h] = b2; num[h] = cnum;
 	}
@@ -430,24 +535,24 @@ __device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>&
 #pragma unroll
 	for (int h = 0; h < NH; ++h) out[h] = c.V <= 1 ? m1[h] : (m2[h] >= c.thRobust ? m1[h] : (m1[h] + m2[h]) / 2.f);
 }
-template <int S>
-__device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, float v0, float v1,
+template <int S, class ST>
+__device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const ST& st, float v0, float v1,
                                              float smoothF, float depth, float n0, float n1, float n2) {
 	const float f[1] = {smoothF}, d[1] = {depth}, a0[1] = {n0}, a1[1] = {n1}, a2[1] = {n2};
 	float o[1];
-	score_multi<S, 1>(c, L, P, v0, v1, f, d, a0, a1, a2, o);
+	score_multi<S, 1>(c, L, P, st, v0, v1, f, d, a0, a1, a2, o);
 	return o[0];
 }
 
 // score the hypotheses listed in `idx[0..n)` (indices into the lane-held hypothesis arrays hd/h0/h1/h2, lane t =
 // hypothesis t; smoothness factor of hypothesis idx[i] in lane fLane[i]); lane idx[i] of the result gets the score
-template <int S>
-__device__ __forceinline__ float score_list(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, float v0, float v1, float F,
+template <int S, class ST>
+__device__ __forceinline__ float score_list(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const ST& st, float v0, float v1, float F,
                                             float hd, float h0, float h1, float h2, const int* idx, const int* fLane, int n,
                                             float mine, unsigned& issued) {
 	for (int i = 0; i < n; ++i) {
 		const int ta = idx[i];
-		const float sc = score_pixel<S>(c, L, P, v0, v1, rlf(F, fLane[i]), rlf(hd, ta), rlf(h0, ta), rlf(h1, ta), rlf(h2, ta));
+		const float sc = score_pixel<S>(c, L, P, st, v0, v1, rlf(F, fLane[i]), rlf(hd, ta), rlf(h0, ta), rlf(h1, ta), rlf(h2, ta));
 		++issued;
 		if (L.lane == ta) mine = sc;
 	}
@@ -528,19 +633,20 @@ __device__ __forceinline__ void pixel_geom(const EstConst& c, int x, int y, Pixe
 // (1 - bD e^{sD (dist/d)^2}) (1 - bN e^{sN acos^2}) are multiplied by a butterfly inside each 8-lane group (slots
 // without a neighbour contribute exactly 1), chunk after chunk.  hd..hpd: the lane's own group's hypothesis
 // (depth, normal, plane normal, plane offset); limit: last slot whose corrected normal is already in effect.
-__device__ __forceinline__ float smooth_pass(const EstConst& c, const Close& C, int lane, float hd, float h0, float h1, float h2,
+__device__ __forceinline__ float smooth_pass(const EstConst& c, const float (*cl)[64], unsigned long long closeMask,
+                                             unsigned long long eligMask, int lane, float hd, float h0, float h1, float h2,
                                              float hp0, float hp1, float hp2, float hpd, int limit) {
 	float F = 1.f;
-	if (C.closeMask == 0ull) return F;
-	const int nChunks = (64 - __builtin_clzll(C.closeMask) + 7) >> 3;
+	if (closeMask == 0ull) return F;
+	const int nChunks = (64 - __builtin_clzll(closeMask) + 7) >> 3;
 	const int j = lane & 7;
 	for (int ch = 0; ch < nChunks; ++ch) {
 		const int slot = ch * 8 + j;
-		const float X0 = __shfl(C.X0, slot, 64), X1 = __shfl(C.X1, slot, 64), X2 = __shfl(C.X2, slot, 64);
-		const float o0 = __shfl(C.n0, slot, 64), o1 = __shfl(C.n1, slot, 64), o2 = __shfl(C.n2, slot, 64);
-		const float k0 = __shfl(C.k0, slot, 64), k1 = __shfl(C.k1, slot, 64), k2 = __shfl(C.k2, slot, 64);
-		const bool valid = (C.closeMask >> slot) & 1ull;
-		const bool corr = ((C.eligMask >> slot) & 1ull) && slot <= limit;
+		const float X0 = cl[0][slot], X1 = cl[1][slot], X2 = cl[2][slot];
+		const float o0 = cl[3][slot], o1 = cl[4][slot], o2 = cl[5][slot];
+		const float k0 = cl[6][slot], k1 = cl[7][slot], k2 = cl[8][slot];
+		const bool valid = (closeMask >> slot) & 1ull;
+		const bool corr = ((eligMask >> slot) & 1ull) && slot <= limit;
 		const float c0 = corr ? k0 : o0, c1 = corr ? k1 : o1, c2 = corr ? k2 : o2;
 		const float dist = dot3(hp0, hp1, hp2, X0, X1, X2) + hpd; // Planef::Distance
 		const float fd = pm_expf(HC_SQ(dist / hd) * c.smoothSigmaDepth);
@@ -575,7 +681,7 @@ struct RowShared {
 	int row;
 };
 
-__device__ __forceinline__ int wait_progress(int32_t* word, int need, int32_t* err) {
+__device__ __forceinline__ int wait_progress(HC_GLOBAL int32_t* word, int need, HC_GLOBAL int32_t* err) {
 	int v;
 	unsigned spins = 0;
 	while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, HC_SCOPE)) < need) {
@@ -600,7 +706,7 @@ struct RowPipe {
 	int known;        // columns the previous logical row is known to have finished
 	int poll;         // progress value of an in-flight poll
 	int pendingPub;   // > 0: results up to this column are stored but not yet published
-	int32_t *upWord, *myWord, *err;
+	HC_GLOBAL int32_t *upWord, *myWord, *err;
 	int r, y, ncols;
 	bool rev, fail;
 };
@@ -688,7 +794,7 @@ __device__ __forceinline__ float share_scores(RowShared<NW>& sh, int& par, int l
 template <int S, int NW>
 __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S>& L, RowShared<NW>& sh, int& par, int wv,
                                               int x, int y, int q, int iter, const PixIn<S>& in, const Patch<S>& P,
-                                              RowPipe<S>& pp, unsigned& evals, unsigned& issued STAMP_ARGS) {
+                                              const LdsStore<S>& st, RowPipe<S>& pp, unsigned& evals, unsigned& issued STAMP_ARGS) {
 	const int W = c.W, lane = L.lane;
 	PixelGeom G;
 	pixel_geom(c, x, y, G);
@@ -717,6 +823,13 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		C.kd = interpolate_pixel(c, G, nx, ny, C.d, C.n0, C.n1, C.n2);
 		correct_normal(G, C.k0, C.k1, C.k2);
 	}
+	const unsigned long long closeMask = C.closeMask, eligMask = C.eligMask;
+	{ // park the slots for the smoothness passes (LDS of this wave; same-wave LDS accesses are ordered)
+		float (*cl)[64] = st.pk->cl;
+		cl[0][lane] = C.X0; cl[1][lane] = C.X1; cl[2][lane] = C.X2;
+		cl[3][lane] = C.n0; cl[4][lane] = C.n1; cl[5][lane] = C.n2;
+		cl[6][lane] = C.k0; cl[7][lane] = C.k1; cl[8][lane] = C.k2;
+	}
 
 	const int idx = y * W + x;
 	float conf = in.curConf;
@@ -729,11 +842,11 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 	//   RAND   completely random hypotheses, DepthMap.cpp:1448-1465 (independent of the estimate: a batch is exact)
 	//   REFINE perturbations of the current estimate, DepthMap.cpp:1466-1501 (after an accept the later trials are redone)
 	enum { PH_PROP, PH_PICK, PH_RAND, PH_REFINE, PH_DONE };
-	const int nc = __builtin_popcountll(C.eligMask);
+	const int nc = __builtin_popcountll(eligMask);
 	int candSlot = 0; // lane i <- slot of the i-th candidate
 	{
 		int i = 0;
-		for (unsigned long long mk = C.eligMask; mk; mk &= mk - 1ull, ++i)
+		for (unsigned long long mk = eligMask; mk; mk &= mk - 1ull, ++i)
 			if (lane == i) candSlot = __builtin_ctzll(mk);
 	}
 	// candidate i's estimate, brought from lane candSlot(i) to lane i
@@ -814,7 +927,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 #if defined(HCMVS_ABL) && HCMVS_ABL == 2 /* diagnostic ablation: no smoothness pass */
 			const float F = 1.f + 0.f * (gd + g0 + g1 + g2 + gp0 + gp1 + gp2 + gpd + (float)glimit);
 #else
-			const float F = smooth_pass(c, C, lane, gd, g0, g1, g2, gp0, gp1, gp2, gpd, glimit);
+			const float F = smooth_pass(c, st.pk->cl, closeMask, eligMask, lane, gd, g0, g1, g2, gp0, gp1, gp2, gpd, glimit);
 #endif
 			const int top = base + 8 < hi ? base + 8 : hi;
 			int idxs[8], fl[8], nv = 0;
@@ -822,7 +935,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 				if (!((vmask >> t) & 1ull)) continue;
 				idxs[nv] = t; fl[nv] = (t - base) * 8; ++nv;
 			}
-			mine = score_list<S>(c, L, P, G.v0, G.v1, F, hd, h0, h1, h2, idxs, fl, nv, mine, issued);
+			mine = score_list<S>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, idxs, fl, nv, mine, issued);
 		}
 		STAMP(7)
 		const float all = share_scores<NW>(sh, par, lane, lo, hi, mine);
@@ -890,6 +1003,7 @@ template <int S, int NW>
 __global__ __launch_bounds__(64 * NW) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
                                                         int iter, int lag) {
 	__shared__ RowShared<NW> sh;
+	__shared__ WavePark<S> park[NW];
 	const int wv = threadIdx.x >> 6;
 	const bool rev = (iter & 1) != 0; // dir = RB2LT on odd iterations, DepthMap.cpp:418
 	unsigned evals = 0, issued = 0;
@@ -897,7 +1011,7 @@ __global__ __launch_bounds__(64 * NW) void sweep_kernel(const EstConst* __restri
 	int par = 0;
 	STAMP_DECL
 	RowPipe<S> pp;
-	pp.err = sy.error; pp.rev = rev;
+	pp.err = as_global(sy.error); pp.rev = rev;
 	for (;;) {
 		// rows are handed out in dependency order: whoever holds row r-1 of an image is already running
 		if (NW > 1) __syncthreads(); // everyone is done with the previous row's shared state
@@ -911,40 +1025,43 @@ __global__ __launch_bounds__(64 * NW) void sweep_kernel(const EstConst* __restri
 		if (r >= nrows) continue; // a smaller image of the batch
 		LaneCtx<S> L;
 		lane_init<S>(c, L);
+		LdsStore<S> st;
+		st.pk = &park[wv]; st.lane = L.lane; st.view = L.view;
+		st.put_view(as_global(c.views) + (L.vact ? L.view : 0), L.seg);
 		pp.ncols = ncols;
 		const int y = rev ? c.H - 1 - kHalfWindow - r : kHalfWindow + r;
 		pp.r = r; pp.y = y;
-		pp.upWord = c.progress + (size_t)(r > 0 ? r - 1 : 0) * kProgressStride;
-		pp.myWord = c.progress + (size_t)r * kProgressStride;
+		pp.upWord = as_global(c.progress) + (size_t)(r > 0 ? r - 1 : 0) * kProgressStride;
+		pp.myWord = as_global(c.progress) + (size_t)r * kProgressStride;
 		pp.known = r > 0 ? 0 : 0x7fffffff; // columns the previous logical row has finished
 		pp.poll = 0; pp.pendingPub = 0; pp.fail = false;
 		if (r > 0) {
 			const int need = lag < ncols ? lag : ncols;
-			pp.known = wait_progress(pp.upWord, need, sy.error);
+			pp.known = wait_progress(pp.upWord, need, pp.err);
 			pp.fail = pp.known < 0;
 		}
 		const int x0 = rev ? c.W - 1 - kHalfWindow : kHalfWindow;
-		pp.tx1 = c.gra[y * c.W + x0];
+		pp.tx1 = as_global(c.gra)[y * c.W + x0];
 		for (int q = 0; q < ncols && !pp.fail; ++q) {
 			const int x = rev ? c.W - 1 - kHalfWindow - q : kHalfWindow + q;
 			// all loads of this pixel that do not depend on other rows go out in one batch ...
 			PixIn<S> in;
 			in.tx = (float)pp.tx1;
 			prefetch_static<S>(c, L, x, y, q, rev, in);
-			if (q + 1 < ncols) pp.tx1 = c.gra[y * c.W + (rev ? x - 1 : x + 1)];
+			if (q + 1 < ncols) pp.tx1 = as_global(c.gra)[y * c.W + (rev ? x - 1 : x + 1)];
 			if (pp.known >= q + 1) prefetch_up<S>(c, in);
 			// ... and the patch weights are computed while they (and the previous row) arrive
 			Patch<S> P;
-			fill_patch<S>(c, L, x, y, in, P);
+			fill_patch<S>(c, L, x, y, in, P, st);
 			STAMP(1)
 			if (pp.known < q + 1) { // the previous row must have finished this column
-				pp.known = wait_progress(pp.upWord, q + 1, sy.error);
+				pp.known = wait_progress(pp.upWord, q + 1, pp.err);
 				if (pp.known < 0) { pp.fail = true; break; }
 				prefetch_up<S>(c, in);
 			}
 			STAMP(0)
 			const unsigned e0 = evals;
-			process_pixel<S, NW>(c, L, sh, par, wv, x, y, q, iter, in, P, pp, evals, issued STAMP_PASS);
+			process_pixel<S, NW>(c, L, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
 			taps += (unsigned long long)(evals - e0) * (unsigned)((P.a + 1) * (P.a + 1));
 		}
 		if (pp.fail) break;
@@ -984,22 +1101,24 @@ template <int S>
 __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long long* evalsOut) {
 	LaneCtx<S> L;
 	lane_init<S>(c, L);
+	RegStore<S> st;
+	st.put_view(as_global(c.views) + (L.vact ? L.view : 0), L.seg);
 	const int nrows = c.H - 2 * kHalfWindow, ncols = c.W - 2 * kHalfWindow;
 	const int total = nrows * ncols;
 	const int wavesPerBlock = blockDim.x >> 6;
 	const int gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), nw = gridDim.x * wavesPerBlock;
 	unsigned evals = 0;
 	unsigned long long taps = 0;
-	const uint32_t st = (uint32_t)c.itExternal * 64u;
+	const uint32_t stream0 = (uint32_t)c.itExternal * 64u;
 	for (int p = gw; p < total; p += nw) {
 		const int x = kHalfWindow + p % ncols, y = kHalfWindow + p / ncols;
 		const int idx = y * c.W + x;
-		const uint32_t rk = rand_key(c.seed, (uint32_t)idx, st);
+		const uint32_t rk = rand_key(c.seed, (uint32_t)idx, stream0);
 		PixIn<S> in;
 		in.tx = (float)c.gra[idx];
 		load_patch_inputs<S>(c, L, x, y, in);
 		Patch<S> P;
-		fill_patch<S>(c, L, x, y, in, P);
+		fill_patch<S>(c, L, x, y, in, P, st);
 		PixelGeom G;
 		pixel_geom(c, x, y, G);
 		const float4 cur = c.dn[idx];
@@ -1010,7 +1129,7 @@ __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long lo
 		} else if (dot3(n0, n1, n2, G.v0, G.v1, 1.f) >= 0.f) {
 			random_normal(G, rand_unit(rk, 1u), rand_unit(rk, 2u), n0, n1, n2);
 		}
-		const float s = score_pixel<S>(c, L, P, G.v0, G.v1, 1.f, d, n0, n1, n2);
+		const float s = score_pixel<S>(c, L, P, st, G.v0, G.v1, 1.f, d, n0, n1, n2);
 		++evals;
 		taps += (unsigned)((P.a + 1) * (P.a + 1));
 		if (L.lane == 0) {
@@ -1028,24 +1147,28 @@ __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long lo
 #ifdef HCMVS_COUNT
 // instruction-count probes (never built into the library): the scorer and the smoothness pass in isolation
 template <int S>
-__global__ void probe_score_kernel(EstConst c, Patch<S> P, float F, float d, float n0, float n1, float n2, float* out) {
+__global__ void probe_score_kernel(EstConst c, Patch<S> P, RegStore<S> st, float F, float d, float n0, float n1, float n2, float* out) {
 	LaneCtx<S> L;
 	lane_init<S>(c, L);
-	out[threadIdx.x] = score_pixel<S>(c, L, P, 0.1f, 0.2f, F, d, n0, n1, n2);
+	out[threadIdx.x] = score_pixel<S>(c, L, P, st, 0.1f, 0.2f, F, d, n0, n1, n2);
 }
-template __global__ void probe_score_kernel<8>(EstConst, Patch<8>, float, float, float, float, float, float*);
+template __global__ void probe_score_kernel<8>(EstConst, Patch<8>, RegStore<8>, float, float, float, float, float, float*);
 __global__ void probe_smooth_kernel(EstConst c, Close C, float* out) {
-	out[threadIdx.x] = smooth_pass(c, C, threadIdx.x & 63, out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], 63);
+	__shared__ float cl[9][64];
+	for (int k = 0; k < 9; ++k) cl[k][threadIdx.x & 63] = out[k * 64 + threadIdx.x];
+	out[threadIdx.x] = smooth_pass(c, cl, C.closeMask, C.eligMask, threadIdx.x & 63, out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], 63);
 }
 template <int S>
-__global__ void probe_patch_kernel(EstConst c, PixIn<S> in, Patch<S>* out) {
+__global__ void probe_patch_kernel(EstConst c, PixIn<S> in, Patch<S>* out, RegStore<S>* so) {
 	LaneCtx<S> L;
 	lane_init<S>(c, L);
 	Patch<S> P;
-	fill_patch<S>(c, L, 100, 100, in, P);
+	RegStore<S> st;
+	fill_patch<S>(c, L, 100, 100, in, P, st);
 	out[threadIdx.x] = P;
+	so[threadIdx.x] = st;
 }
-template __global__ void probe_patch_kernel<8>(EstConst, PixIn<8>, Patch<8>*);
+template __global__ void probe_patch_kernel<8>(EstConst, PixIn<8>, Patch<8>*, RegStore<8>*);
 #endif
 
 // SceneDensify.cpp:688-744 EndDepthMapTmp (finalPass) or plain export of the working state
