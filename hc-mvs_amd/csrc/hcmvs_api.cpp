@@ -22,7 +22,7 @@ using namespace hcmvs;
 
 namespace {
 
-constexpr int kMaxBatch = 16; // reference images estimated by one call
+constexpr int kMaxBatch = 32; // reference images estimated by one call
 
 struct View {
 	int w = 0, h = 0;
@@ -63,12 +63,13 @@ struct hcmvs_ctx {
 	std::vector<DevView> hViews;          // host copy handed to hipMemcpyAsync (must outlive the call)
 	EstConst* dItems = nullptr;           // [kMaxBatch]
 	std::vector<EstConst> hItems;
-	int32_t* sync = nullptr;              // [ticket, error, pad...]
+	int32_t* sync = nullptr;              // [0] unused, [1] error word, [16 .. 16 + kMaxBatch) row tickets of the batch items
 	unsigned long long* evals = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	int lastSweeps = 0;
 	bool haveStats = false;
 	int sweepLag = 1;
+	int xcdAffinity = 1; // rows of an image prefer the workgroups of one XCD (HCMVS_XCD_AFFINITY=0 turns it off)
 	// filter / fuse scratch
 	DevMap* dMaps = nullptr; size_t capMaps = 0;
 	unsigned long long* counters = nullptr;
@@ -170,12 +171,14 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 		if (hipEventCreate(&e) != hipSuccess) { delete c; return HCMVS_ERR_NO_DEVICE; }
 	c->hViews.resize((size_t)kMaxBatch * kMaxViews); c->hItems.resize(kMaxBatch);
 	if (hipMalloc(&c->dViews, sizeof(DevView) * kMaxViews * kMaxBatch) != hipSuccess || hipMalloc(&c->evals, 32) != hipSuccess ||
-	    hipMalloc(&c->dItems, sizeof(EstConst) * kMaxBatch) != hipSuccess || hipMalloc(&c->sync, 64) != hipSuccess) {
+	    hipMalloc(&c->dItems, sizeof(EstConst) * kMaxBatch) != hipSuccess || hipMalloc(&c->sync, 256) != hipSuccess) {
 		delete c;
 		return HCMVS_ERR_NO_DEVICE;
 	}
 	const char* lag = getenv("HCMVS_SWEEP_LAG");
 	if (lag && atoi(lag) >= 1) c->sweepLag = atoi(lag);
+	const char* aff = getenv("HCMVS_XCD_AFFINITY");
+	if (aff) c->xcdAffinity = atoi(aff) != 0;
 	const char* wpr = getenv("HCMVS_WAVES_PER_ROW"); // tuning knob: 1, 2, 3 or 4 waves cooperate on one image row
 	if (wpr && (atoi(wpr) == 1 || atoi(wpr) == 2 || atoi(wpr) == 3 || atoi(wpr) == 4)) c->wavesPerRow = atoi(wpr);
 	*out = c;
@@ -438,7 +441,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 	HIPCHK(c, hipMemcpyAsync(c->dViews, c->hViews.data(), sizeof(DevView) * kMaxViews * n_items, hipMemcpyHostToDevice, s));
 	HIPCHK(c, hipMemcpyAsync(c->dItems, c->hItems.data(), sizeof(EstConst) * n_items, hipMemcpyHostToDevice, s));
 	HIPCHK(c, hipMemsetAsync(c->evals, 0, 32, s));
-	HIPCHK(c, hipMemsetAsync(c->sync, 0, 64, s));
+	HIPCHK(c, hipMemsetAsync(c->sync, 0, 256, s));
 
 	HIPCHK(c, hipEventRecord(c->ev[0], s));
 	for (int i = 0; i < n_items; ++i) {
@@ -452,13 +455,13 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 	}
 	HIPCHK(c, hipEventRecord(c->ev[1], s));
 	SweepSync sy;
-	sy.ticket = c->sync; sy.error = c->sync + 1; sy.evals = c->evals;
+	sy.ticket = c->sync + 16; sy.error = c->sync + 1; sy.evals = c->evals;
 	for (int iter = 0; iter < p->n_estimation_iters; ++iter) {
-		HIPCHK(c, hipMemsetAsync(c->sync, 0, 4, s)); // the ticket; the error word stays sticky
+		HIPCHK(c, hipMemsetAsync(c->sync + 16, 0, sizeof(int32_t) * kMaxBatch, s)); // the tickets; the error word stays sticky
 		for (int i = 0; i < n_items; ++i)
 			HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * kHalfWindow) * kProgressStride * sizeof(int32_t), s));
 		launch_sweep(c->dItems, n_items, maxRows, totalRows, items[0].n_src, sy, iter, c->sweepLag,
-		             c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : 2), s);
+		             c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : 2), c->xcdAffinity, s);
 	}
 	HIPCHK(c, hipEventRecord(c->ev[2], s));
 	for (int i = 0; i < n_items; ++i)

@@ -45,7 +45,7 @@ struct EstConst {
 };
 
 struct SweepSync {
-	int32_t* ticket;   // next (row, image) pair to hand out
+	int32_t* ticket;   // [kMaxBatch] next row of every image of the batch
 	int32_t* error;    // set non-zero when a worker times out
 	unsigned long long* evals;  // [0] ScorePixel calls of the sequential algorithm, [1] evaluations issued (incl. speculative), [2] patch taps of [0]
 };
@@ -58,7 +58,7 @@ void launch_median3(const float* in, float* out, int W, int H, hipStream_t s);
 void launch_score_pass(const EstConst& c, const float* depthIn, const float* normalIn, unsigned long long* evals,
                        hipStream_t s);
 void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int lag,
-                  int wavesPerRow, hipStream_t s);
+                  int wavesPerRow, int affinity, hipStream_t s);
 void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s);
 
 } // namespace hcmvs

@@ -31,6 +31,7 @@
 #include "pm_math.h"
 
 #include <float.h>
+#include <type_traits>
 
 namespace hcmvs {
 
@@ -144,6 +145,18 @@ __device__ __forceinline__ void min2_across(float& m1, float& m2) {
 	}
 }
 
+// the same inside aligned groups of NV lanes (one lane per view)
+template <int NV, int STEP = 1>
+__device__ __forceinline__ void min2_group(float& m1, float& m2) {
+	if constexpr (STEP < NV) {
+		const float o1 = lane_xor<STEP>(m1), o2 = lane_xor<STEP>(m2);
+		const float lo = fminf(m1, o1), hi = fmaxf(m1, o1);
+		m2 = fminf(hi, fminf(m2, o2));
+		m1 = lo;
+		min2_group<NV, STEP * 2>(m1, m2);
+	}
+}
+
 // ------------------------------------------------------------------------------------------------------
 // per-lane context
 
@@ -219,7 +232,9 @@ struct WavePark { // LDS of one wave of a row worker
 	static constexpr int MAXM = 64 / S;
 	float4 vh[64 / S][3];     // per view group: A[0..8], Hm[0..2]
 	float pw[3 * MAXM][64];   // py | w | tw, see LdsStore
-	float cl[9][64];          // smoothness neighbours, slot k at [.][k]: X0 X1 X2 | n0 n1 n2 | k0 k1 k2 (see Close)
+	float cl[9][kMaxSlots];   // smoothness neighbours, slot k at [.][k]: X0 X1 X2 | n0 n1 n2 | k0 k1 k2 (see Close)
+	float4 hl[8][64 / S][3];  // homographies of the (hypothesis, view) pairs of the current chunk of eight hypotheses
+	float4 acc[8][64 / S];    // their ZNCC sums: sum, sumSq, num, 1 if a tap left the image
 };
 template <int S>
 struct LdsStore {
@@ -336,11 +351,12 @@ __device__ __forceinline__ void load_patch_inputs(const EstConst& c, const LaneC
 
 // DepthMap.cpp:450-519 FillPixelPatch + DepthMap.h:537-548 GetWeight.
 // Lanes whose tap index is past the patch repeat the last tap with zero weights: they add exactly +0.
-template <int S, class ST>
-__device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& L, int x, int y, const PixIn<S>& in, Patch<S>& P, ST& st) {
+// NR: steps of a lane that can carry a tap (S == 8: the a + 1 rows of the patch; otherwise all 64 / S); the steps
+// past NR are such zero-weight repeats in every lane, so their arithmetic is skipped -- the sums are the same bits.
+template <int S, int NR, class ST>
+__device__ __forceinline__ void fill_patch_n(const EstConst& c, const LaneCtx<S>& L, int x, int y, int a, const PixIn<S>& in, Patch<S>& P, ST& st) {
 	constexpr int MAXM = 64 / S;
 	float Pw[MAXM], Ptw[MAXM], Ppy[MAXM];
-	const int a = patch_halfwin(c, in.tx);
 	const float sigmaColor = -1.f / (2.f * HC_SQ(0.2f));
 	const float sigmaSpatial = -1.f / (2.f * (float)HC_SQ(a));
 	float sa = 0.f, sb = 0.f;
@@ -350,6 +366,7 @@ __device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& 
 		const bool valid = tap_offset<S>(a, L.seg, m, i, j);
 		Ppy[m] = (float)(y + i);
 		if (m == 0) P.px0 = (float)(x + j);
+		if (m >= NR) { Pw[m] = 0.f; continue; }
 		const float wColor = HC_SQ(in.I[m] - in.center) * sigmaColor;
 		const float wSpatial = (float)(HC_SQ(j) + HC_SQ(i)) * sigmaSpatial;
 		const float w = pm_expf(wColor + wSpatial);
@@ -362,6 +379,7 @@ __device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& 
 	sa = 0.f;
 #pragma unroll
 	for (int m = 0; m < MAXM; ++m) {
+		if (m >= NR) { Ptw[m] = 0.f; continue; }
 		const float t = in.I[m] - tm;
 		Ptw[m] = Pw[m] * t;
 		sa = fmaf(Ptw[m], t, sa);
@@ -371,6 +389,17 @@ __device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& 
 	P.normSq0 = group_sum<S>(sa);
 	P.x = x; P.y = y; P.a = a;
 	st.put_patch(Ppy, Pw, Ptw);
+}
+template <int S, class ST>
+__device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& L, int x, int y, const PixIn<S>& in, Patch<S>& P, ST& st) {
+	const int a = patch_halfwin(c, in.tx);
+	if constexpr (S == 8) {
+		if (a == 6) fill_patch_n<S, 7>(c, L, x, y, a, in, P, st);
+		else if (a == 5) fill_patch_n<S, 6>(c, L, x, y, a, in, P, st);
+		else fill_patch_n<S, 8>(c, L, x, y, a, in, P, st);
+	} else {
+		fill_patch_n<S, 64 / S>(c, L, x, y, a, in, P, st);
+	}
 }
 
 // smoothness neighbours (DepthMap.h:376-382 NeighborEstimate): slot k lives in lane k
@@ -392,52 +421,53 @@ struct PixelGeom {
 // hypotheses in ONE instruction stream: the NH evaluations are independent, so writing every phase as a loop over
 // them lets the scheduler overlap one hypothesis' dependent chains and load latency with the other's arithmetic.
 // smoothF: product of the plane-smoothness factors of the hypothesis (DepthMap.cpp:607-615), see smooth_pass().
-template <int S, int NH, class ST>
-__device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const ST& st, float v0, float v1,
-                                            const float (&smoothF)[NH], const float (&depth)[NH], const float (&n0)[NH],
-                                            const float (&n1)[NH], const float (&n2)[NH], float (&out)[NH]) {
-	constexpr int MAXM = 64 / S;
-	// homography of my view (DepthMap.h:565-574), association H = A + Hm (Hr^T n)^T / (n.X0 d)
-	float H[NH][9];
-	float vA[9], vHm[3], Ppy[MAXM];
-	st.get_view(vA, vHm);
+// homography of one (hypothesis, view) pair (DepthMap.h:565-574), association H = A + Hm (Hr^T n)^T / (n.X0 d)
+__device__ __forceinline__ void make_homography(const EstConst& c, const float (&vA)[9], const float (&vHm)[3], float v0, float v1,
+                                                float depth, float n0, float n1, float n2, float (&H)[9]) {
+	const float nx0 = fmaf(n2, 1.0f, fmaf(n1, v1, n0 * v0));
+	const float inv = 1.0f / (nx0 * depth);
+	float q[3];
+#pragma unroll
+	for (int j = 0; j < 3; ++j) q[j] = fmaf(n2, c.Hr[6 + j], fmaf(n1, c.Hr[3 + j], n0 * c.Hr[j])) * inv;
+#pragma unroll
+	for (int i = 0; i < 3; ++i)
+#pragma unroll
+		for (int j = 0; j < 3; ++j) H[i * 3 + j] = fmaf(vHm[i], q[j], vA[i * 3 + j]);
+}
+
+// DepthMap.cpp:522-606 ScorePixelImage up to the ZNCC sums, all views at once: every lane warps and samples its taps of
+// its own view through H (the homography of the lane's view), the partial sums are combined inside the view group.
+// (1) warp every tap, (2) issue all loads, (3) interpolate + accumulate.  The inside-the-image test (Types.h:1633-1635)
+// is done once on the min/max of the warped coordinates; texel addresses are clamped into the image, so taps that fall
+// outside read valid memory and only raise `viewBad`.
+// NR: as in fill_patch_n -- steps >= NR are zero-weight repeats of step NR - 1 in every lane and are skipped; the grouped
+// reciprocal still multiplies the repeated denominators, so every remaining tap gets the same bits as with all steps.
+template <int S, int NR, class ST>
+__device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const ST& st, const float (&H)[9],
+                                           float& sum, float& sumSq, float& num, bool& viewBad) {
+	constexpr int MAXM = NR;
+	float Ppy[64 / S];
 	st.get_py(Ppy);
-#pragma unroll
-	for (int h = 0; h < NH; ++h) {
-		const float nx0 = fmaf(n2[h], 1.0f, fmaf(n1[h], v1, n0[h] * v0));
-		const float inv = 1.0f / (nx0 * depth[h]);
-		float q[3];
-#pragma unroll
-		for (int j = 0; j < 3; ++j) q[j] = fmaf(n2[h], c.Hr[6 + j], fmaf(n1[h], c.Hr[3 + j], n0[h] * c.Hr[j])) * inv;
-#pragma unroll
-		for (int i = 0; i < 3; ++i)
-#pragma unroll
-			for (int j = 0; j < 3; ++j) H[h][i * 3 + j] = fmaf(vHm[i], q[j], vA[i * 3 + j]);
-	}
-	// (1) warp every tap, (2) issue all loads, (3) interpolate + accumulate.  The inside-the-image test
-	// (Types.h:1633-1635) is done once per hypothesis on the min/max of the warped coordinates; texel addresses are
-	// clamped into the image, so taps that fall outside read valid memory and only raise `bad`.
-	float fx[NH][MAXM], fy[NH][MAXM];
-	unsigned off[NH][MAXM];
-	bool bad[NH];
-#pragma unroll
-	for (int h = 0; h < NH; ++h) {
+	float fx[MAXM], fy[MAXM];
+	unsigned off[MAXM];
+	bool bad;
+	{
 		float Xx[MAXM], Xy[MAXM], Xz[MAXM], iz[MAXM];
 		// a segment walks down one patch column: the column term of the warp is hoisted (S >= 8).  Steps past the
 		// patch repeat the last row (zero weights), so they change neither the sums nor the inside test.
-		const float bx = fmaf(H[h][0], P.px0, H[h][2]), by = fmaf(H[h][3], P.px0, H[h][5]), bz = fmaf(H[h][6], P.px0, H[h][8]);
+		const float bx = fmaf(H[0], P.px0, H[2]), by = fmaf(H[3], P.px0, H[5]), bz = fmaf(H[6], P.px0, H[8]);
 #pragma unroll
 		for (int m = 0; m < MAXM; ++m) {
 			const float py = Ppy[m];
 			if constexpr (S >= 8) {
-				Xx[m] = fmaf(H[h][1], py, bx); Xy[m] = fmaf(H[h][4], py, by); Xz[m] = fmaf(H[h][7], py, bz);
+				Xx[m] = fmaf(H[1], py, bx); Xy[m] = fmaf(H[4], py, by); Xz[m] = fmaf(H[7], py, bz);
 			} else { // S == 4: a segment covers two columns
 				int ti, tj;
 				tap_offset<S>(P.a, L.seg, m, ti, tj);
 				const float px = (float)(P.x + tj);
-				Xx[m] = fmaf(H[h][1], py, fmaf(H[h][0], px, H[h][2]));
-				Xy[m] = fmaf(H[h][4], py, fmaf(H[h][3], px, H[h][5]));
-				Xz[m] = fmaf(H[h][7], py, fmaf(H[h][6], px, H[h][8]));
+				Xx[m] = fmaf(H[1], py, fmaf(H[0], px, H[2]));
+				Xy[m] = fmaf(H[4], py, fmaf(H[3], px, H[5]));
+				Xz[m] = fmaf(H[7], py, fmaf(H[6], px, H[8]));
 			}
 		}
 		bool nan = false;
@@ -445,12 +475,16 @@ __device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>&
 		if constexpr (MAXM >= 4) {
 #pragma unroll
 			for (int g = 0; g < MAXM; g += 4) {
-				const float p01 = Xz[g] * Xz[g + 1], p23 = Xz[g + 2] * Xz[g + 3];
+				constexpr int last = MAXM - 1;
+				const int i1 = g + 1 < last ? g + 1 : last, i2 = g + 2 < last ? g + 2 : last, i3 = g + 3 < last ? g + 3 : last;
+				const float p01 = Xz[g] * Xz[i1], p23 = Xz[i2] * Xz[i3];
 				const float r = 1.0f / (p01 * p23);
 				nan = nan || !(fabsf(r) < __builtin_huge_valf()); // a zero / non-finite denominator poisons the group
 				const float r01 = r * p23, r23 = r * p01;
-				iz[g] = r01 * Xz[g + 1]; iz[g + 1] = r01 * Xz[g];
-				iz[g + 2] = r23 * Xz[g + 3]; iz[g + 3] = r23 * Xz[g + 2];
+				iz[g] = r01 * Xz[i1];
+				if (g + 1 <= last) iz[g + 1] = r01 * Xz[g];
+				if (g + 2 <= last) iz[g + 2] = r23 * Xz[i3];
+				if (g + 3 <= last) iz[g + 3] = r23 * Xz[i2];
 			}
 		} else if constexpr (MAXM == 2) {
 			const float r = 1.0f / (Xz[0] * Xz[1]);
@@ -468,93 +502,157 @@ __device__ __forceinline__ void score_multi(const EstConst& c, const LaneCtx<S>&
 			// top-left texel clamped into the image (one v_med3_f32 each; same integer as clamping after the
 			// conversion, and a NaN gives 0)
 			const int lx = (int)__builtin_amdgcn_fmed3f(qx, 0.f, L.wmax), ly = (int)__builtin_amdgcn_fmed3f(qy, 0.f, L.hmax);
-			fx[h][m] = __builtin_amdgcn_fractf(qx);
-			fy[h][m] = __builtin_amdgcn_fractf(qy);
-			off[h][m] = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 2);
+			fx[m] = __builtin_amdgcn_fractf(qx);
+			fy[m] = __builtin_amdgcn_fractf(qy);
+			off[m] = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 2);
 		}
-		bad[h] = nan || !(qxlo >= 1.f && qylo >= 1.f && qxhi <= L.wmax && qyhi <= L.hmax);
+		bad = nan || !(qxlo >= 1.f && qylo >= 1.f && qxhi <= L.wmax && qyhi <= L.hmax);
 	}
-	float2 top[NH][MAXM], bot[NH][MAXM];
+	float2 top[MAXM], bot[MAXM];
 	const HC_GLOBAL char* imgBase = as_global(c.imgBase);
 	const unsigned pitch = (unsigned)L.iw << 2;
 #pragma unroll
-	for (int h = 0; h < NH; ++h)
-#pragma unroll
-		for (int m = 0; m < MAXM; ++m) {
+	for (int m = 0; m < MAXM; ++m) {
 #if defined(HCMVS_ABL) && HCMVS_ABL == 1 /* diagnostic ablation: no gather loads (results are wrong) */
-			const float fake = (float)(off[h][m] & 255u) * (1.f / 255.f);
-			top[h][m] = make_float2(fake, fake * 0.9f);
-			bot[h][m] = make_float2(fake * 0.8f, fake * 0.7f);
+		const float fake = (float)(off[m] & 255u) * (1.f / 255.f);
+		top[m] = make_float2(fake, fake * 0.9f);
+		bot[m] = make_float2(fake * 0.8f, fake * 0.7f);
 #else
-			const f32x2 tv = *(const HC_GLOBAL f32x2*)(imgBase + off[h][m]);
-			const f32x2 bv = *(const HC_GLOBAL f32x2*)(imgBase + (off[h][m] + pitch));
-			top[h][m] = make_float2(tv.x, tv.y);
-			bot[h][m] = make_float2(bv.x, bv.y);
+		const f32x2 tv = *(const HC_GLOBAL f32x2*)(imgBase + off[m]);
+		const f32x2 bv = *(const HC_GLOBAL f32x2*)(imgBase + (off[m] + pitch));
+		top[m] = make_float2(tv.x, tv.y);
+		bot[m] = make_float2(bv.x, bv.y);
 #endif
-		}
-	float sum[NH], sumSq[NH], num[NH];
-	float Pw[MAXM], Ptw[MAXM];
+	}
+	float Pw[64 / S], Ptw[64 / S];
 	st.get_w(Pw, Ptw);
+	float a = 0.f, b2 = 0.f, cnum = 0.f;
 #pragma unroll
-	for (int h = 0; h < NH; ++h) {
-		float a = 0.f, b2 = 0.f, cnum = 0.f;
-#pragma unroll
-		for (int m = 0; m < MAXM; ++m) {
-			// bilinear sample (Types.inl:2250-2258) in lerp form
-			const float t = fmaf(fx[h][m], top[h][m].y - top[h][m].x, top[h][m].x);
-			const float b = fmaf(fx[h][m], bot[h][m].y - bot[h][m].x, bot[h][m].x);
-			const float val = fmaf(fy[h][m], b - t, t);
-			const float vw = val * Pw[m];
-			a = a + vw;
-			b2 = fmaf(val, vw, b2);
-			cnum = fmaf(val, Ptw[m], cnum);
-		}
-		sum[h] = a; sumSq[h] = b2; num[h] = cnum;
+	for (int m = 0; m < MAXM; ++m) {
+		// bilinear sample (Types.inl:2250-2258) in lerp form
+		const float t = fmaf(fx[m], top[m].y - top[m].x, top[m].x);
+		const float b = fmaf(fx[m], bot[m].y - bot[m].x, bot[m].x);
+		const float val = fmaf(fy[m], b - t, t);
+		const float vw = val * Pw[m];
+		a = a + vw;
+		b2 = fmaf(val, vw, b2);
+		cnum = fmaf(val, Ptw[m], cnum);
 	}
-	bool viewBad[NH];
-#pragma unroll
-	for (int h = 0; h < NH; ++h) {
-		viewBad[h] = (__ballot(bad[h]) & L.groupMask) != 0ull;
-		sum[h] = group_sum<S>(sum[h]); sumSq[h] = group_sum<S>(sumSq[h]); num[h] = group_sum<S>(num[h]);
-	}
-	float m1[NH], m2[NH];
-#pragma unroll
-	for (int h = 0; h < NH; ++h) {
-		const float normSq1 = sumSq[h] - HC_SQ(sum[h]) * P.invSumW;
-		const float nrmSq = P.normSq0 * normSq1;
-		float ncc = num[h] / sqrtf(nrmSq);
-		ncc = ncc < -1.f ? -1.f : (ncc > 1.f ? 1.f : ncc);
-		float s = (1.f - ncc) * smoothF[h];
-		s = c.pfScale * s;
-		if (viewBad[h] || !(nrmSq > 0.f)) s = c.thRobust;
-		m1[h] = L.vact ? s : __builtin_huge_valf();
-		m2[h] = __builtin_huge_valf();
-	}
-#pragma unroll
-	for (int h = 0; h < NH; ++h) min2_across<S>(m1[h], m2[h]);
-#pragma unroll
-	for (int h = 0; h < NH; ++h) out[h] = c.V <= 1 ? m1[h] : (m2[h] >= c.thRobust ? m1[h] : (m1[h] + m2[h]) / 2.f);
+	viewBad = (__ballot(bad) & L.groupMask) != 0ull;
+	sum = group_sum<S>(a); sumSq = group_sum<S>(b2); num = group_sum<S>(cnum);
 }
+
+// DepthMap.cpp:597-615, 890-893: score of one view from its ZNCC sums, times the smoothness factor of the hypothesis
+__device__ __forceinline__ float view_score(const EstConst& c, float sum, float sumSq, float num, bool viewBad, float invSumW,
+                                            float normSq0, float smoothF) {
+	const float normSq1 = sumSq - HC_SQ(sum) * invSumW;
+	const float nrmSq = normSq0 * normSq1;
+	float ncc = num / sqrtf(nrmSq);
+	ncc = ncc < -1.f ? -1.f : (ncc > 1.f ? 1.f : ncc);
+	float s = (1.f - ncc) * smoothF;
+	s = c.pfScale * s;
+	if (viewBad || !(nrmSq > 0.f)) s = c.thRobust;
+	return s;
+}
+// DepthMap.cpp:987-1046 ScorePixel: mean of the two best views (m1 <= m2 are the two smallest view scores)
+__device__ __forceinline__ float two_best(const EstConst& c, float m1, float m2) {
+	return c.V <= 1 ? m1 : (m2 >= c.thRobust ? m1 : (m1 + m2) / 2.f);
+}
+
+// one hypothesis, everything in one go (init-score pass)
 template <int S, class ST>
 __device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const ST& st, float v0, float v1,
                                              float smoothF, float depth, float n0, float n1, float n2) {
-	const float f[1] = {smoothF}, d[1] = {depth}, a0[1] = {n0}, a1[1] = {n1}, a2[1] = {n2};
-	float o[1];
-	score_multi<S, 1>(c, L, P, st, v0, v1, f, d, a0, a1, a2, o);
-	return o[0];
+	float vA[9], vHm[3], H[9];
+	st.get_view(vA, vHm);
+	make_homography(c, vA, vHm, v0, v1, depth, n0, n1, n2, H);
+	float sum, sumSq, num;
+	bool viewBad;
+	if constexpr (S == 8) {
+		if (P.a == 6) score_taps<S, 7>(c, L, P, st, H, sum, sumSq, num, viewBad);
+		else if (P.a == 5) score_taps<S, 6>(c, L, P, st, H, sum, sumSq, num, viewBad);
+		else score_taps<S, 8>(c, L, P, st, H, sum, sumSq, num, viewBad);
+	} else {
+		score_taps<S, 64 / S>(c, L, P, st, H, sum, sumSq, num, viewBad);
+	}
+	const float s = view_score(c, sum, sumSq, num, viewBad, P.invSumW, P.normSq0, smoothF);
+	float m1 = L.vact ? s : __builtin_huge_valf(), m2 = __builtin_huge_valf();
+	min2_across<S>(m1, m2);
+	return two_best(c, m1, m2);
 }
 
-// score the hypotheses listed in `idx[0..n)` (indices into the lane-held hypothesis arrays hd/h0/h1/h2, lane t =
-// hypothesis t; smoothness factor of hypothesis idx[i] in lane fLane[i]); lane idx[i] of the result gets the score
-template <int S, class ST>
-__device__ __forceinline__ float score_list(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const ST& st, float v0, float v1, float F,
-                                            float hd, float h0, float h1, float h2, const int* idx, const int* fLane, int n,
-                                            float mine, unsigned& issued) {
-	for (int i = 0; i < n; ++i) {
-		const int ta = idx[i];
-		const float sc = score_pixel<S>(c, L, P, st, v0, v1, rlf(F, fLane[i]), rlf(hd, ta), rlf(h0, ta), rlf(h1, ta), rlf(h2, ta));
-		++issued;
-		if (L.lane == ta) mine = sc;
+// Score one chunk of up to eight hypotheses of a round (bits of `todo`, all in [base, base + 8); lane t holds hypothesis t
+// in hd/h0/h1/h2; F: smoothness factors in the layout of smooth_pass, hypothesis base + g in lanes 8g..8g+7).
+//   (1) the homographies of all (hypothesis, view) pairs of the chunk, one pair per lane -> LDS
+//   (2) per hypothesis: the tap sums of all views (score_taps), one lane per view parks them in LDS
+//   (3) the per-view scores and the two-best-views means of the whole chunk, one (hypothesis, view) pair per lane
+// (1) and (3) cost one instruction stream per chunk instead of one per hypothesis.  Lane t of the result gets the score
+// of hypothesis t.
+template <int S>
+__device__ __forceinline__ float score_chunk(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const LdsStore<S>& st, float v0, float v1,
+                                             float F, float hd, float h0, float h1, float h2, unsigned long long todo, int base,
+                                             int fallback, float mine, unsigned& issued) {
+	constexpr int NV = 64 / S;               // views (lane groups) of a wave
+	constexpr int HP = S < 8 ? S : 8;        // hypotheses per pair-pass (lane = g * NV + v)
+	WavePark<S>* pk = st.pk;
+	const int lane = L.lane, pv = lane % NV, pg = lane / NV;
+	float vA[9], vHm[3];
+	{
+		const float4 a = pk->vh[pv][0], b = pk->vh[pv][1], cc = pk->vh[pv][2];
+		vA[0] = a.x; vA[1] = a.y; vA[2] = a.z; vA[3] = a.w; vA[4] = b.x; vA[5] = b.y; vA[6] = b.z; vA[7] = b.w; vA[8] = cc.x;
+		vHm[0] = cc.y; vHm[1] = cc.z; vHm[2] = cc.w;
+	}
+#pragma unroll
+	for (int p0 = 0; p0 < 8; p0 += HP) {
+		if ((todo >> (base + p0)) == 0ull) break;
+		const int g = p0 + (pg < HP ? pg : 0);
+		const int src = ((todo >> (base + g)) & 1ull) ? base + g : fallback;
+		const float gd = __shfl(hd, src, 64), g0 = __shfl(h0, src, 64), g1 = __shfl(h1, src, 64), g2 = __shfl(h2, src, 64);
+		if (pg < HP) {
+			float H[9];
+			make_homography(c, vA, vHm, v0, v1, gd, g0, g1, g2, H);
+			pk->hl[g][pv][0] = make_float4(H[0], H[1], H[2], H[3]);
+			pk->hl[g][pv][1] = make_float4(H[4], H[5], H[6], H[7]);
+			pk->hl[g][pv][2] = make_float4(H[8], 0.f, 0.f, 0.f);
+		}
+	}
+	auto taps_of = [&](auto nr) {
+		constexpr int NR = decltype(nr)::value;
+		for (unsigned long long td = todo; td; td &= td - 1ull) {
+			const int g = __builtin_ctzll(td) - base;
+			float H[9];
+			{
+				const float4 a = pk->hl[g][L.view][0], b = pk->hl[g][L.view][1], cc = pk->hl[g][L.view][2];
+				H[0] = a.x; H[1] = a.y; H[2] = a.z; H[3] = a.w; H[4] = b.x; H[5] = b.y; H[6] = b.z; H[7] = b.w; H[8] = cc.x;
+			}
+			float sum, sumSq, num;
+			bool viewBad;
+			score_taps<S, NR>(c, L, P, st, H, sum, sumSq, num, viewBad);
+			++issued;
+			if (L.seg == 0) pk->acc[g][L.view] = make_float4(sum, sumSq, num, viewBad ? 1.f : 0.f);
+		}
+	};
+	if constexpr (S == 8) {
+		if (P.a == 6) taps_of(std::integral_constant<int, 7>());
+		else if (P.a == 5) taps_of(std::integral_constant<int, 6>());
+		else taps_of(std::integral_constant<int, 8>());
+	} else {
+		taps_of(std::integral_constant<int, 64 / S>());
+	}
+#pragma unroll
+	for (int p0 = 0; p0 < 8; p0 += HP) {
+		if ((todo >> (base + p0)) == 0ull) break;
+		const int g = p0 + (pg < HP ? pg : 0);
+		const float4 r = pk->acc[g][pv];
+		const float Fg = __shfl(F, g * 8, 64);
+		const float s = view_score(c, r.x, r.y, r.z, r.w != 0.f, P.invSumW, P.normSq0, Fg);
+		float m1 = pv < c.V ? s : __builtin_huge_valf(), m2 = __builtin_huge_valf();
+		min2_group<NV>(m1, m2);
+		const float sc = two_best(c, m1, m2);
+		// hypothesis base + p0 + k sits in lanes k * NV ... of sc
+		const int k = lane - base - p0;
+		const float got = __shfl(sc, (k >= 0 && k < HP ? k : 0) * NV, 64);
+		if (k >= 0 && k < HP && ((todo >> lane) & 1ull)) mine = got;
 	}
 	return mine;
 }
@@ -633,7 +731,7 @@ __device__ __forceinline__ void pixel_geom(const EstConst& c, int x, int y, Pixe
 // (1 - bD e^{sD (dist/d)^2}) (1 - bN e^{sN acos^2}) are multiplied by a butterfly inside each 8-lane group (slots
 // without a neighbour contribute exactly 1), chunk after chunk.  hd..hpd: the lane's own group's hypothesis
 // (depth, normal, plane normal, plane offset); limit: last slot whose corrected normal is already in effect.
-__device__ __forceinline__ float smooth_pass(const EstConst& c, const float (*cl)[64], unsigned long long closeMask,
+__device__ __forceinline__ float smooth_pass(const EstConst& c, const float (*cl)[kMaxSlots], unsigned long long closeMask,
                                              unsigned long long eligMask, int lane, float hd, float h0, float h1, float h2,
                                              float hp0, float hp1, float hp2, float hpd, int limit) {
 	float F = 1.f;
@@ -678,7 +776,7 @@ template <int NW>
 struct RowShared {
 	float sc[2][32];   // per round parity: score of hypothesis t (propagation candidate or trial number)
 	float hist[kHist][6];
-	int row;
+	int row, item;
 };
 
 __device__ __forceinline__ int wait_progress(HC_GLOBAL int32_t* word, int need, HC_GLOBAL int32_t* err) {
@@ -825,10 +923,12 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 	}
 	const unsigned long long closeMask = C.closeMask, eligMask = C.eligMask;
 	{ // park the slots for the smoothness passes (LDS of this wave; same-wave LDS accesses are ordered)
-		float (*cl)[64] = st.pk->cl;
-		cl[0][lane] = C.X0; cl[1][lane] = C.X1; cl[2][lane] = C.X2;
-		cl[3][lane] = C.n0; cl[4][lane] = C.n1; cl[5][lane] = C.n2;
-		cl[6][lane] = C.k0; cl[7][lane] = C.k1; cl[8][lane] = C.k2;
+		float (*cl)[kMaxSlots] = st.pk->cl;
+		if (lane < kMaxSlots) {
+			cl[0][lane] = C.X0; cl[1][lane] = C.X1; cl[2][lane] = C.X2;
+			cl[3][lane] = C.n0; cl[4][lane] = C.n1; cl[5][lane] = C.n2;
+			cl[6][lane] = C.k0; cl[7][lane] = C.k1; cl[8][lane] = C.k2;
+		}
 	}
 
 	const int idx = y * W + x;
@@ -914,6 +1014,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			}
 		}
 		const unsigned long long vmask = __ballot(hv);
+		STAMP(3)
 		// ---- my share of the round: one smoothness pass per eight hypotheses, then the scorer ----
 		const int cnt = r1 - r0, per = (cnt + NW - 1) / NW, lo = r0 + wv * per, hi = (lo + per < r1 ? lo + per : r1);
 		float mine = __builtin_huge_valf();
@@ -930,12 +1031,9 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			const float F = smooth_pass(c, st.pk->cl, closeMask, eligMask, lane, gd, g0, g1, g2, gp0, gp1, gp2, gpd, glimit);
 #endif
 			const int top = base + 8 < hi ? base + 8 : hi;
-			int idxs[8], fl[8], nv = 0;
-			for (int t = base; t < top; ++t) {
-				if (!((vmask >> t) & 1ull)) continue;
-				idxs[nv] = t; fl[nv] = (t - base) * 8; ++nv;
-			}
-			mine = score_list<S>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, idxs, fl, nv, mine, issued);
+			const unsigned long long todo = vmask & ((1ull << top) - 1ull) & ~((1ull << base) - 1ull); // top <= 32
+			STAMP(4)
+			if (todo) mine = score_chunk<S>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, todo, base, __builtin_ctzll(todo), mine, issued);
 		}
 		STAMP(7)
 		const float all = share_scores<NW>(sh, par, lane, lo, hi, mine);
@@ -979,6 +1077,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			t0 = tnext;
 			if (t0 >= nR) phase = PH_DONE;
 		}
+		STAMP(11)
 		if (phase == PH_DONE) break;
 	}
 	if (pp.r > 0 && pp.poll > pp.known) pp.known = pp.poll; // consume the poll issued after the propagation phase
@@ -1000,29 +1099,54 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 // One launch sweeps a BATCH of independent reference images: ticket t -> (row t / nItems of image t % nItems), so the
 // rows of every image are still handed out in dependence order while the images fill each other's wavefront ramps.
 template <int S, int NW>
-__global__ __launch_bounds__(64 * NW) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
-                                                        int iter, int lag) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 ? 3 : 1, S >= 8 ? 3 : 2))) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
+                                                        int iter, int lag, int affinity) {
 	__shared__ RowShared<NW> sh;
 	__shared__ WavePark<S> park[NW];
 	const int wv = threadIdx.x >> 6;
 	const bool rev = (iter & 1) != 0; // dir = RB2LT on odd iterations, DepthMap.cpp:418
 	unsigned evals = 0, issued = 0;
 	unsigned long long taps = 0; // patch taps of the sequential algorithm's evaluations (per source view)
-	int par = 0;
+	int par = 0, rot = (int)blockIdx.x;
 	STAMP_DECL
 	RowPipe<S> pp;
 	pp.err = as_global(sy.error); pp.rev = rev;
 	for (;;) {
-		// rows are handed out in dependency order: whoever holds row r-1 of an image is already running
+		// Rows are handed out per image in dependence order (one counter per image): whoever holds row r-1 of an image
+		// is already running, so a waiting worker always waits on a running one.  Which image a worker serves is a
+		// matter of speed only: with affinity on, a workgroup prefers the images whose index is congruent to the id of
+		// its XCD (the rows of one image then share one L2, which holds the source lines the row above has just
+		// fetched) and only takes rows of the other images when its own are used up.
 		if (NW > 1) __syncthreads(); // everyone is done with the previous row's shared state
-		if (threadIdx.x == 0) sh.row = atomicAdd(sy.ticket, 1);
-		if (NW > 1) __syncthreads();
-		const int t = __builtin_amdgcn_readfirstlane(sh.row);
-		if (t >= maxRows * nItems) break;
-		const int r = t / nItems;
-		const EstConst c = items[t - r * nItems];
+		if (threadIdx.x == 0) {
+			int item = -1, row = 0;
+			const int G = nItems < 8 ? nItems : 8;
+			const int home = affinity ? (int)(__builtin_amdgcn_s_getreg(6164) & 7u) % G : 0; // HW_REG_XCC_ID[3:0]
+			const int nHome = affinity ? (nItems - home + G - 1) / G : nItems;
+			for (int k = 0; k < nItems && item < 0; ++k) {
+				int cand;
+				if (!affinity) cand = (rot + k) % nItems;
+				else if (k < nHome) cand = home + ((rot + k) % nHome) * G;
+				else { // the other images, in index order
+					cand = k - nHome;
+					cand += cand / (G - 1) + (cand % (G - 1) >= home ? 1 : 0); // skip the indices congruent to home
+				}
+				const int nrows_ = items[cand].H - 2 * kHalfWindow;
+				HC_GLOBAL int32_t* tk = as_global(sy.ticket) + cand;
+				if (__hip_atomic_load(tk, __ATOMIC_RELAXED, HC_SCOPE) >= nrows_) continue;
+				const int r_ = atomicAdd(sy.ticket + cand, 1);
+				if (r_ < nrows_) { item = cand; row = r_; }
+			}
+			++rot;
+			sh.row = row; sh.item = item;
+		}
+		__syncthreads();
+		const int itemIdx = __builtin_amdgcn_readfirstlane(sh.item);
+		if (itemIdx < 0) break;
+		const int r = __builtin_amdgcn_readfirstlane(sh.row);
+		const EstConst c = items[itemIdx];
 		const int nrows = c.H - 2 * kHalfWindow, ncols = c.W - 2 * kHalfWindow;
-		if (r >= nrows) continue; // a smaller image of the batch
+		(void)nrows;
 		LaneCtx<S> L;
 		lane_init<S>(c, L);
 		LdsStore<S> st;
@@ -1154,8 +1278,8 @@ __global__ void probe_score_kernel(EstConst c, Patch<S> P, RegStore<S> st, float
 }
 template __global__ void probe_score_kernel<8>(EstConst, Patch<8>, RegStore<8>, float, float, float, float, float, float*);
 __global__ void probe_smooth_kernel(EstConst c, Close C, float* out) {
-	__shared__ float cl[9][64];
-	for (int k = 0; k < 9; ++k) cl[k][threadIdx.x & 63] = out[k * 64 + threadIdx.x];
+	__shared__ float cl[9][kMaxSlots];
+	for (int k = 0; k < 9; ++k) cl[k][threadIdx.x & 31] = out[k * 64 + threadIdx.x];
 	out[threadIdx.x] = smooth_pass(c, cl, C.closeMask, C.eligMask, threadIdx.x & 63, out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], 63);
 }
 template <int S>
@@ -1285,26 +1409,26 @@ void launch_score_pass(const EstConst& c, const float* depthIn, const float* nor
 
 template <int NW>
 static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int lag,
-                            hipStream_t s) {
+                            int affinity, hipStream_t s) {
 	// one workgroup per row; rows beyond the resident set are picked up through the ticket
 	int grid = totalRows < 8192 ? totalRows : 8192;
 	if (grid < 1) return;
 	const dim3 g(grid), b(64 * NW);
 	switch (segments_for(V)) {
-	case 64: hipLaunchKernelGGL((sweep_kernel<64, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag); break;
-	case 32: hipLaunchKernelGGL((sweep_kernel<32, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag); break;
-	case 16: hipLaunchKernelGGL((sweep_kernel<16, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag); break;
-	case 8: hipLaunchKernelGGL((sweep_kernel<8, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag); break;
-	default: hipLaunchKernelGGL((sweep_kernel<4, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag); break;
+	case 64: hipLaunchKernelGGL((sweep_kernel<64, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
+	case 32: hipLaunchKernelGGL((sweep_kernel<32, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
+	case 16: hipLaunchKernelGGL((sweep_kernel<16, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
+	case 8: hipLaunchKernelGGL((sweep_kernel<8, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
+	default: hipLaunchKernelGGL((sweep_kernel<4, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
 	}
 }
 void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int lag,
-                  int wavesPerRow, hipStream_t s) {
+                  int wavesPerRow, int affinity, hipStream_t s) {
 	switch (wavesPerRow) {
-	case 1: launch_sweep_nw<1>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, s); break;
-	case 3: launch_sweep_nw<3>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, s); break;
-	case 4: launch_sweep_nw<4>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, s); break;
-	default: launch_sweep_nw<2>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, s); break;
+	case 1: launch_sweep_nw<1>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
+	case 3: launch_sweep_nw<3>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
+	case 4: launch_sweep_nw<4>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
+	default: launch_sweep_nw<2>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
 	}
 }
 

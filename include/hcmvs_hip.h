@@ -119,7 +119,9 @@ int hcmvs_estimate_device(hcmvs_ctx* ctx, uint32_t ref_id, const uint32_t* src_i
 /* A batch of independent EstimateDepthMap calls (different reference images, the same options and number of
  * source views) in ONE set of launches: the sweep kernel interleaves the rows of all items, so the images fill each
  * other's wavefront ramps (the reference overlaps images with two worker threads, SceneDensify.cpp:3699).
- * Every item produces exactly the maps hcmvs_estimate_device would produce for it with seed + seed_offset. */
+ * Every item produces exactly the maps hcmvs_estimate_device would produce for it with seed + seed_offset.
+ * 1 <= n_items <= HCMVS_MAX_BATCH. */
+#define HCMVS_MAX_BATCH 32
 typedef struct {
 	uint32_t ref_id;
 	const uint32_t* src_ids;

@@ -23,7 +23,7 @@ for b in range(B):
     keep.append((g, init, work))
 p = binding.default_params(adapthalfwin=6, n_estimation_iters=I)
 torch.cuda.synchronize()
-for rep in range(3):
+for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 3):
     t = time.time()
     for g, init, work in keep: work.copy_(init)
     ctx.estimate_batch_device(items, p)

@@ -1,26 +1,42 @@
-"""diagnostic (not a test): per-phase cycle shares of the sweep workers, using the stamps build"""
+"""diagnostic (not a test): per-phase cycle shares of the sweep workers, using the stamps build (batch of B images)"""
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
 binding = importlib.import_module("hc-mvs_amd.binding")
 binding.LIB_PATH = binding.LIB_PATH.replace("libhcmvs_hip.so", "libhcmvs_hip_stamps.so")
 synth = importlib.import_module("hc-mvs_amd.synth")
 W, H, F, V, I = 1920, 1080, 1600.0, 8, 4
-views = synth.make_views(W, H, F, V, seed=2); pts = synth.sparse_points(views, 2000)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dev = torch.device("cuda:0")
 ctx = binding.Context(0)
-for i, v in enumerate(views): ctx.upload_view(i, v["gray"], v["K"], v["R"], v["C"])
-d0, n0, dmin, dmax = ctx.splat_init(0, pts)
+items, keep = [], []
+for b in range(B):
+    views = synth.make_views(W, H, F, V, seed=2 + b); pts = synth.sparse_points(views, 2000)
+    g = [torch.from_numpy(v["gray"]).to(dev) for v in views]
+    for i, v in enumerate(views): ctx.set_view_device(100 * b + i, W, H, g[i].data_ptr(), v["K"], v["R"], v["C"])
+    ctx.shapes[100 * b] = (H, W)
+    d0, n0, dmin, dmax = ctx.splat_init(100 * b, pts)
+    init = torch.cat([torch.from_numpy(d0).reshape(-1), torch.from_numpy(n0).reshape(-1), torch.zeros(H * W)]).to(dev)
+    work = torch.empty_like(init)
+    HW = H * W
+    items.append(dict(ref_id=100 * b, src_ids=[100 * b + i for i in range(1, V + 1)], d_min=dmin, d_max=dmax, d_depth=work.data_ptr(),
+                      d_normal=work.data_ptr() + 4 * HW, d_conf=work.data_ptr() + 16 * HW, seed_offset=b))
+    keep.append((g, init, work))
 p = binding.default_params(adapthalfwin=6, n_estimation_iters=I)
 L = binding.lib(); L.hcmvs_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
 out = (C.c_uint64 * 16)()
-ctx.estimate(0, list(range(1, V + 1)), p, dmin, dmax, d0, n0)
-L.hcmvs_debug_stamps(ctx._h, out, 1)
-ctx.estimate(0, list(range(1, V + 1)), p, dmin, dmax, d0, n0)
+for rep in range(2):
+    for g, init, work in keep: work.copy_(init)
+    torch.cuda.synchronize()
+    L.hcmvs_debug_stamps(ctx._h, out, 1)
+    ctx.estimate_batch_device(items, p)
+    torch.cuda.synchronize()
 st = ctx.stats()
 L.hcmvs_debug_stamps(ctx._h, out, 1)
-names = ["0 loop top (wait/poll/upload)", "1 fill_patch", "2 slots+interp", "3 prop score", "4 prop exchange", "5 prop scan",
-         "6 hook1", "7 refine hyp+score", "8 refine exchange", "9 refine scan+store", "10 row end/ticket", "11"]
+names = ["0 wait for the row above", "1 loads issue + fill_patch", "2 slots + interp + park", "3 hypothesis generation", "4 smooth_pass",
+         "5 (prop tail)", "6 publish hook", "7 score_chunk", "8 exchange", "9 store + ring", "10 row end/ticket", "11 accept scan"]
 tot = sum(out[i] for i in range(12))
-npx = (W - 14) * (H - 14) * I
-print("NW", os.environ.get("HCMVS_WAVES_PER_ROW", "4"), "ms_sweep_avg %.2f" % st.ms_sweep_avg, "cycles/pixel (wave0) %.0f" % (tot / npx))
-for i in range(11):
-    print("%-32s %6.1f%%  %8.0f cyc/px" % (names[i], 100.0 * out[i] / tot, out[i] / npx))
+npx = (W - 14) * (H - 14) * I * B
+print("B", B, "ms_sweep_avg %.2f" % st.ms_sweep_avg, "s_memtime ticks/pixel (wave0) %.0f" % (tot / npx))
+for i in range(12):
+    print("%-32s %6.1f%%  %8.0f ticks/px" % (names[i], 100.0 * out[i] / tot, out[i] / npx))
