@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- PatchMatch depth-map estimation throughput on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one BATCH of synthetic input: --batch B (default 8) independent units
+One "step" = one pass of the hot path over one BATCH of synthetic input: --batch B (default 32) independent units
 of BASELINE.json configs[1] -- 1 reference x 8 source views, 1920x1080, 7x7 taps (adapthalfwin 6), 8 sweeps --
 each a complete EstimateDepthMap (median + init-score pass + 8 propagate/refine sweeps + end pass;
 SceneDensify.cpp:758-1072) of its own synthetic pinhole scene, issued as one hcmvs_estimate_batch_device call
 (the reference likewise overlaps images, SceneDensify.cpp:3699).  Inputs (images, initial maps) are resident in HBM
-before the timed region starts.  The single-unit latency (B = 1) is reported next to it as "single_unit".
+before the timed region starts; every unit has its own buffers and its own RNG stream, the synthetic scene content
+repeats every 4 units (rendering 32 distinct 1080p scenes on the host would take minutes).  The single-unit latency
+(B = 1) is reported next to it as "single_unit".
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -55,13 +57,14 @@ def cpu_baseline(n_threads):
             "sample": "960x540 synthetic scene, 8 source views, 7x7 taps, 8 sweeps, one full estimate (%.1f s)" % dt}
 
 
-def pmc_traffic(batch):
-    """HBM bytes per sweep launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes of this same
-    command (profiles/r01_pmc_hbm.json, made by tests/prof_bench.sh + profiles/summarize_pmc.py); PMC counters
-    cannot be collected from inside the process, so the value is null for any other batch size."""
+def pmc_value(batch, what):
+    """Per-launch counter totals of the sweep kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_pmc_hbm.json, made by tests/prof_bench.sh + profiles/summarize_pmc.py): `hbm_bytes` = FETCH_SIZE +
+    WRITE_SIZE, `valu_insts` = SQ_INSTS_VALU.  PMC counters cannot be collected from inside the process, so the
+    value is null for any other batch size."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
-            return json.load(f).get("sweep_kernel_batch%d_hbm_bytes_per_launch" % batch)
+            return json.load(f).get("sweep_kernel_batch%d_%s_per_launch" % (batch, what))
     except OSError:
         return None
 
@@ -71,7 +74,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="independent reference images per step and GPU")
+    ap.add_argument("--batch", type=int, default=32, help="independent reference images per step and GPU (1..32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -104,10 +107,14 @@ def main():
     HW = H * W
     params = binding.default_params(adapthalfwin=AHW, n_estimation_iters=SWEEPS, it_external=0, n_external_iters=1,
                                     seed=1234)
-    items, inits, works, keep = [], [], [], []
+    items, inits, works, keep, scenes = [], [], [], [], {}
+    allwork = torch.empty(B, 5 * HW, dtype=torch.float32, device=dev)  # the rank's packed maps: unit b -> allwork[b]
+    gathered = torch.empty(world * B, 5 * HW, dtype=torch.float32, device=dev) if world > 1 else None
     for b_ in range(B):
-        views = synth.make_views(W, H, FOCAL, N_SRC, seed=2 + rank * B + b_)
-        pts = synth.sparse_points(views, 2000, seed=5 + rank * B + b_)
+        if b_ % 4 not in scenes:  # 4 distinct scenes per rank; every unit still gets its own copy in HBM
+            vs = synth.make_views(W, H, FOCAL, N_SRC, seed=2 + rank * 4 + b_ % 4)
+            scenes[b_ % 4] = (vs, synth.sparse_points(vs, 2000, seed=5 + rank * 4 + b_ % 4))
+        views, pts = scenes[b_ % 4]
         slab = torch.from_numpy(np.stack([v["gray"] for v in views])).to(dev)  # one allocation per unit
         keep.append(slab)
         for i, v in enumerate(views):
@@ -116,21 +123,19 @@ def main():
         # initial maps (SceneDensify.cpp:783-808 splat of the sparse points), resident on the device
         d0, n0, dmin, dmax = ctx.splat_init(100 * b_, pts)
         init = torch.cat([torch.from_numpy(d0).reshape(-1), torch.from_numpy(n0).reshape(-1), torch.zeros(HW)]).to(dev)
-        work = torch.empty_like(init)
+        work = allwork[b_]
         esz = work.element_size()
         inits.append(init); works.append(work)
         items.append(dict(ref_id=100 * b_, src_ids=[100 * b_ + i for i in range(1, N_SRC + 1)], d_min=dmin, d_max=dmax,
                           d_depth=work.data_ptr(), d_normal=work.data_ptr() + HW * esz, d_conf=work.data_ptr() + 4 * HW * esz,
                           seed_offset=b_))
-    allwork = torch.stack(works) if world > 1 else None
 
     def step(its=items):
         for init, work in zip(inits, works):
             work.copy_(init)
         ctx.estimate_batch_device(its, params)
         if world > 1:  # the exchange FuseDepthMaps needs: every rank receives every map (20 B/px)
-            allwork.copy_(torch.stack(works))
-            D.allgather_maps(allwork)
+            D.allgather_maps(allwork, out=gathered)
 
     def fence():
         if world > 1:
@@ -151,16 +156,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     st = ctx.stats()  # of the last step: HIP events recorded on the stream the kernels ran on
-    # single-unit latency, outside the timed region
-    step(items[:1]); torch.cuda.synchronize()
-    t1 = time.perf_counter(); step(items[:1]); torch.cuda.synchronize()
+    # single-unit latency, outside the timed region and without the exchange
+    def single():
+        works[0].copy_(inits[0])
+        ctx.estimate_batch_device(items[:1], params)
+        torch.cuda.synchronize()
+    single()
+    t1 = time.perf_counter(); single()
     single_ms = (time.perf_counter() - t1) * 1e3
 
     if rank == 0:
         P = (W - 14) * (H - 14)
         taps_a = 0  # pass A scores every pixel of every unit once
         for b_ in range(B):
-            gra = ctx.gradient_map(100 * b_)[7:H - 7, 7:W - 7]
+            gra = ctx.gradient_map(100 * (b_ % 4))[7:H - 7, 7:W - 7]  # same content every 4 units
             taps_a += int(np.where(gra > 100, 36, (AHW + 1) ** 2).astype(np.int64).sum())
         tap_evals_sweeps = int(st.tap_evals) - taps_a
         # algorithmic bytes of ONE sweep launch (SURVEY.md 8d tap-gather convention): every bilinear sample
@@ -188,7 +197,9 @@ def main():
                           "estimate_total": round(st.ms_total, 3)},
             "roofline": {"kernel": "sweep_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(B),
+                         "traffic": pmc_value(B, "hbm_bytes"),
+                         "compulsory_bytes_per_launch": int(B * P * (4 * N_SRC + 4 + 40)),
+                         "valu_insts_per_launch": pmc_value(B, "valu_insts"),
                          "algorithmic_bytes_per_launch": int(bytes_sweep),
                          "avg_launch_ms": round(st.ms_sweep_avg, 3)},
         }

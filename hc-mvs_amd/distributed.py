@@ -39,15 +39,17 @@ def unpack_maps(slab, h, w):
     return slab[:hw].view(h, w), slab[hw:4 * hw].view(h, w, 3), slab[4 * hw:].view(h, w)
 
 
-def allgather_maps(local_slabs, group=None):
+def allgather_maps(local_slabs, group=None, out=None):
     """local_slabs: [n_local, 5*H*W] (the same n_local on every rank; pad with zero slabs if the images do not
     divide evenly).  Returns [world * n_local, 5*H*W], rank-major, identical on every rank.  One collective:
-    with fixed equal slabs RCCL moves each rank's block directly to all peers over its xGMI links."""
+    with fixed equal slabs RCCL moves each rank's block directly to all peers over its xGMI links.
+    out: optional preallocated result buffer (reused by callers that gather every step)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local_slabs
-    out = torch.empty((world * local_slabs.shape[0],) + tuple(local_slabs.shape[1:]), dtype=local_slabs.dtype,
-                      device=local_slabs.device)
+    if out is None:
+        out = torch.empty((world * local_slabs.shape[0],) + tuple(local_slabs.shape[1:]), dtype=local_slabs.dtype,
+                          device=local_slabs.device)
     dist.all_gather_into_tensor(out, local_slabs.contiguous(), group=group)
     return out
 
