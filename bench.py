@@ -57,6 +57,29 @@ def cpu_baseline(n_threads):
             "sample": "960x540 synthetic scene, 8 source views, 7x7 taps, 8 sweeps, one full estimate (%.1f s)" % dt}
 
 
+def fuse_throughput(ctx, n_views=8):
+    """Secondary figure of BASELINE.json's metric: FuseDepthMaps (SceneDensify.cpp:3265-3495) points/s on a ring of
+    n_views 1080p views whose maps are the synthetic ground truth with noise, outliers and holes; maps and images are
+    resident on the device, the cloud is copied back to the host inside the timed call."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fusion_scene import make_maps
+    maps, order = make_maps(w=W, h=H, f=FOCAL, n_views=n_views, noise=0.002, outliers=0.03, holes=0.05)
+    best = None
+    for _ in range(2):
+        for i, m in enumerate(maps):
+            ctx.upload_view(9000 + i, m["gray"], m["K"], m["R"], m["C"], bgr=m["bgr"])
+            ctx.set_depthmap(9000 + i, m["depth"], m["normal"], m["conf"], m["d_min"], m["d_max"])
+            ctx.set_neighbors(9000 + i, [9000 + j for j in m["neighbors"][:8]])
+        t0 = time.perf_counter()
+        got = ctx.fuse([9000 + i for i in order], W * H * n_views // 2)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, got["n_points"], got["n_depths"])
+    dt, npts, ndep = best
+    return {"points_per_s": round(npts / dt), "depths_per_s": round(ndep / dt), "ms": round(dt * 1e3, 2), "points": int(npts),
+            "views": "%d x %dx%d" % (n_views, W, H)}
+
+
 def pmc_value(batch, what):
     """Per-launch counter totals of the sweep kernel from the committed rocprofv3 --pmc passes of this same command
     (profiles/r01_pmc_hbm.json, made by tests/prof_bench.sh + profiles/summarize_pmc.py): `hbm_bytes` = FETCH_SIZE +
@@ -76,6 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="independent reference images per step and GPU (1..32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true", help="skip the FuseDepthMaps points/s figure")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -203,6 +227,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(bytes_sweep),
                          "avg_launch_ms": round(st.ms_sweep_avg, 3)},
         }
+        if world == 1 and not args.no_fuse:
+            out["fuse"] = fuse_throughput(ctx)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))
         print(json.dumps(out), flush=True)

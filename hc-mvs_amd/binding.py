@@ -252,10 +252,10 @@ class Context:
     def fuse(self, order, capacity, n_min_views_fuse=2, depth_diff_threshold=0.01, normal_diff_deg=25.0, depthweight=1.0,
              normalweight=1.0, with_normals=True, with_colors=True):
         """FuseDepthMaps: returns dict(xyz, normal, bgr, n_views, n_points, n_depths)"""
-        xyz = np.zeros((capacity, 3), np.float32)
-        nrm = np.zeros((capacity, 3), np.float32) if with_normals else None
-        bgr = np.zeros((capacity, 3), np.uint8) if with_colors else None
-        nv = np.zeros(capacity, np.uint32)
+        xyz = np.empty((capacity, 3), np.float32)  # only the first n_points rows are written and returned
+        nrm = np.empty((capacity, 3), np.float32) if with_normals else None
+        bgr = np.empty((capacity, 3), np.uint8) if with_colors else None
+        nv = np.empty(capacity, np.uint32)
         ids = (C.c_uint32 * len(order))(*order)
         npts = C.c_uint64(); nd = C.c_uint64()
         self._chk(lib().hcmvs_fuse(self._h, ids, len(order), n_min_views_fuse, depth_diff_threshold, normal_diff_deg,

@@ -31,10 +31,11 @@ void launch_fill_u64(unsigned long long* p, unsigned long long v, size_t n, hipS
 void launch_filter_splat(const DevMap& ref, const DevMap& nb, unsigned long long* key, hipStream_t s);
 void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsigned long long* keys, int adjust, int nMinViews,
                         int nMinViewsAdjust, float thr, float* newDepth, float* newConf, unsigned long long* counters, hipStream_t s);
-void launch_fuse_begin(const DevMap& A, uint8_t* state, uint8_t* flag, unsigned long long* counters, hipStream_t s);
-void launch_fuse_bid(const DevMap& A, const DevMap* maps, uint8_t* state, int reset, hipStream_t s);
-void launch_fuse_decide(const DevMap& A, const DevMap* maps, uint8_t* state, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv,
-                        uint8_t* oflag, int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, hipStream_t s);
+void launch_fuse_begin(const DevMap& A, uint32_t* pending, uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters, hipStream_t s);
+void launch_fuse_round(const DevMap& A, const DevMap* maps, const uint32_t* pending, const uint32_t* roundCnt, uint32_t* nextPending,
+                       uint32_t* nextCnt, uint32_t* decidedList, float* decidedDepth, uint32_t* decidedCnt, float* oxyz, float* onormal,
+                       uint8_t* obgr, uint32_t* onv, uint8_t* oflag, int nMinViewsFuse, float thDepth, float normalError,
+                       unsigned long long* counters, int blocks, hipStream_t s);
 size_t fuse_scan_temp_bytes(int n);
 void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,
                          float* onormal, uint8_t* obgr, uint32_t* onv, unsigned long long base, unsigned long long capacity, float* xyz,

@@ -181,31 +181,42 @@ __device__ __forceinline__ void pixel_point(const DevMap& A, int idx, float dept
 	point[0] = (float)Xw[0]; point[1] = (float)Xw[1]; point[2] = (float)Xw[2];
 }
 
-// state: 0 = nothing to do, 1 = pending, 2 / 3 = accepted / rejected in this round, 4 / 5 = ... in an earlier round
-__global__ void fuse_begin_kernel(DevMap A, uint8_t* state, uint8_t* flag, unsigned long long* counters) {
-	const int n = A.w * A.h;
-	unsigned nd = 0, np = 0;
-	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-		uint8_t s = 0;
-		if (A.depth[idx] != 0.f) {
-			++nd;
-			if (A.claim[idx] == NO_ID) { s = 1; ++np; }
-		}
-		state[idx] = s;
-		flag[idx] = 0;
-	}
-	if (nd) atomicAdd(&counters[0], (unsigned long long)nd); // valid depths visited (SceneDensify.cpp:3359)
-	if (np) atomicAdd(&counters[1], (unsigned long long)np); // pending pixels
+// Rounds of one image pass work on device-side lists of pixel indices (their order is irrelevant: contention is
+// settled by the raster index itself): `pending` in, still-pending + decided out.  Round r reads its pixel count from
+// roundCnt[r] and appends to roundCnt[r + 1] / decidedCnt[r], so a group of rounds runs without the host in between.
+__device__ __forceinline__ void list_append(bool pred, int value, uint32_t* list, uint32_t* count) { // one atomic per wave
+	const unsigned long long m = __ballot(pred);
+	if (!pred) return;
+	const int lane = threadIdx.x & 63, leader = __builtin_ctzll(m);
+	uint32_t base = 0;
+	if (lane == leader) base = atomicAdd(count, (uint32_t)__builtin_popcountll(m));
+	base = __shfl(base, leader, 64);
+	list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)value;
 }
 
-// reset == 0: every pending pixel bids for its targets.  reset != 0: pending pixels and the ones decided in this
-// round clear their targets again (states 2/3 then become 4/5 = done)
-__global__ void fuse_bid_kernel(DevMap A, const DevMap* maps, uint8_t* state, int reset) {
+__global__ void fuse_begin_kernel(DevMap A, uint32_t* pending, uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters) {
 	const int n = A.w * A.h;
-	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-		const uint8_t st = state[idx];
-		if (st != 1 && !(reset && (st == 2 || st == 3))) continue;
-		if (reset && st != 1) state[idx] = st + 2;
+	unsigned nd = 0;
+	const int nPad = (n + 63) & ~63; // whole waves take part in list_append
+	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nPad; idx += gridDim.x * blockDim.x) {
+		bool pend = false;
+		if (idx < n) {
+			if (A.depth[idx] != 0.f) {
+				++nd;
+				pend = A.claim[idx] == NO_ID;
+			}
+			flag[idx] = 0;
+		}
+		list_append(pend, idx, pending, roundCnt);
+	}
+	if (nd) atomicAdd(&counters[0], (unsigned long long)nd); // valid depths visited (SceneDensify.cpp:3359)
+}
+
+// every pending pixel bids (atomicMin of its raster index) for the neighbour pixels it projects onto
+__global__ void fuse_bid_kernel(DevMap A, const DevMap* maps, const uint32_t* pending, const uint32_t* roundCnt) {
+	const int n = (int)*roundCnt;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const int idx = (int)pending[i];
 		float point[3];
 		pixel_point(A, idx, A.depth[idx], point);
 		for (int q = 0; q < A.nNeighbors; ++q) {
@@ -213,8 +224,24 @@ __global__ void fuse_bid_kernel(DevMap A, const DevMap* maps, uint8_t* state, in
 			if (!B.depth) continue;
 			float ptz; int ib, xB, yB;
 			if (!project_target(B, point, ptz, ib, xB, yB)) continue;
-			if (reset) B.bid[ib] = NO_ID;
-			else atomicMin(&B.bid[ib], (unsigned)idx);
+			atomicMin(&B.bid[ib], (unsigned)idx);
+		}
+	}
+}
+// the pixels decided in this round owned all their targets: clearing those restores "lowest pending index" once the
+// remaining pixels have bid again.  `point` is recomputed from the depth the pixel had when it bid (saved by decide).
+__global__ void fuse_unbid_kernel(DevMap A, const DevMap* maps, const uint32_t* decided, const float* decidedDepth, const uint32_t* decidedCnt) {
+	const int n = (int)*decidedCnt;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const int idx = (int)decided[i];
+		float point[3];
+		pixel_point(A, idx, decidedDepth[i], point);
+		for (int q = 0; q < A.nNeighbors; ++q) {
+			const DevMap& B = maps[A.neighbors[q]];
+			if (!B.depth) continue;
+			float ptz; int ib, xB, yB;
+			if (!project_target(B, point, ptz, ib, xB, yB)) continue;
+			B.bid[ib] = NO_ID;
 		}
 	}
 }
@@ -223,26 +250,42 @@ struct FuseOut { // per pixel of the current image, compacted in raster order af
 	float* xyz; float* normal; uint8_t* bgr; uint32_t* nviews; uint8_t* flag;
 };
 
-__global__ void fuse_decide_kernel(DevMap A, const DevMap* maps, uint8_t* state, FuseOut out, int nMinViewsFuse, float thDepth,
-                                   float normalError, unsigned long long* counters) {
-	const int n = A.w * A.h;
-	unsigned decided = 0, accepted = 0;
-	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-		if (state[idx] != 1) continue;
-		const float depth = A.depth[idx];
-		float point[3];
-		pixel_point(A, idx, depth, point);
-		// do I own every target?  (then no lower raster index is still undecided on any of them)
-		bool ready = true;
-		for (int q = 0; q < A.nNeighbors && ready; ++q) {
-			const DevMap& B = maps[A.neighbors[q]];
-			if (!B.depth) continue;
-			float ptz; int ib, xB, yB;
-			if (!project_target(B, point, ptz, ib, xB, yB)) continue;
-			ready = B.bid[ib] == (unsigned)idx;
+__global__ void fuse_decide_kernel(DevMap A, const DevMap* maps, const uint32_t* pending, const uint32_t* roundCnt, uint32_t* nextPending,
+                                   uint32_t* nextCnt, uint32_t* decidedList, float* decidedDepth, uint32_t* decidedCnt, FuseOut out,
+                                   int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters) {
+	const int n = (int)*roundCnt;
+	const int nPad = (n + 63) & ~63;
+	unsigned accepted = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nPad; i += gridDim.x * blockDim.x) {
+		const bool have = i < n;
+		const int idx = have ? (int)pending[i] : 0;
+		bool ready = have;
+		const float depth = have ? A.depth[idx] : 0.f;
+		float point[3] = {0.f, 0.f, 0.f};
+		if (have) {
+			pixel_point(A, idx, depth, point);
+			// do I own every target?  (then no lower raster index is still undecided on any of them)
+			for (int q = 0; q < A.nNeighbors && ready; ++q) {
+				const DevMap& B = maps[A.neighbors[q]];
+				if (!B.depth) continue;
+				float ptz; int ib, xB, yB;
+				if (!project_target(B, point, ptz, ib, xB, yB)) continue;
+				ready = B.bid[ib] == (unsigned)idx;
+			}
+		}
+		list_append(have && !ready, idx, nextPending, nextCnt);
+		{ // decided pixels: remember them (and the depth they bid with) for fuse_unbid_kernel
+			const unsigned long long m = __ballot(ready);
+			if (ready) {
+				const int lane = threadIdx.x & 63, leader = __builtin_ctzll(m);
+				uint32_t base = 0;
+				if (lane == leader) base = atomicAdd(decidedCnt, (uint32_t)__builtin_popcountll(m));
+				base = __shfl(base, leader, 64);
+				const uint32_t o = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+				decidedList[o] = (uint32_t)idx; decidedDepth[o] = depth;
+			}
 		}
 		if (!ready) continue;
-		++decided;
 		// the reference's body, SceneDensify.cpp:3364-3450
 		uint32_t vimg[kFuseMaxViews]; int vpix[kFuseMaxViews]; int nv = 0;
 		vimg[nv] = A.id; vpix[nv] = idx; ++nv;
@@ -293,7 +336,6 @@ __global__ void fuse_decide_kernel(DevMap A, const DevMap* maps, uint8_t* state,
 		}
 		if (nv < nMinViewsFuse) {
 			for (int v = 0; v < nv; ++v) maps[vimg[v]].claim[vpix[v]] = NO_ID;
-			state[idx] = 3;
 		} else {
 			A.claim[idx] = 0u;
 			const double nrm = 1.0 / confidence;
@@ -311,10 +353,8 @@ __global__ void fuse_decide_kernel(DevMap A, const DevMap* maps, uint8_t* state,
 			out.flag[idx] = 1;
 			++accepted;
 			for (int v = 0; v < ninv; ++v) maps[invImg[v]].depth[invPix[v]] = 0.f;
-			state[idx] = 2;
 		}
 	}
-	if (decided) atomicAdd(&counters[2], (unsigned long long)decided);
 	if (accepted) atomicAdd(&counters[3], (unsigned long long)accepted);
 }
 
@@ -357,16 +397,20 @@ void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsig
                         int nMinViewsAdjust, float thr, float* newDepth, float* newConf, unsigned long long* counters, hipStream_t s) {
 	hipLaunchKernelGGL(filter_vote_kernel, kGrid, kBlock, 0, s, ref, nbs, N, keys, adjust, nMinViews, nMinViewsAdjust, thr, newDepth, newConf, counters);
 }
-void launch_fuse_begin(const DevMap& A, uint8_t* state, uint8_t* flag, unsigned long long* counters, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, state, flag, counters);
+void launch_fuse_begin(const DevMap& A, uint32_t* pending, uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, pending, roundCnt, flag, counters);
 }
-void launch_fuse_bid(const DevMap& A, const DevMap* maps, uint8_t* state, int reset, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_bid_kernel, kGrid, kBlock, 0, s, A, maps, state, reset);
-}
-void launch_fuse_decide(const DevMap& A, const DevMap* maps, uint8_t* state, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv,
-                        uint8_t* oflag, int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, hipStream_t s) {
+// one round: bid, decide (+ split the list), clear the bids of the decided pixels
+void launch_fuse_round(const DevMap& A, const DevMap* maps, const uint32_t* pending, const uint32_t* roundCnt, uint32_t* nextPending,
+                       uint32_t* nextCnt, uint32_t* decidedList, float* decidedDepth, uint32_t* decidedCnt, float* oxyz, float* onormal,
+                       uint8_t* obgr, uint32_t* onv, uint8_t* oflag, int nMinViewsFuse, float thDepth, float normalError,
+                       unsigned long long* counters, int blocks, hipStream_t s) {
 	FuseOut out{oxyz, onormal, obgr, onv, oflag};
-	hipLaunchKernelGGL(fuse_decide_kernel, kGrid, kBlock, 0, s, A, maps, state, out, nMinViewsFuse, thDepth, normalError, counters);
+	const dim3 g(blocks < 1 ? 1 : blocks);
+	hipLaunchKernelGGL(fuse_bid_kernel, g, kBlock, 0, s, A, maps, pending, roundCnt);
+	hipLaunchKernelGGL(fuse_decide_kernel, g, kBlock, 0, s, A, maps, pending, roundCnt, nextPending, nextCnt, decidedList, decidedDepth,
+	                   decidedCnt, out, nMinViewsFuse, thDepth, normalError, counters);
+	hipLaunchKernelGGL(fuse_unbid_kernel, g, kBlock, 0, s, A, maps, decidedList, decidedDepth, decidedCnt);
 }
 size_t fuse_scan_temp_bytes(int n) {
 	size_t bytes = 0;

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 using namespace hcmvs;
@@ -739,16 +740,23 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	hipStream_t s = c->stream;
 	for (auto& m : host) if (m.depth) { launch_fill_u32(m.claim, 0xFFFFFFFFu, (size_t)m.w * m.h, s); launch_fill_u32(m.bid, 0xFFFFFFFFu, (size_t)m.w * m.h, s); }
 	// per-pass scratch (sized for the largest image) + device cloud
+	constexpr int kRoundCap = 1 << 16; // rounds of one image pass (one counter each; a round decides >= 1 pixel)
+	constexpr int kGroup = 8;          // rounds issued between two looks at the pending count
 	const size_t scanBytes = (fuse_scan_temp_bytes((int)maxArea) + 255) & ~(size_t)255;
 	size_t off = 0;
 	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-	const size_t oState = carve(maxArea), oFlag = carve(maxArea), oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
+	const size_t oList0 = carve(maxArea * 4), oList1 = carve(maxArea * 4), oDec = carve(maxArea * 4), oDecD = carve(maxArea * 4),
+	             oCnt = carve((size_t)(kRoundCap + 1) * 4), oDCnt = carve((size_t)kRoundCap * 4), oFlag = carve(maxArea),
+	             oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
 	             oXyz = carve(maxArea * 12), oNrm = carve(maxArea * 12), oBgr = carve(maxArea * 3), oNv = carve(maxArea * 4),
 	             oCX = carve(capacity * 12), oCN = carve(normal ? capacity * 12 : 0), oCB = carve(bgr ? capacity * 3 : 0), oCV = carve(n_views ? capacity * 4 : 0);
 	rc = ensure_scratch(c, off);
 	if (rc) return rc;
 	char* b = (char*)c->fuseScratch;
-	uint8_t* state = (uint8_t*)(b + oState); uint8_t* flag = (uint8_t*)(b + oFlag);
+	uint32_t* lists[2] = {(uint32_t*)(b + oList0), (uint32_t*)(b + oList1)};
+	uint32_t* decList = (uint32_t*)(b + oDec); float* decDepth = (float*)(b + oDecD);
+	uint32_t* roundCnt = (uint32_t*)(b + oCnt); uint32_t* decCnt = (uint32_t*)(b + oDCnt);
+	uint8_t* flag = (uint8_t*)(b + oFlag);
 	uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos);
 	float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
 	float* cX = (float*)(b + oCX); float* cN = normal ? (float*)(b + oCN) : nullptr; uint8_t* cB = bgr ? (uint8_t*)(b + oCB) : nullptr;
@@ -760,25 +768,29 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 		const DevMap& A = host[order[oi]];
 		const int n = A.w * A.h;
 		HIPCHK(c, hipMemsetAsync(c->counters, 0, 64, s));
-		launch_fuse_begin(A, state, flag, c->counters, s);
+		HIPCHK(c, hipMemsetAsync(roundCnt, 0, oFlag - oCnt, s)); // both counter arrays
+		launch_fuse_begin(A, lists[0], roundCnt, flag, c->counters, s);
+		uint32_t pending = 0;
+		HIPCHK(c, hipMemcpyAsync(&pending, roundCnt, 4, hipMemcpyDeviceToHost, s));
+		HIPCHK(c, hipStreamSynchronize(s));
+		int r = 0;
+		while (pending > 0) {
+			if (r + kGroup > kRoundCap) return fail(c, HCMVS_ERR_HIP, "fuse: image %u needs more than %d rounds (%u pixels pending)", A.id, kRoundCap, pending);
+			const int blocks = (int)std::min<uint32_t>(2048u, (pending + 255u) / 256u);
+			for (int k = 0; k < kGroup; ++k, ++r)
+				launch_fuse_round(A, c->dMaps, lists[r & 1], roundCnt + r, lists[(r + 1) & 1], roundCnt + r + 1, decList, decDepth, decCnt + r, pxyz,
+				                  cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, n_min_views_fuse, thDepth, normalError, c->counters, blocks, s);
+			uint32_t left = 0;
+			HIPCHK(c, hipMemcpyAsync(&left, roundCnt + r, 4, hipMemcpyDeviceToHost, s));
+			HIPCHK(c, hipStreamSynchronize(s));
+			if (left >= pending) return fail(c, HCMVS_ERR_HIP, "fuse: no progress in image %u (%u pixels pending)", A.id, pending);
+			pending = left;
+		}
 		unsigned long long cnt[4];
 		HIPCHK(c, hipMemcpyAsync(cnt, c->counters, 32, hipMemcpyDeviceToHost, s));
 		HIPCHK(c, hipStreamSynchronize(s));
 		depths += cnt[0];
-		unsigned long long pending = cnt[1], accepted = 0;
-		int guard = 0;
-		while (pending > 0) {
-			HIPCHK(c, hipMemsetAsync(c->counters + 2, 0, 16, s));
-			launch_fuse_bid(A, c->dMaps, state, 0, s);
-			launch_fuse_decide(A, c->dMaps, state, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, n_min_views_fuse, thDepth, normalError,
-			                   c->counters, s);
-			launch_fuse_bid(A, c->dMaps, state, 1, s);
-			HIPCHK(c, hipMemcpyAsync(cnt, c->counters, 32, hipMemcpyDeviceToHost, s));
-			HIPCHK(c, hipStreamSynchronize(s));
-			if (cnt[2] == 0 || ++guard > 100000) return fail(c, HCMVS_ERR_HIP, "fuse: no progress in image %u (%llu pixels pending)", A.id, pending);
-			pending -= cnt[2];
-			accepted += cnt[3];
-		}
+		const unsigned long long accepted = cnt[3];
 		if (total + accepted > capacity) return fail(c, HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity);
 		if (accepted) launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, total, capacity, cX, cN, cB, cV, s);
 		total += accepted;
