@@ -49,8 +49,21 @@ _lib = None
 SYMBOLS = ["hcmvs_default_params", "hcmvs_create", "hcmvs_destroy", "hcmvs_last_error", "hcmvs_set_stream",
            "hcmvs_synchronize", "hcmvs_upload_view", "hcmvs_set_view_device", "hcmvs_release_view",
            "hcmvs_get_gradient_map", "hcmvs_estimate", "hcmvs_estimate_device", "hcmvs_estimate_batch_device", "hcmvs_get_stats",
-           "hcmvs_splat_init", "hcmvs_set_depthmap", "hcmvs_set_depthmap_device", "hcmvs_get_depthmap",
+           "hcmvs_splat_init", "hcmvs_triangulate_init", "hcmvs_triangulate_points", "hcmvs_set_depthmap", "hcmvs_set_depthmap_device", "hcmvs_get_depthmap",
            "hcmvs_set_neighbors", "hcmvs_filter", "hcmvs_fuse"]
+
+
+def triangulate_points(w, h, K, R, Cc, points_xyz, avg_depth=0.0, add_corners=True):
+    """hcmvs_triangulate_points: the triangulation initialisation without a context (pure host code)"""
+    pts = np.ascontiguousarray(points_xyz, np.float32)
+    depth = np.zeros((h, w), np.float32); normal = np.zeros((h, w, 3), np.float32)
+    dmin = C.c_float(); dmax = C.c_float()
+    Ka, Kp = _d(K); Ra, Rp = _d(R); Ca, Cp = _d(Cc)
+    rc = lib().hcmvs_triangulate_points(w, h, Kp, Rp, Cp, _f(pts), len(pts), C.c_float(avg_depth), int(add_corners), _f(depth),
+                                        _f(normal), C.byref(dmin), C.byref(dmax))
+    if rc != 0:
+        raise HcmvsError(rc, "triangulate_points failed")
+    return depth, normal, dmin.value, dmax.value
 
 
 def lib():
@@ -88,6 +101,9 @@ def lib():
         L.hcmvs_estimate_batch_device.argtypes = [vp, C.POINTER(BatchItem), C.c_int32, C.POINTER(Params)]
         L.hcmvs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.hcmvs_splat_init.argtypes = [vp, C.c_uint32, fp, C.c_int32, fp, fp, fp, fp]
+        L.hcmvs_triangulate_init.argtypes = [vp, C.c_uint32, fp, C.c_int32, C.c_float, C.c_int32, fp, fp, fp, fp]
+        dp = C.POINTER(C.c_double)
+        L.hcmvs_triangulate_points.argtypes = [C.c_int32, C.c_int32, dp, dp, dp, fp, C.c_int32, C.c_float, C.c_int32, fp, fp, fp, fp]
         u64p = C.POINTER(C.c_uint64)
         L.hcmvs_set_depthmap.argtypes = [vp, C.c_uint32, fp, fp, fp, C.c_float, C.c_float]
         L.hcmvs_set_depthmap_device.argtypes = [vp, C.c_uint32, vp, vp, vp, C.c_float, C.c_float]
@@ -186,6 +202,16 @@ class Context:
         dmin = C.c_float(); dmax = C.c_float()
         self._chk(lib().hcmvs_splat_init(self._h, vid, _f(pts), len(pts), _f(depth), _f(normal), C.byref(dmin),
                                          C.byref(dmax)))
+        return depth, normal, dmin.value, dmax.value
+
+    def triangulate_init(self, vid, points_xyz, avg_depth=0.0, add_corners=True):
+        """TriangulatePoints2DepthMap as InitDepthMap uses it: returns (depth, normal, d_min, d_max)"""
+        h, w = self.shapes[vid]
+        pts = np.ascontiguousarray(points_xyz, np.float32)
+        depth = np.zeros((h, w), np.float32); normal = np.zeros((h, w, 3), np.float32)
+        dmin = C.c_float(); dmax = C.c_float()
+        self._chk(lib().hcmvs_triangulate_init(self._h, vid, _f(pts), len(pts), C.c_float(avg_depth), int(add_corners), _f(depth),
+                                               _f(normal), C.byref(dmin), C.byref(dmax)))
         return depth, normal, dmin.value, dmax.value
 
     def estimate(self, ref_id, src_ids, params, d_min, d_max, depth, normal, conf=None):

@@ -9,6 +9,7 @@
 #include "../../include/hcmvs_hip.h"
 #include "pm_common.h"
 #include "fuse_common.h"
+#include "tri_init.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -570,6 +571,26 @@ int hcmvs_splat_init(hcmvs_ctx* c, uint32_t id, const float* pts, int32_t n, flo
 	return HCMVS_OK;
 }
 
+int hcmvs_triangulate_points(int32_t W, int32_t H, const double K[9], const double R[9], const double C[3], const float* pts,
+                             int32_t n, float avg_depth, int32_t add_corners, float* depth, float* normal, float* d_min, float* d_max) {
+	if (!K || !R || !C || !pts || !depth || !normal || !d_min || !d_max || n < 1 || W < 1 || H < 1) return HCMVS_ERR_INVALID;
+	float lo = 0.f, hi = 0.f;
+	if (!hcmvs::triangulate_init(W, H, K, R, C, pts, n, avg_depth, add_corners != 0, depth, normal, &lo, &hi)) return HCMVS_ERR_INVALID;
+	*d_min = lo * 0.9f; // SceneDensify.cpp:524-525
+	*d_max = hi * 1.1f;
+	return HCMVS_OK;
+}
+int hcmvs_triangulate_init(hcmvs_ctx* c, uint32_t id, const float* pts, int32_t n, float avg_depth, int32_t add_corners, float* depth,
+                           float* normal, float* d_min, float* d_max) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!pts || !depth || !normal || !d_min || !d_max || n < 1) return fail(c, HCMVS_ERR_INVALID, "triangulate_init: bad arguments");
+	auto it = c->views.find(id);
+	if (it == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "triangulate_init: unknown view %u", id);
+	const View& v = it->second;
+	if (hcmvs_triangulate_points(v.w, v.h, v.K, v.R, v.C, pts, n, avg_depth, add_corners, depth, normal, d_min, d_max) != HCMVS_OK)
+		return fail(c, HCMVS_ERR_INVALID, "triangulate_init: no sparse point in front of view %u", id);
+	return HCMVS_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // filter / fuse

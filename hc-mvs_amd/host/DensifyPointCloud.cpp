@@ -10,8 +10,9 @@
  *
  * Deliberately narrower than the reference ("defined subset"): images are read from binary
  * PPM/PGM files (no PNG/JPEG codecs here); resolution levels halve the image with a box filter (== cv::resize
- * INTER_AREA for integer factors); the initial maps are splatted from the sparse points (nMinViewsTrustPoint < 2
- * branch); optical flow, semantic priors, view spread, gap interpolation and SGM modes are not available and the
+ * INTER_AREA for integer factors); the initial maps come from the Delaunay triangulation of the sparse points
+ * (--n-initTriangulate 1, the default), from the previous level's depth maps in the working folder
+ * (--n-initTriangulate 0, the fork's coarse-to-fine hand-off) or from a splat (--min-views-trust-point 1); optical flow, semantic priors, view spread, gap interpolation and SGM modes are not available and the
  * corresponding flags are accepted and ignored with a note.
  */
 #include "../../include/hcmvs_hip.h"
@@ -36,6 +37,8 @@ struct Options { // DensifyPointCloud.cpp:139-198 (defaults from there)
 	int resolutionLevel = 1, numberViews = 5, numberViewsFuse = 2, fusionMode = 0, verbosity = 2;
 	int estimationIters = 1, estimationItersExternal = 4, adaptHalfWin = 5, propagateHalfWin = 1, propagateStep = 4;
 	float photometricFlow = 0.5f, depthweight = 1.f, normalweight = 1.f;
+	int initTriangulate = 1;      // 1: Delaunay init from the sparse points, 0: read the previous level's maps (SceneDensify.cpp:522-553)
+	int minViewsTrustPoint = 2;   // < 2: splat the sparse points instead (SceneDensify.cpp:783-808)
 	int device = 0, batch = 8;
 	uint32_t seed = 1234;
 };
@@ -304,6 +307,59 @@ bool save_ply(const std::string& path, const std::vector<float>& xyz, const std:
 	return (bool)f;
 }
 
+// raw 'DR' depth map written by save_dmap / the reference (Interface.h:634-652); returns false when absent or malformed
+bool load_dmap(const std::string& path, int& w, int& h, std::vector<float>& d, std::vector<float>& n) {
+	std::ifstream f(path, std::ios::binary);
+	if (!f) return false;
+	struct __attribute__((packed)) Hdr { uint16_t name; uint8_t type, pad; uint32_t iw, ih, dw, dh; float dMin, dMax; } hd;
+	f.read((char*)&hd, 28);
+	if (!f || hd.name != 0x5244 || !(hd.type & 1)) return false;
+	uint16_t nl = 0; f.read((char*)&nl, 2); f.seekg(nl, std::ios::cur);
+	uint32_t nids = 0; f.read((char*)&nids, 4); f.seekg((std::streamoff)nids * 4 + 72 + 72 + 24, std::ios::cur);
+	w = (int)hd.dw; h = (int)hd.dh;
+	d.resize((size_t)w * h);
+	f.read((char*)d.data(), (std::streamsize)d.size() * 4);
+	n.assign((size_t)w * h * 3, 0.f);
+	if (hd.type & 2) f.read((char*)n.data(), (std::streamsize)n.size() * 4);
+	return (bool)f;
+}
+// cv::resize(..., INTER_CUBIC) as the hand-off uses it (SceneDensify.cpp:541-542): Keys kernel a = -0.75, pixel centres
+// aligned ((x + 0.5) * scale - 0.5), replicated border
+void resize_cubic(const std::vector<float>& src, int sw, int sh, int ch, std::vector<float>& dst, int dw, int dh) {
+	dst.resize((size_t)dw * dh * ch);
+	auto weights = [](float t, float* w) {
+		const float A = -0.75f;
+		w[0] = ((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A;
+		w[1] = ((A + 2) * t - (A + 3)) * t * t + 1;
+		w[2] = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1;
+		w[3] = 1.f - w[0] - w[1] - w[2];
+	};
+	const double sx = (double)sw / dw, sy = (double)sh / dh;
+	for (int y = 0; y < dh; ++y) {
+		const float fy = (float)((y + 0.5) * sy - 0.5);
+		const int iy = (int)std::floor(fy);
+		float wy[4]; weights(fy - iy, wy);
+		for (int x = 0; x < dw; ++x) {
+			const float fx = (float)((x + 0.5) * sx - 0.5);
+			const int ix = (int)std::floor(fx);
+			float wx[4]; weights(fx - ix, wx);
+			for (int c = 0; c < ch; ++c) {
+				float acc = 0.f;
+				for (int j = 0; j < 4; ++j) {
+					const int yy = std::min(std::max(iy - 1 + j, 0), sh - 1);
+					float row = 0.f;
+					for (int i = 0; i < 4; ++i) {
+						const int xx = std::min(std::max(ix - 1 + i, 0), sw - 1);
+						row += wx[i] * src[((size_t)yy * sw + xx) * ch + c];
+					}
+					acc += wy[j] * row;
+				}
+				dst[((size_t)y * dw + x) * ch + c] = acc;
+			}
+		}
+	}
+}
+
 std::string dirname_of(const std::string& p) { const size_t k = p.find_last_of('/'); return k == std::string::npos ? "." : p.substr(0, k); }
 
 } // namespace
@@ -332,6 +388,7 @@ int main(int argc, char** argv) {
 	geti("--n-EstimationIters-external", o.estimationItersExternal); geti("--n-adapthalfwin", o.adaptHalfWin);
 	geti("--n-propagatehalfwin", o.propagateHalfWin); geti("--n-propagatestep", o.propagateStep);
 	getf("--n-photometric_flow", o.photometricFlow); getf("--depthweight", o.depthweight); getf("--normalweight", o.normalweight);
+	geti("--n-initTriangulate", o.initTriangulate); geti("--min-views-trust-point", o.minViewsTrustPoint);
 	geti("--device", o.device); geti("--batch", o.batch);
 	if (kv.count("--seed")) o.seed = (uint32_t)strtoul(kv["--seed"].c_str(), nullptr, 10);
 	for (const char* k : {"--n-opticalflow", "--n-viewspread", "--use-semantic", "--n-nOptimize", "--n-usegeoconsistency", "--n-usepartconsistency"})
@@ -398,14 +455,42 @@ int main(int argc, char** argv) {
 	prm.adapthalfwin = o.adaptHalfWin; prm.n_estimation_iters = o.estimationIters; prm.n_external_iters = o.estimationItersExternal;
 	prm.propagate_halfwin = o.propagateHalfWin; prm.propagate_step = o.propagateStep; prm.photometric_flow = o.photometricFlow; prm.seed = o.seed;
 
-	// initial maps: splat of the sparse points (SceneDensify.cpp:783-808), kept on the device between outer iterations
+	// initial maps (SceneDensify.cpp:772-812), kept on the device between outer iterations:
+	//   nMinViewsTrustPoint < 2      splat of the sparse points (SceneDensify.cpp:783-808)
+	//   initTriangulate != 0         Delaunay triangulation of the sparse points (DepthMapsData::InitDepthMap, DepthMap.cpp:1796-1936)
+	//   initTriangulate == 0         the previous (coarser) level's maps from the working folder, resized (SceneDensify.cpp:527-553)
 	for (uint32_t id : todo) {
 		ImageData& im = images[id];
 		std::vector<float> pts;
 		for (uint32_t idx : im.points) { pts.push_back(verts[idx].X[0]); pts.push_back(verts[idx].X[1]); pts.push_back(verts[idx].X[2]); }
 		const size_t n = (size_t)im.w * im.h;
 		std::vector<float> d(n), nn(3 * n, 0.f);
-		CHK(hcmvs_splat_init(ctx, id, pts.data(), (int32_t)im.points.size(), d.data(), nn.data(), &im.dMin, &im.dMax));
+		if (o.minViewsTrustPoint < 2) {
+			CHK(hcmvs_splat_init(ctx, id, pts.data(), (int32_t)im.points.size(), d.data(), nn.data(), &im.dMin, &im.dMax));
+		} else if (o.initTriangulate) {
+			CHK(hcmvs_triangulate_init(ctx, id, pts.data(), (int32_t)im.points.size(), 0.f, 1, d.data(), nn.data(), &im.dMin, &im.dMax));
+		} else {
+			char nm[64];
+			snprintf(nm, sizeof nm, "/depth%04u.dmap", id);
+			int pw = 0, ph = 0;
+			std::vector<float> pd, pn;
+			if (!load_dmap(o.workdir + nm, pw, ph, pd, pn)) { fprintf(stderr, "error: can not read the previous level's '%s%s'\n", o.workdir.c_str(), nm); return EXIT_FAILURE; }
+			if (o.verbosity > 2) printf("read  :  %s%s (%dx%d -> %dx%d)\n", o.workdir.c_str(), nm, pw, ph, im.w, im.h);
+			resize_cubic(pd, pw, ph, 1, d, im.w, im.h);
+			resize_cubic(pn, pw, ph, 3, nn, im.w, im.h);
+			// depth range of the resized map (SceneDensify.cpp:544-553; taken over the valid depths only, the cubic
+			// kernel overshoots next to holes and a non-positive bound would poison the random-depth range)
+			float lo = 3.402823466e+38f, hi = 0.f;
+			for (size_t k = 0; k < n; ++k) {
+				if (!(d[k] > 0.f)) { d[k] = 0.f; continue; }
+				lo = std::min(lo, d[k]); hi = std::max(hi, d[k]);
+				float* q = &nn[3 * k];
+				const float len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+				if (len > 0.f) { q[0] /= len; q[1] /= len; q[2] /= len; }
+			}
+			if (!(hi > 0.f)) { fprintf(stderr, "error: '%s%s' holds no valid depth\n", o.workdir.c_str(), nm); return EXIT_FAILURE; }
+			im.dMin = lo * 0.9f; im.dMax = hi * 1.1f;
+		}
 		HIPOK(hipMalloc(&im.dDepth, n * 4)); HIPOK(hipMalloc(&im.dNormal, n * 12)); HIPOK(hipMalloc(&im.dConf, n * 4));
 		HIPOK(hipMemcpy(im.dDepth, d.data(), n * 4, hipMemcpyHostToDevice)); HIPOK(hipMemcpy(im.dNormal, nn.data(), n * 12, hipMemcpyHostToDevice));
 		HIPOK(hipMemset(im.dConf, 0, n * 4));

@@ -139,6 +139,18 @@ int hcmvs_get_stats(hcmvs_ctx* ctx, hcmvs_stats* out);
 int hcmvs_splat_init(hcmvs_ctx* ctx, uint32_t id, const float* points_xyz, int32_t n_points, float* depth,
                      float* normal, float* d_min, float* d_max);
 
+/* DepthMap.cpp:1796-1936 TriangulatePoints2DepthMap (the default initialisation, nMinViewsTrustPoint >= 2) as
+ * DepthMapsData::InitDepthMap uses it (SceneDensify.cpp:522-526): Delaunay-triangulate the projections of the sparse
+ * points seen by view `id`, add the four image corners as support points when add_corners != 0 (OPTDENSE::bAddCorners;
+ * their depth = distance-weighted mean of the three closest faces), rasterise one plane per face into host maps
+ * depth (w*h) / normal (w*h*3, camera space); returns the depth range (min*0.9, max*1.1).  avg_depth <= 0: mean depth
+ * of the points (Scene.cpp:565-603).  Host-side helper; hcmvs_triangulate_points is the same without a context. */
+int hcmvs_triangulate_init(hcmvs_ctx* ctx, uint32_t id, const float* points_xyz, int32_t n_points, float avg_depth,
+                           int32_t add_corners, float* depth, float* normal, float* d_min, float* d_max);
+int hcmvs_triangulate_points(int32_t width, int32_t height, const double K[9], const double R[9], const double C[3],
+                             const float* points_xyz, int32_t n_points, float avg_depth, int32_t add_corners, float* depth,
+                             float* normal, float* d_min, float* d_max);
+
 /* ---- filter and fuse: work on the estimated maps registered per view ------------------------------------ */
 
 /* register the maps of view `id` (host buffers are copied).  normal may be NULL.  d_min/d_max: the depth range

@@ -103,3 +103,59 @@ def test_densify_driver_resolution_level_and_errors(tmp_path):
     assert r.returncode != 0 and "can not load" in r.stderr
     r = subprocess.run([EXE], capture_output=True, text=True)
     assert r.returncode != 0 and "usage" in r.stderr
+
+
+def _accuracy(tmp, views, thr=0.01):
+    acc = []
+    for i, v in enumerate(views):
+        dm = mvsio.read_dmap(os.path.join(tmp, "depth%04d.dmap" % i))
+        m = dm["depth"] > 0
+        gt = v["depth"]
+        if dm["depth"].shape != gt.shape:
+            return None
+        acc.append(float(((np.abs(dm["depth"] - gt) / gt < thr) & m).mean()))
+    return float(np.mean(acc))
+
+
+@pytest.mark.gpu
+def test_densify_driver_coarse_to_fine_handoff(tmp_path):
+    """SURVEY.md 8f row F3 (reference SceneDensify.cpp:527-553, --n-initTriangulate 0): a coarse run leaves its depth maps
+    in the working folder, the next finer run starts from them (cubic resize) instead of the sparse points"""
+    tmp = str(tmp_path)
+    scene, views = make_scene(tmp, w=384, h=256, n_views=5)
+    common = ["--number-views", "4", "--fusion-mode", "1", "--n-EstimationIters-external", "1", "-v", "3"]
+    r = subprocess.run([EXE, "-i", scene, "--resolution-level", "1", "--n-EstimationIters", "4"] + common, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert mvsio.read_dmap(os.path.join(tmp, "depth0000.dmap"))["depth"].shape == (128, 192)
+    r = subprocess.run([EXE, "-i", scene, "--resolution-level", "0", "--n-initTriangulate", "0", "--n-EstimationIters", "1"] + common,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "read  :" in r.stdout
+    handoff = _accuracy(tmp, views)
+    # the same single fine sweep started from the triangulated sparse points
+    r = subprocess.run([EXE, "-i", scene, "--resolution-level", "0", "--n-initTriangulate", "1", "--n-EstimationIters", "1"] + common,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    tri = _accuracy(tmp, views)
+    assert handoff is not None and handoff > 0.7 and handoff >= tri - 0.02
+    # missing previous level -> clean error
+    for f in os.listdir(tmp):
+        if f.endswith(".dmap"):
+            os.remove(os.path.join(tmp, f))
+    r = subprocess.run([EXE, "-i", scene, "--resolution-level", "0", "--n-initTriangulate", "0"] + common, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "previous level" in r.stderr
+
+
+@pytest.mark.gpu
+def test_densify_driver_init_modes(tmp_path):
+    """triangulated init (default, DepthMap.cpp:1796-1936) vs splat init (nMinViewsTrustPoint < 2, SceneDensify.cpp:783-808)"""
+    tmp = str(tmp_path)
+    scene, views = make_scene(tmp, w=256, h=192, n_views=4)
+    common = ["--resolution-level", "0", "--number-views", "3", "--fusion-mode", "1", "--n-EstimationIters", "2", "--n-EstimationIters-external", "1"]
+    acc = {}
+    for name, extra in (("tri", []), ("splat", ["--min-views-trust-point", "1"])):
+        r = subprocess.run([EXE, "-i", scene] + common + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        acc[name] = _accuracy(tmp, views)
+    assert acc["tri"] > 0.6 and acc["splat"] > 0.3
+    assert acc["tri"] >= acc["splat"] - 0.02      # a full rough surface is at least as good a start as isolated splats
