@@ -102,7 +102,8 @@ def sparse_points(views, n, seed=5):
     v = views[0]
     rng = np.random.RandomState(seed)
     h, w = v['depth'].shape
-    xs = rng.randint(8, w - 8, n); ys = rng.randint(8, h - 8, n)
+    mx, my = min(8, (w - 1) // 2), min(8, (h - 1) // 2)  # margin; small test images still get points
+    xs = rng.randint(mx, max(mx + 1, w - mx), n); ys = rng.randint(my, max(my + 1, h - my), n)
     z = v['depth'][ys, xs].astype(np.float64)
     K = v['K']
     Xc = np.stack([(xs - K[0, 2]) * z / K[0, 0], (ys - K[1, 2]) * z / K[1, 1], z], -1)

@@ -147,3 +147,91 @@ def test_batch_of_reference_images_bit_exact(ctx):
     assert st.evals == sum(w[3] for w in wants)
     for (td, tn, tc), w in zip(keep, wants):
         _compare((td.cpu().numpy(), tn.cpu().numpy(), tc.cpu().numpy()), w[:3])
+
+
+def _batch_run(ctx, torch, scenes, pg, seed_offsets, refs=None):
+    """estimate every scene's view 0 (or refs[i]) in ONE batch call; returns the device maps as numpy triples"""
+    dev = torch.device("cuda:0")
+    items, keep = [], []
+    vid = 1000
+    for si, (views, pts) in enumerate(scenes):
+        ids = list(range(vid, vid + len(views)))
+        for i, v in zip(ids, views):
+            ctx.upload_view(i, v["gray"], v["K"], v["R"], v["C"])
+        vid += len(views)
+        ref = ids[0]
+        d0, n0, dmin, dmax = ctx.splat_init(ref, pts)
+        td = torch.from_numpy(d0).to(dev); tn = torch.from_numpy(n0).to(dev); tc = torch.zeros_like(td)
+        keep.append((td, tn, tc, d0, n0, dmin, dmax))
+        items.append(dict(ref_id=ref, src_ids=ids[1:], d_min=dmin, d_max=dmax, d_depth=td.data_ptr(), d_normal=tn.data_ptr(),
+                          d_conf=tc.data_ptr(), seed_offset=seed_offsets[si]))
+    torch.cuda.synchronize()
+    ctx.estimate_batch_device(items, pg)
+    ctx.synchronize()
+    return [(k[0].cpu().numpy(), k[1].cpu().numpy(), k[2].cpu().numpy()) for k in keep], keep
+
+
+def test_batch_more_than_eight_views_and_cross_pattern(ctx):
+    """the S = 4 lane layout (9..16 source views, two patch columns per segment) and the outer-iteration cross pattern
+    inside a batch: every item equals the oracle bit for bit"""
+    torch = pytest.importorskip("torch")
+    scenes = [_scene(88, 72, 90.0, 10, seed=41), _scene(88, 72, 90.0, 10, seed=42), _scene(72, 88, 90.0, 10, seed=43)]
+    pg, po = _params(adapthalfwin=6, n_estimation_iters=2, seed=77, it_external=1, n_external_iters=3, propagate_halfwin=5,
+                     propagate_step=2)
+    got, keep = _batch_run(ctx, torch, scenes, pg, [0, 5, 9])
+    for si, ((views, pts), g, k) in enumerate(zip(scenes, got, keep)):
+        po.seed = 77 + [0, 5, 9][si]
+        want = O.estimate(views, po, k[5], k[6], k[3], k[4])
+        _compare(g, want[:3])
+
+
+def test_ragged_and_minimum_sizes(ctx):
+    """odd image sizes down to the smallest image that still has pixels inside the 7 px border"""
+    with pytest.raises(binding.HcmvsError):   # nothing left inside the border
+        ctx.upload_view(0, np.zeros((15, 15), np.float32), np.eye(3), np.eye(3), np.zeros(3))
+    for (w, h, seed) in ((16, 16, 51), (17, 31, 52), (129, 16, 53)):
+        views, pts = _scene(w, h, 60.0, 2, seed=seed, n_pts=10)
+        _upload(ctx, views)
+        d0, n0, dmin, dmax = ctx.splat_init(0, pts)
+        pg, po = _params(adapthalfwin=6, n_estimation_iters=2, seed=9)
+        got = ctx.estimate(0, [1, 2], pg, dmin, dmax, d0, n0)
+        want = O.estimate(views, po, dmin, dmax, d0, n0)
+        _compare(got, want[:3])
+        assert (got[0][:7] == 0).all() and (got[0][:, :7] == 0).all()   # the fixed border stays empty (DepthMap.cpp:442-447)
+
+
+def test_full_size_schedule_invariance():
+    """BASELINE.json configs[1] at full size (1920x1080, 8 source views, 7x7): the oracle cannot run this in seconds, so
+    parity is shown through properties that do not depend on the size -- the maps must not depend on how the rows are
+    scheduled (one image alone with two waves per row == the same image inside a batch with one wave per row and XCD
+    affinity), the evaluation count per pixel-sweep is the algorithm's (2 propagations + 6 refinements, fewer where a
+    neighbour is already good), and the result converges to the analytic ground truth."""
+    torch = pytest.importorskip("torch")
+    c = binding.Context(0)
+    try:
+        W, H = 1920, 1080
+        scenes = [_scene(W, H, 1600.0, 8, seed=61, n_pts=2000), _scene(W, H, 1600.0, 8, seed=62, n_pts=2000),
+                  _scene(W, H, 1600.0, 8, seed=63, n_pts=2000)]
+        pg = binding.default_params(adapthalfwin=6, n_estimation_iters=3, seed=4321)
+        got3, keep = _batch_run(c, torch, scenes, pg, [0, 1, 2])
+        evals3 = c.stats().evals
+        # item 1 alone (two waves per row, no interleaving)
+        views, pts = scenes[1]
+        k = keep[1]
+        pg1 = binding.default_params(adapthalfwin=6, n_estimation_iters=3, seed=4321 + 1)
+        ids = list(range(1000 + 9, 1000 + 18))
+        alone = c.estimate(ids[0], ids[1:], pg1, k[5], k[6], k[3], k[4])
+        evals1 = c.stats().evals
+        for g, a, n in zip(got3[1], alone, ("depth", "normal", "conf")):
+            assert np.array_equal(g, a), n
+        P = (W - 14) * (H - 14)
+        per_px_sweep = (evals1 / P - 1) / 3
+        assert 6.5 < per_px_sweep <= 8.0
+        assert abs(evals3 / 3 - evals1) / evals1 < 0.05
+        d = alone[0]
+        valid = d > 0
+        gt = views[0]["depth"]
+        assert valid.mean() > 0.85
+        assert (np.abs(d - gt)[valid] / gt[valid] < 0.01).mean() > 0.9
+    finally:
+        c.close()
