@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 		const int itemIdx = __builtin_amdgcn_readfirstlane(sh.item);
 		if (itemIdx < 0) break;
 		const int r = __builtin_amdgcn_readfirstlane(sh.row);
-		const EstConst c = items[itemIdx];
+		const EstConst& c = items[itemIdx];
 		const int nrows = c.H - 2 * kHalfWindow, ncols = c.W - 2 * kHalfWindow;
 		(void)nrows;
 		LaneCtx<S> L;
