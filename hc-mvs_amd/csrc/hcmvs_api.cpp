@@ -431,7 +431,8 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 	HIPCHK(c, hipSetDevice(c->device));
 	int maxRows = 0, totalRows = 0;
 	for (int i = 0; i < n_items; ++i) {
-		if (items[i].n_src != items[0].n_src) return fail(c, HCMVS_ERR_INVALID, "estimate: all items of a batch must use the same number of source views");
+		if (items[i].n_src < 1 || items[i].n_src > kMaxViews || hcmvs::segments_for(items[i].n_src) != hcmvs::segments_for(items[0].n_src))
+			return fail(c, HCMVS_ERR_INVALID, "estimate: the items of a batch must use source-view counts of one class (1, 2, 3-4, 5-8 or 9-16)");
 		int rc = build_item(c, i, items[i], p, c->hItems[i]);
 		if (rc) return rc;
 		const int rows = c->hItems[i].H - 2 * kHalfWindow;

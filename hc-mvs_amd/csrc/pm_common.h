@@ -50,6 +50,9 @@ struct SweepSync {
 	unsigned long long* evals;  // [0] ScorePixel calls of the sequential algorithm, [1] evaluations issued (incl. speculative), [2] patch taps of [0]
 };
 
+// lanes per view group for V source views (64 / views-per-wave): 1 -> 64, 2 -> 32, 3..4 -> 16, 5..8 -> 8, 9..16 -> 4
+int segments_for(int V);
+
 // launch wrappers (pm_kernels.hip)
 void launch_gray_to_u8(const float* gray, uint8_t* out, int n, hipStream_t s);
 void launch_bgr_to_u8(const uint8_t* bgr, uint8_t* out, int n, hipStream_t s);

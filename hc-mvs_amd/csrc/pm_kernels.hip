@@ -1379,7 +1379,7 @@ void debug_read_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
-static inline int segments_for(int V) { return V <= 1 ? 64 : (V <= 2 ? 32 : (V <= 4 ? 16 : (V <= 8 ? 8 : 4))); }
+int segments_for(int V) { return V <= 1 ? 64 : (V <= 2 ? 32 : (V <= 4 ? 16 : (V <= 8 ? 8 : 4))); }
 
 void launch_gray_to_u8(const float* gray, uint8_t* out, int n, hipStream_t s) {
 	hipLaunchKernelGGL(gray_to_u8_kernel, dim3(2048), dim3(256), 0, s, gray, out, n);

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdint>
 #include <map>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -31,35 +32,79 @@ inline long double in_circle(const P3& a, const P3& b, const P3& c, const P3& d)
 	return (ax * ax + ay * ay) * (bx * cy - cx * by) - (bx * bx + by * by) * (ax * cy - cx * ay) + (cx * cx + cy * cy) * (ax * by - bx * ay);
 }
 
-// Delaunay triangulation of pts[4..) inside the rectangle spanned by pts[0..4) (already in the list, counter-clockwise)
-void bowyer_watson(const std::vector<P3>& pts, std::vector<Tri>& tris) {
-	tris.clear();
-	tris.push_back({{0, 1, 2}});
-	tris.push_back({{0, 2, 3}});
-	std::vector<int> bad;
-	std::vector<std::pair<int, int>> edges;
-	for (int p = 4; p < (int)pts.size(); ++p) {
-		bad.clear();
-		for (int t = 0; t < (int)tris.size(); ++t)
-			if (in_circle(pts[tris[t].v[0]], pts[tris[t].v[1]], pts[tris[t].v[2]], pts[p]) > 0) bad.push_back(t);
-		if (bad.empty()) continue; // numerically on a circle of every candidate: leave the point out
-		edges.clear();
-		for (int t : bad)
-			for (int e = 0; e < 3; ++e) {
-				const int a = tris[t].v[e], b = tris[t].v[(e + 1) % 3];
-				bool shared = false;
-				for (int u : bad) {
-					if (u == t) continue;
-					for (int f = 0; f < 3 && !shared; ++f) shared = tris[u].v[f] == b && tris[u].v[(f + 1) % 3] == a;
-					if (shared) break;
-				}
-				if (!shared) edges.push_back({a, b});
-			}
-		// drop the cavity (from the back, so the indices stay valid) and fan the new point to its boundary
-		for (size_t k = bad.size(); k-- > 0;) { tris[bad[k]] = tris.back(); tris.pop_back(); }
-		for (const auto& e : edges)
-			if (orient(pts[e.first], pts[e.second], pts[p]) > 0) tris.push_back({{e.first, e.second, p}}); // skips flat fans on the border
+// Delaunay triangulation of pts[4..) inside the rectangle spanned by pts[0..4) (already in the list, counter-clockwise).
+// Incremental Bowyer-Watson: the points go in along a serpentine grid order, the triangle holding a point is found by
+// a visibility walk from the last triangle made, the cavity by a flood fill over edge neighbours.
+void bowyer_watson(const std::vector<P3>& pts, std::vector<Tri>& out) {
+	struct T3 { int v[3]; bool alive; };
+	std::vector<T3> tris;
+	std::unordered_map<uint64_t, int> owner; // directed edge a->b  ->  the (counter-clockwise) triangle that has it
+	auto key = [](int a, int b) { return ((uint64_t)(uint32_t)a << 32) | (uint32_t)b; };
+	auto add = [&](int a, int b, int c) {
+		const int t = (int)tris.size();
+		tris.push_back({{a, b, c}, true});
+		owner[key(a, b)] = t; owner[key(b, c)] = t; owner[key(c, a)] = t;
+		return t;
+	};
+	add(0, 1, 2); add(0, 2, 3);
+	const int n = (int)pts.size();
+	std::vector<int> order;
+	for (int i = 4; i < n; ++i) order.push_back(i);
+	{ // serpentine order over a grid of ~sqrt(n) cells per side keeps consecutive insertions close to each other
+		const double x0 = pts[0].x, y0 = pts[0].y, w = pts[2].x - pts[0].x, h = pts[2].y - pts[0].y;
+		const int g = std::max(1, (int)std::sqrt((double)n / 2));
+		auto cell = [&](int i) {
+			const int cx = std::min(g - 1, std::max(0, (int)((pts[i].x - x0) / w * g))), cy = std::min(g - 1, std::max(0, (int)((pts[i].y - y0) / h * g)));
+			return cy * g + ((cy & 1) ? g - 1 - cx : cx);
+		};
+		std::stable_sort(order.begin(), order.end(), [&](int l, int r) { return cell(l) < cell(r); });
 	}
+	std::vector<int> cavity, stack;
+	std::vector<std::pair<int, int>> edges;
+	std::vector<char> bad;
+	int last = 1;
+	for (int p : order) {
+		// visibility walk to the triangle that holds p
+		int t = last;
+		while (!tris[t].alive) --t;
+		for (int guard = 0; guard < (int)tris.size() + 8; ++guard) {
+			bool moved = false;
+			for (int e = 0; e < 3 && !moved; ++e) {
+				const int a = tris[t].v[e], b = tris[t].v[(e + 1) % 3];
+				if (orient(pts[a], pts[b], pts[p]) < 0) {
+					auto it = owner.find(key(b, a));
+					if (it != owner.end()) { t = it->second; moved = true; }
+				}
+			}
+			if (!moved) break;
+		}
+		if (!(in_circle(pts[tris[t].v[0]], pts[tris[t].v[1]], pts[tris[t].v[2]], pts[p]) > 0)) continue; // numerically degenerate: leave it out
+		// flood fill the cavity: triangles whose circumcircle holds p
+		bad.assign(tris.size(), 0);
+		cavity.clear(); stack.clear(); edges.clear();
+		stack.push_back(t); bad[t] = 1;
+		while (!stack.empty()) {
+			const int u = stack.back(); stack.pop_back();
+			cavity.push_back(u);
+			for (int e = 0; e < 3; ++e) {
+				const int a = tris[u].v[e], b = tris[u].v[(e + 1) % 3];
+				auto it = owner.find(key(b, a));
+				if (it == owner.end()) { edges.push_back({a, b}); continue; } // hull edge
+				const int g = it->second;
+				if (bad[g] == 1) continue;
+				if (bad[g] == 0 && in_circle(pts[tris[g].v[0]], pts[tris[g].v[1]], pts[tris[g].v[2]], pts[p]) > 0) { bad[g] = 1; stack.push_back(g); }
+				else { bad[g] = 2; edges.push_back({a, b}); }
+			}
+		}
+		for (int u : cavity) {
+			tris[u].alive = false;
+			for (int e = 0; e < 3; ++e) owner.erase(key(tris[u].v[e], tris[u].v[(e + 1) % 3]));
+		}
+		for (const auto& e : edges)
+			if (orient(pts[e.first], pts[e.second], pts[p]) > 0) last = add(e.first, e.second, p); // skips flat fans on the border
+	}
+	out.clear();
+	for (const T3& t : tris) if (t.alive) out.push_back({{t.v[0], t.v[1], t.v[2]}});
 }
 
 inline void i2c(const double* K, double x, double y, double z, double* o) { // Camera.h:306-312

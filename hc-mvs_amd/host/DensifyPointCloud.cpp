@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -367,7 +368,10 @@ std::string dirname_of(const std::string& p) { const size_t k = p.find_last_of('
 #define CHK(call) do { const int rc_ = (call); if (rc_ != HCMVS_OK) { fprintf(stderr, "error: %s -> %d (%s)\n", #call, rc_, hcmvs_last_error(ctx)); return EXIT_FAILURE; } } while (0)
 #define HIPOK(call) do { if ((call) != hipSuccess) { fprintf(stderr, "error: %s failed\n", #call); return EXIT_FAILURE; } } while (0)
 
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int main(int argc, char** argv) {
+	const double tStart = now_s();
 	Options o;
 	std::map<std::string, std::string> kv;
 	for (int i = 1; i < argc; ++i) {
@@ -437,6 +441,7 @@ int main(int argc, char** argv) {
 	}
 	if (o.verbosity > 1) printf("Scene loaded: %zu images (%u calibrated), %zu sparse points\n", images.size(), nValid, verts.size());
 
+	const double tLoaded = now_s();
 	hcmvs_ctx* ctx = nullptr;
 	if (hcmvs_create(o.device, &ctx) != HCMVS_OK) { fprintf(stderr, "error: no usable MI355X device (there is no CPU path)\n"); return EXIT_FAILURE; }
 	std::vector<uint32_t> todo;
@@ -495,11 +500,13 @@ int main(int argc, char** argv) {
 		HIPOK(hipMemcpy(im.dDepth, d.data(), n * 4, hipMemcpyHostToDevice)); HIPOK(hipMemcpy(im.dNormal, nn.data(), n * 12, hipMemcpyHostToDevice));
 		HIPOK(hipMemset(im.dConf, 0, n * 4));
 	}
+	const double tInit = now_s();
 	// outer iterations over all images (SceneDensify.cpp:3684), images of equal source count batched per launch
 	for (int it = 0; it < o.estimationItersExternal; ++it) {
 		prm.it_external = it;
 		std::map<size_t, std::vector<uint32_t>> byV;
-		for (uint32_t id : todo) byV[images[id].srcs.size()].push_back(id);
+		auto viewClass = [](size_t v) { return v <= 1 ? 1 : (v <= 2 ? 2 : (v <= 4 ? 4 : (v <= 8 ? 8 : 16))); }; // one kernel layout per class
+		for (uint32_t id : todo) byV[viewClass(images[id].srcs.size())].push_back(id);
 		for (auto& g : byV)
 			for (size_t b0 = 0; b0 < g.second.size(); b0 += (size_t)o.batch) {
 				std::vector<hcmvs_batch_item> items;
@@ -519,6 +526,14 @@ int main(int argc, char** argv) {
 						       itx.n_src, images[itx.ref_id].w, images[itx.ref_id].h, it, st.ms_total);
 			}
 	}
+	double pixels = 0;
+	for (uint32_t id : todo) pixels += (double)images[id].w * images[id].h;
+	CHK(hcmvs_synchronize(ctx));
+	const double tEstimated = now_s();
+	if (o.verbosity > 1)
+		printf("Depth-maps estimated: %zu images, %d outer x %d inner sweeps in %.2f s (%.2f Mpix/s per outer iteration); loading %.2f s, view selection + init %.2f s\n",
+		       todo.size(), o.estimationItersExternal, o.estimationIters, tEstimated - tInit,
+		       pixels * o.estimationItersExternal / (tEstimated - tInit) / 1e6, tLoaded - tStart, tInit - tLoaded);
 	// save the depth maps (raw 'DR'), register them for fusion
 	uint64_t capacity = 0;
 	for (uint32_t id : todo) {
@@ -537,6 +552,8 @@ int main(int argc, char** argv) {
 		CHK(hcmvs_set_neighbors(ctx, id, nb.data(), (int32_t)nb.size()));
 		capacity += (uint64_t)(n / 2);
 	}
+	const double tSaved = now_s();
+	if (o.verbosity > 1) printf("Depth-maps saved in %.2f s\n", tSaved - tEstimated);
 	if (o.fusionMode == 1 || todo.empty()) { hcmvs_destroy(ctx); return EXIT_SUCCESS; }
 	// fuse: best connected images first (SceneDensify.cpp:3285-3302)
 	std::vector<uint32_t> order(todo);
@@ -546,9 +563,11 @@ int main(int argc, char** argv) {
 	CHK(hcmvs_fuse(ctx, order.data(), (int32_t)order.size(), std::min<int>(o.numberViewsFuse, (int)images.size()), 0.01f, 25.f, o.depthweight,
 	               o.normalweight, capacity, xyz.data(), nrm.data(), bgr.data(), nviews.data(), &nPoints, &nDepths));
 	xyz.resize(nPoints * 3); nrm.resize(nPoints * 3); bgr.resize(nPoints * 3);
+	const double tFused = now_s();
 	if (o.verbosity > 1)
-		printf("Depth-maps fused and filtered: %zu depth-maps, %llu depths, %llu points (%d%%)\n", order.size(), (unsigned long long)nDepths,
-		       (unsigned long long)nPoints, nDepths ? (int)std::lround(100.0 * nPoints / nDepths) : 0);
+		printf("Depth-maps fused and filtered: %zu depth-maps, %llu depths, %llu points (%d%%) in %.2f s (%.2f Mpoints/s)\n", order.size(),
+		       (unsigned long long)nDepths, (unsigned long long)nPoints, nDepths ? (int)std::lround(100.0 * nPoints / nDepths) : 0, tFused - tSaved,
+		       nPoints / (tFused - tSaved) / 1e6);
 	const std::string base = o.output.substr(0, o.output.rfind('.'));
 	if (!save_mvs(o.output, platforms, mimages, xyz, nrm, bgr) || !save_ply(base + ".ply", xyz, nrm, bgr)) {
 		fprintf(stderr, "error: can not write the output files\n");

@@ -116,8 +116,8 @@ int hcmvs_estimate(hcmvs_ctx* ctx, uint32_t ref_id, const uint32_t* src_ids, int
 int hcmvs_estimate_device(hcmvs_ctx* ctx, uint32_t ref_id, const uint32_t* src_ids, int32_t n_src,
                           const hcmvs_params* params, float d_min, float d_max, float* d_depth, float* d_normal,
                           float* d_conf);
-/* A batch of independent EstimateDepthMap calls (different reference images, the same options and number of
- * source views) in ONE set of launches: the sweep kernel interleaves the rows of all items, so the images fill each
+/* A batch of independent EstimateDepthMap calls (different reference images, the same options, source-view counts
+ * of one class: 1, 2, 3-4, 5-8 or 9-16) in ONE set of launches: the sweep kernel interleaves the rows of all items, so the images fill each
  * other's wavefront ramps (the reference overlaps images with two worker threads, SceneDensify.cpp:3699).
  * Every item produces exactly the maps hcmvs_estimate_device would produce for it with seed + seed_offset.
  * 1 <= n_items <= HCMVS_MAX_BATCH. */

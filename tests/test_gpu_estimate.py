@@ -235,3 +235,16 @@ def test_full_size_schedule_invariance():
         assert (np.abs(d - gt)[valid] / gt[valid] < 0.01).mean() > 0.9
     finally:
         c.close()
+
+
+def test_batch_mixed_view_counts(ctx):
+    """items with 5, 7 and 8 source views share one launch (same lane layout class); 3 and 8 do not"""
+    torch = pytest.importorskip("torch")
+    scenes = [_scene(96, 80, 90.0, 5, seed=71), _scene(96, 80, 90.0, 8, seed=72), _scene(80, 96, 90.0, 7, seed=73)]
+    pg, po = _params(adapthalfwin=6, n_estimation_iters=2, seed=33)
+    got, keep = _batch_run(ctx, torch, scenes, pg, [0, 1, 2])
+    for si, ((views, pts), g, k) in enumerate(zip(scenes, got, keep)):
+        po.seed = 33 + si
+        _compare(g, O.estimate(views, po, k[5], k[6], k[3], k[4])[:3])
+    with pytest.raises(binding.HcmvsError):
+        _batch_run(ctx, torch, [_scene(96, 80, 90.0, 3, seed=74), _scene(96, 80, 90.0, 8, seed=75)], pg, [0, 1])
