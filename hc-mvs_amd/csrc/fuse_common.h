@@ -21,7 +21,7 @@ struct DevMap {
 	const float* conf;
 	const uint8_t* bgr;      // may be null
 	uint32_t* claim;         // SceneDensify.cpp:3313 arrDepthIdx: NO_ID or claimed
-	uint32_t* bid;           // lowest pending raster index projecting onto each pixel (fusion rounds)
+	unsigned long long* bid; // [2][w*h] fusion rounds: (~round tag, lowest pending raster index) bidding for each pixel, by round parity
 	const uint32_t* neighbors; // device array of image ids, decreasing importance
 	float dMin, dMax;
 };
@@ -31,11 +31,11 @@ void launch_fill_u64(unsigned long long* p, unsigned long long v, size_t n, hipS
 void launch_filter_splat(const DevMap& ref, const DevMap& nb, unsigned long long* key, hipStream_t s);
 void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsigned long long* keys, int adjust, int nMinViews,
                         int nMinViewsAdjust, float thr, float* newDepth, float* newConf, unsigned long long* counters, hipStream_t s);
-void launch_fuse_begin(const DevMap& A, uint32_t* pending, uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters, hipStream_t s);
-void launch_fuse_round(const DevMap& A, const DevMap* maps, const uint32_t* pending, const uint32_t* roundCnt, uint32_t* nextPending,
-                       uint32_t* nextCnt, uint32_t* decidedList, float* decidedDepth, uint32_t* decidedCnt, float* oxyz, float* onormal,
-                       uint8_t* obgr, uint32_t* onv, uint8_t* oflag, int nMinViewsFuse, float thDepth, float normalError,
-                       unsigned long long* counters, int blocks, hipStream_t s);
+void launch_fuse_begin(const DevMap& A, const DevMap* maps, uint32_t* pending, uint32_t* roundCnt, int32_t* targets, uint8_t* flag,
+                       unsigned long long* counters, hipStream_t s);
+void launch_fuse_pass(const DevMap& A, const DevMap* maps, uint32_t* list0, uint32_t* list1, const int32_t* targets, uint32_t* roundCnt, uint32_t* barrier,
+                      uint32_t ridBase, uint32_t roundCap, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
+                      int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, int blocks, hipStream_t s);
 size_t fuse_scan_temp_bytes(int n);
 void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,
                          float* onormal, uint8_t* obgr, uint32_t* onv, unsigned long long base, unsigned long long capacity, float* xyz,

@@ -13,9 +13,10 @@
  *     sequential rule "nearest wins, the later writer wins ties" exactly; the vote is embarrassingly
  *     parallel.  HBM-bound integer/float work, one thread per pixel, coalesced over the reference map.
  *   - Fuse: a pixel of image A interacts with other pixels of A only through the neighbour pixels it
- *     projects onto (its targets).  Per image pass, rounds of three small kernels pick, for every target,
- *     the lowest raster index still pending (atomicMin), let exactly the pixels that own all their targets
- *     run the reference's body, and reset.  Pixels sharing a target are therefore decided in raster order
+ *     projects onto (its targets).  One persistent kernel per image pass runs rounds separated by a grid
+ *     barrier: for every target the lowest raster index still pending holds the bid (64-bit atomicMin on
+ *     (round tag, index)); exactly the pixels that own all their targets run the reference's body, the
+ *     others bid again for the next round.  Pixels sharing a target are therefore decided in raster order
  *     and the cloud is identical to the sequential one, point order included (ordered compaction).
  *
  * Double precision follows the reference (Point3 = double); no contraction (-ffp-contract=off).
@@ -181,9 +182,25 @@ __device__ __forceinline__ void pixel_point(const DevMap& A, int idx, float dept
 	point[0] = (float)Xw[0]; point[1] = (float)Xw[1]; point[2] = (float)Xw[2];
 }
 
-// Rounds of one image pass work on device-side lists of pixel indices (their order is irrelevant: contention is
-// settled by the raster index itself): `pending` in, still-pending + decided out.  Round r reads its pixel count from
-// roundCnt[r] and appends to roundCnt[r + 1] / decidedCnt[r], so a group of rounds runs without the host in between.
+// ---- the image pass -----------------------------------------------------------------------------------------------
+// Pending pixels live in two device-side lists (their order is irrelevant: contention is settled by the raster index).
+// Bids are 64-bit keys (~round tag, raster index) in two arrays per map used alternately by round parity, so a bid of
+// a newer round always beats what an older round left behind and nothing has to be cleared:
+//   round r: a pending pixel that holds the bid of round r on all its targets is decided (the reference's body);
+//            the others bid for round r + 1 into the other array and stay on the list.  One grid barrier per round.
+// Everything another workgroup may have written in this launch (bids, claims, depths, the lists) is accessed with
+// agent-scope (sc1) atomics, which reach past the per-XCD L2; every wave drains its stores before the barrier.
+
+#define FS_SCOPE __HIP_MEMORY_SCOPE_AGENT
+typedef __attribute__((address_space(1))) uint32_t* g_u32p;
+typedef __attribute__((address_space(1))) unsigned long long* g_u64p;
+__device__ __forceinline__ uint32_t ld_u32(const uint32_t* p) { return __hip_atomic_load((g_u32p)p, __ATOMIC_RELAXED, FS_SCOPE); }
+__device__ __forceinline__ void st_u32(uint32_t* p, uint32_t v) { __hip_atomic_store((g_u32p)p, v, __ATOMIC_RELAXED, FS_SCOPE); }
+__device__ __forceinline__ float ld_f32(const float* p) { return __uint_as_float(ld_u32((const uint32_t*)p)); }
+__device__ __forceinline__ void st_f32(float* p, float v) { st_u32((uint32_t*)p, __float_as_uint(v)); }
+__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* p) { return __hip_atomic_load((g_u64p)p, __ATOMIC_RELAXED, FS_SCOPE); }
+__device__ __forceinline__ unsigned long long bid_key(uint32_t round, uint32_t idx) { return ((unsigned long long)(0xFFFFFFFFu - round) << 32) | idx; }
+
 __device__ __forceinline__ void list_append(bool pred, int value, uint32_t* list, uint32_t* count) { // one atomic per wave
 	const unsigned long long m = __ballot(pred);
 	if (!pred) return;
@@ -191,10 +208,13 @@ __device__ __forceinline__ void list_append(bool pred, int value, uint32_t* list
 	uint32_t base = 0;
 	if (lane == leader) base = atomicAdd(count, (uint32_t)__builtin_popcountll(m));
 	base = __shfl(base, leader, 64);
-	list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)value;
+	st_u32(&list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))], (uint32_t)value);
 }
 
-__global__ void fuse_begin_kernel(DevMap A, uint32_t* pending, uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters) {
+// also writes the targets of every pending pixel -- the pixel index it projects onto in each neighbour map, -1 for
+// none (SceneDensify.cpp:3387-3393) -- so that the rounds only chase indices
+__global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, uint32_t* pending, uint32_t* roundCnt, int32_t* targets, uint8_t* flag,
+                                  unsigned long long* counters) {
 	const int n = A.w * A.h;
 	unsigned nd = 0;
 	const int nPad = (n + 63) & ~63; // whole waves take part in list_append
@@ -207,155 +227,236 @@ __global__ void fuse_begin_kernel(DevMap A, uint32_t* pending, uint32_t* roundCn
 			}
 			flag[idx] = 0;
 		}
+		if (pend) {
+			float point[3];
+			pixel_point(A, idx, A.depth[idx], point);
+			for (int q = 0; q < A.nNeighbors; ++q) {
+				const DevMap& B = maps[A.neighbors[q]];
+				float ptz; int ib = -1, xB, yB;
+				if (!B.depth || !project_target(B, point, ptz, ib, xB, yB)) ib = -1;
+				targets[(size_t)idx * A.nNeighbors + q] = ib;
+			}
+		}
 		list_append(pend, idx, pending, roundCnt);
 	}
 	if (nd) atomicAdd(&counters[0], (unsigned long long)nd); // valid depths visited (SceneDensify.cpp:3359)
 }
 
-// every pending pixel bids (atomicMin of its raster index) for the neighbour pixels it projects onto
-__global__ void fuse_bid_kernel(DevMap A, const DevMap* maps, const uint32_t* pending, const uint32_t* roundCnt) {
-	const int n = (int)*roundCnt;
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const int idx = (int)pending[i];
-		float point[3];
-		pixel_point(A, idx, A.depth[idx], point);
-		for (int q = 0; q < A.nNeighbors; ++q) {
-			const DevMap& B = maps[A.neighbors[q]];
-			if (!B.depth) continue;
-			float ptz; int ib, xB, yB;
-			if (!project_target(B, point, ptz, ib, xB, yB)) continue;
-			atomicMin(&B.bid[ib], (unsigned)idx);
-		}
-	}
-}
-// the pixels decided in this round owned all their targets: clearing those restores "lowest pending index" once the
-// remaining pixels have bid again.  `point` is recomputed from the depth the pixel had when it bid (saved by decide).
-__global__ void fuse_unbid_kernel(DevMap A, const DevMap* maps, const uint32_t* decided, const float* decidedDepth, const uint32_t* decidedCnt) {
-	const int n = (int)*decidedCnt;
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const int idx = (int)decided[i];
-		float point[3];
-		pixel_point(A, idx, decidedDepth[i], point);
-		for (int q = 0; q < A.nNeighbors; ++q) {
-			const DevMap& B = maps[A.neighbors[q]];
-			if (!B.depth) continue;
-			float ptz; int ib, xB, yB;
-			if (!project_target(B, point, ptz, ib, xB, yB)) continue;
-			B.bid[ib] = NO_ID;
-		}
-	}
-}
-
 struct FuseOut { // per pixel of the current image, compacted in raster order afterwards
 	float* xyz; float* normal; uint8_t* bgr; uint32_t* nviews; uint8_t* flag;
 };
+struct FusePass {
+	uint32_t* list[2];       // pending pixels, alternating by round parity
+	const int32_t* targets;  // [w*h][nNeighbors] of A, see fuse_begin_kernel
+	uint32_t* roundCnt;      // [kRoundCap + 1] pending pixels at the start of round r
+	uint32_t* barrier;       // [0] arrivals, [1] error flag, [2] rounds used
+	uint32_t ridBase;        // round tag of round 0 of this pass
+	uint32_t roundCap;
+	uint32_t tailCount;      // once this few pixels are pending, workgroup 0 finishes the pass alone (block barriers)
+	int nMinViewsFuse; float thDepth, normalError;
+};
 
-__global__ void fuse_decide_kernel(DevMap A, const DevMap* maps, const uint32_t* pending, const uint32_t* roundCnt, uint32_t* nextPending,
-                                   uint32_t* nextCnt, uint32_t* decidedList, float* decidedDepth, uint32_t* decidedCnt, FuseOut out,
-                                   int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters) {
-	const int n = (int)*roundCnt;
-	const int nPad = (n + 63) & ~63;
-	unsigned accepted = 0;
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nPad; i += gridDim.x * blockDim.x) {
-		const bool have = i < n;
-		const int idx = have ? (int)pending[i] : 0;
-		bool ready = have;
-		const float depth = have ? A.depth[idx] : 0.f;
-		float point[3] = {0.f, 0.f, 0.f};
-		if (have) {
-			pixel_point(A, idx, depth, point);
-			// do I own every target?  (then no lower raster index is still undecided on any of them)
-			for (int q = 0; q < A.nNeighbors && ready; ++q) {
-				const DevMap& B = maps[A.neighbors[q]];
-				if (!B.depth) continue;
-				float ptz; int ib, xB, yB;
-				if (!project_target(B, point, ptz, ib, xB, yB)) continue;
-				ready = B.bid[ib] == (unsigned)idx;
-			}
-		}
-		list_append(have && !ready, idx, nextPending, nextCnt);
-		{ // decided pixels: remember them (and the depth they bid with) for fuse_unbid_kernel
-			const unsigned long long m = __ballot(ready);
-			if (ready) {
-				const int lane = threadIdx.x & 63, leader = __builtin_ctzll(m);
-				uint32_t base = 0;
-				if (lane == leader) base = atomicAdd(decidedCnt, (uint32_t)__builtin_popcountll(m));
-				base = __shfl(base, leader, 64);
-				const uint32_t o = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-				decidedList[o] = (uint32_t)idx; decidedDepth[o] = depth;
-			}
-		}
-		if (!ready) continue;
-		// the reference's body, SceneDensify.cpp:3364-3450
-		uint32_t vimg[kFuseMaxViews]; int vpix[kFuseMaxViews]; int nv = 0;
-		vimg[nv] = A.id; vpix[nv] = idx; ++nv;
-		double confidence = (double)conf2weight(A.conf[idx], depth);
-		float normal[3] = {0.f, 0.f, -1.f};
-		if (A.normal) {
-			const float* nm = A.normal + 3 * (size_t)idx;
-#pragma unroll
-			for (int k = 0; k < 3; ++k) normal[k] = (float)(A.R[0 * 3 + k] * (double)nm[0] + A.R[1 * 3 + k] * (double)nm[1] + A.R[2 * 3 + k] * (double)nm[2]);
-		}
-		double X[3] = {(double)point[0] * confidence, (double)point[1] * confidence, (double)point[2] * confidence};
-		float Cc[3] = {0.f, 0.f, 0.f}, Nn[3];
-		if (A.bgr) for (int k = 0; k < 3; ++k) Cc[k] = (float)A.bgr[3 * (size_t)idx + k] * (float)confidence;
-		for (int k = 0; k < 3; ++k) Nn[k] = normal[k] * (float)confidence;
-		uint32_t invImg[kFuseMaxViews]; int invPix[kFuseMaxViews]; int ninv = 0;
-		for (int q = 0; q < A.nNeighbors; ++q) {
-			const uint32_t Bid = A.neighbors[q];
-			const DevMap& B = maps[Bid];
-			if (!B.depth) continue;
-			float ptz; int ib, xB, yB;
-			if (!project_target(B, point, ptz, ib, xB, yB)) continue;
-			const float depthB = B.depth[ib];
-			if (depthB == 0.f) continue;
-			if (B.claim[ib] != NO_ID) continue;
-			if (is_depth_similar(ptz, depthB, thDepth)) {
-				float normalB[3] = {0.f, 0.f, -1.f};
-				if (B.normal) {
-					const float* nm = B.normal + 3 * (size_t)ib;
-#pragma unroll
-					for (int k = 0; k < 3; ++k) normalB[k] = (float)(B.R[0 * 3 + k] * (double)nm[0] + B.R[1 * 3 + k] * (double)nm[1] + B.R[2 * 3 + k] * (double)nm[2]);
-				}
-				if (normal[0] * normalB[0] + normal[1] * normalB[1] + normal[2] * normalB[2] > normalError) {
-					const float confB = conf2weight(B.conf[ib], depthB);
-					int pos = nv;
-					while (pos > 0 && vimg[pos - 1] > Bid) { vimg[pos] = vimg[pos - 1]; vpix[pos] = vpix[pos - 1]; --pos; }
-					vimg[pos] = Bid; vpix[pos] = ib; ++nv;
-					B.claim[ib] = 0u;
-					double XB[3];
-					i2w(B, (double)xB, (double)yB, (double)depthB, XB);
-					for (int k = 0; k < 3; ++k) X[k] += XB[k] * (double)confB;
-					if (B.bgr) for (int k = 0; k < 3; ++k) Cc[k] += (float)B.bgr[3 * (size_t)ib + k] * confB;
-					for (int k = 0; k < 3; ++k) Nn[k] += normalB[k] * confB;
-					confidence += (double)confB;
-					continue;
-				}
-			}
-			if (ptz < depthB) { invImg[ninv] = Bid; invPix[ninv] = ib; ++ninv; }
-		}
-		if (nv < nMinViewsFuse) {
-			for (int v = 0; v < nv; ++v) maps[vimg[v]].claim[vpix[v]] = NO_ID;
-		} else {
-			A.claim[idx] = 0u;
-			const double nrm = 1.0 / confidence;
-			for (int k = 0; k < 3; ++k) out.xyz[3 * (size_t)idx + k] = (float)(X[k] * nrm);
-			if (out.bgr) for (int k = 0; k < 3; ++k) {
-				const int r = (int)floorf(Cc[k] * (float)nrm + .5f);
-				out.bgr[3 * (size_t)idx + k] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
-			}
-			if (out.normal) {
-				const float n0 = Nn[0] * (float)nrm, n1 = Nn[1] * (float)nrm, n2 = Nn[2] * (float)nrm;
-				const float len = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
-				out.normal[3 * (size_t)idx] = n0 / len; out.normal[3 * (size_t)idx + 1] = n1 / len; out.normal[3 * (size_t)idx + 2] = n2 / len;
-			}
-			out.nviews[idx] = (uint32_t)nv;
-			out.flag[idx] = 1;
-			++accepted;
-			for (int v = 0; v < ninv; ++v) maps[invImg[v]].depth[invPix[v]] = 0.f;
+// all workgroups of the launch are resident (grid <= number of CUs): arrive, then wait for everybody
+__device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t& target) {
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // my wave's stores are out
+	__syncthreads();
+	__shared__ int failed;
+	if (threadIdx.x == 0) {
+		failed = 0;
+		__hip_atomic_fetch_add((g_u32p)bar, 1u, __ATOMIC_RELAXED, FS_SCOPE);
+		unsigned spins = 0;
+		while (ld_u32(bar) < target) {
+			__builtin_amdgcn_s_sleep(1);
+			if ((++spins & 1023u) == 0u && (ld_u32(bar + 1) != 0u || spins > (1u << 24))) { st_u32(bar + 1, 1u); failed = 1; break; }
 		}
 	}
+	__syncthreads();
+	target += gridDim.x;
+	return failed == 0;
+}
+
+// The neighbour maps' descriptors are staged in LDS once per launch and every per-pixel loop over the neighbours is
+// chunked: first the projections of a chunk, then all its loads back to back, then the (sequential) logic -- a round
+// then costs a couple of memory round trips instead of one per neighbour and table level.
+constexpr int kFuseChunk = 4;
+
+// MAXV: capacity of the per-pixel view lists (the image itself + its neighbours); 16 covers the reference's cap of 12
+// neighbours (nMaxViews, DepthMap.cpp:73) with half the registers of the general 32
+template <int MAXV>
+__global__ __launch_bounds__(256) void fuse_pass_kernel(DevMap A, const DevMap* maps, FusePass fp, FuseOut out, unsigned long long* counters) {
+	__shared__ DevMap nbs[MAXV - 1];
+	const int nNb = A.nNeighbors;
+	{
+		static_assert(sizeof(DevMap) % 4 == 0, "DevMap is copied word by word");
+		constexpr int words = (int)(sizeof(DevMap) / 4);
+		uint32_t* dst = (uint32_t*)nbs;
+		for (int i = threadIdx.x; i < nNb * words; i += blockDim.x) {
+			const int q = i / words, w = i - q * words;
+			dst[i] = ((const uint32_t*)&maps[A.neighbors[q]])[w];
+		}
+		__syncthreads();
+	}
+	const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gthreads = gridDim.x * blockDim.x;
+	uint32_t target = gridDim.x;
+	unsigned accepted = 0;
+	// round 0: everybody bids
+	{
+		const int n = (int)ld_u32(fp.roundCnt);
+		for (int i = gtid; i < n; i += gthreads) {
+			const int idx = (int)ld_u32(&fp.list[0][i]);
+			const unsigned long long key = bid_key(fp.ridBase, (uint32_t)idx);
+			const int32_t* tg = fp.targets + (size_t)idx * nNb;
+			for (int q = 0; q < nNb; ++q) {
+				const int ib = tg[q];
+				if (ib >= 0) atomicMin(&nbs[q].bid[ib], key);
+			}
+		}
+	}
+	if (!grid_barrier(fp.barrier, target)) return;
+	uint32_t r = 0;
+	bool tail = false; // workgroup 0 alone, block barriers
+	for (;; ++r) {
+		const int n = (int)ld_u32(fp.roundCnt + r);
+		if (n == 0 || r + 1 >= fp.roundCap) break;
+		if (!tail && (uint32_t)n <= fp.tailCount) {
+			if (blockIdx.x != 0) break; // every workgroup reads the same count: all but one leave together
+			tail = true;
+		}
+		const int tid = tail ? (int)threadIdx.x : gtid, nthreads = tail ? (int)blockDim.x : gthreads;
+		const size_t par = (size_t)(r & 1u), parNext = par ^ 1u;
+		const uint32_t* listIn = fp.list[par];
+		uint32_t* listOut = fp.list[parNext];
+		const int nPad = (n + 63) & ~63;
+		for (int i = tid; i < nPad; i += nthreads) {
+			const bool have = i < n;
+			const int idx = have ? (int)ld_u32(&listIn[i]) : 0;
+			bool ready = have;
+			const float depth = have ? A.depth[idx] : 0.f;
+			float point[3] = {0.f, 0.f, 0.f};
+			if (have) {
+				// do I hold this round's bid on every target?  (then no lower raster index is still undecided on any of them)
+				const unsigned long long key = bid_key(fp.ridBase + r, (uint32_t)idx);
+				const int32_t* tg = fp.targets + (size_t)idx * nNb;
+				for (int q0 = 0; q0 < nNb && ready; q0 += kFuseChunk) {
+					int ib[kFuseChunk];
+#pragma unroll
+					for (int j = 0; j < kFuseChunk; ++j) ib[j] = q0 + j < nNb ? tg[q0 + j] : -1;
+					unsigned long long got[kFuseChunk];
+#pragma unroll
+					for (int j = 0; j < kFuseChunk; ++j) got[j] = ib[j] >= 0 ? ld_u64(&nbs[q0 + j].bid[par * (size_t)nbs[q0 + j].w * nbs[q0 + j].h + ib[j]]) : key;
+#pragma unroll
+					for (int j = 0; j < kFuseChunk; ++j) ready = ready && got[j] == key;
+				}
+				if (!ready) { // bid for the next round
+					const unsigned long long nkey = bid_key(fp.ridBase + r + 1u, (uint32_t)idx);
+					for (int q = 0; q < nNb; ++q) {
+						const int ibq = tg[q];
+						if (ibq >= 0) atomicMin(&nbs[q].bid[parNext * (size_t)nbs[q].w * nbs[q].h + ibq], nkey);
+					}
+				} else {
+					pixel_point(A, idx, depth, point);
+				}
+			}
+			list_append(have && !ready, idx, listOut, fp.roundCnt + r + 1);
+			if (!ready) continue;
+			// the reference's body, SceneDensify.cpp:3364-3450
+			uint32_t vimg[MAXV]; int vpix[MAXV]; int nv = 0;
+			vimg[nv] = A.id; vpix[nv] = idx; ++nv;
+			double confidence = (double)conf2weight(A.conf[idx], depth);
+			float normal[3] = {0.f, 0.f, -1.f};
+			if (A.normal) {
+				const float* nm = A.normal + 3 * (size_t)idx;
+#pragma unroll
+				for (int k = 0; k < 3; ++k) normal[k] = (float)(A.R[0 * 3 + k] * (double)nm[0] + A.R[1 * 3 + k] * (double)nm[1] + A.R[2 * 3 + k] * (double)nm[2]);
+			}
+			double X[3] = {(double)point[0] * confidence, (double)point[1] * confidence, (double)point[2] * confidence};
+			float Cc[3] = {0.f, 0.f, 0.f}, Nn[3];
+			if (A.bgr) for (int k = 0; k < 3; ++k) Cc[k] = (float)A.bgr[3 * (size_t)idx + k] * (float)confidence;
+			for (int k = 0; k < 3; ++k) Nn[k] = normal[k] * (float)confidence;
+			uint32_t invImg[MAXV]; int invPix[MAXV]; int ninv = 0;
+			for (int q0 = 0; q0 < nNb; q0 += kFuseChunk) {
+				// what the chunk's targets hold (independent loads; a pixel only changes targets of its own, in other maps)
+				bool ok[kFuseChunk]; int ibs[kFuseChunk], xs[kFuseChunk], ys[kFuseChunk];
+				float ptzs[kFuseChunk], dB[kFuseChunk], cfB[kFuseChunk], nB[kFuseChunk][3];
+				uint32_t clB[kFuseChunk]; uint8_t colB[kFuseChunk][3];
+#pragma unroll
+				for (int j = 0; j < kFuseChunk; ++j) {
+					ok[j] = false; ibs[j] = 0; xs[j] = ys[j] = 0; ptzs[j] = 0.f;
+					if (q0 + j >= nNb) continue;
+					const DevMap& B = nbs[q0 + j];
+					if (!B.depth) continue;
+					ok[j] = project_target(B, point, ptzs[j], ibs[j], xs[j], ys[j]);
+				}
+#pragma unroll
+				for (int j = 0; j < kFuseChunk; ++j) {
+					dB[j] = 0.f; clB[j] = 0u; cfB[j] = 0.f; nB[j][0] = nB[j][1] = 0.f; nB[j][2] = -1.f; colB[j][0] = colB[j][1] = colB[j][2] = 0;
+					if (!ok[j]) continue;
+					const DevMap& B = nbs[q0 + j];
+					dB[j] = ld_f32(&B.depth[ibs[j]]);
+					clB[j] = ld_u32(&B.claim[ibs[j]]);
+					cfB[j] = B.conf[ibs[j]];
+					if (B.normal) { const float* nm = B.normal + 3 * (size_t)ibs[j]; nB[j][0] = nm[0]; nB[j][1] = nm[1]; nB[j][2] = nm[2]; }
+					if (B.bgr) { const uint8_t* cb = B.bgr + 3 * (size_t)ibs[j]; colB[j][0] = cb[0]; colB[j][1] = cb[1]; colB[j][2] = cb[2]; }
+				}
+#pragma unroll
+				for (int j = 0; j < kFuseChunk; ++j) {
+					if (!ok[j]) continue;
+					const DevMap& B = nbs[q0 + j];
+					const uint32_t Bid = B.id;
+					const int ib = ibs[j];
+					const float ptz = ptzs[j], depthB = dB[j];
+					if (depthB == 0.f) continue;
+					if (clB[j] != NO_ID) continue;
+					if (is_depth_similar(ptz, depthB, fp.thDepth)) {
+						float normalB[3] = {0.f, 0.f, -1.f};
+						if (B.normal) {
+#pragma unroll
+							for (int k = 0; k < 3; ++k) normalB[k] = (float)(B.R[0 * 3 + k] * (double)nB[j][0] + B.R[1 * 3 + k] * (double)nB[j][1] + B.R[2 * 3 + k] * (double)nB[j][2]);
+						}
+						if (normal[0] * normalB[0] + normal[1] * normalB[1] + normal[2] * normalB[2] > fp.normalError) {
+							const float confB = conf2weight(cfB[j], depthB);
+							int pos = nv;
+							while (pos > 0 && vimg[pos - 1] > Bid) { vimg[pos] = vimg[pos - 1]; vpix[pos] = vpix[pos - 1]; --pos; }
+							vimg[pos] = Bid; vpix[pos] = ib; ++nv;
+							st_u32(&B.claim[ib], 0u);
+							double XB[3];
+							i2w(B, (double)xs[j], (double)ys[j], (double)depthB, XB);
+							for (int k = 0; k < 3; ++k) X[k] += XB[k] * (double)confB;
+							if (B.bgr) for (int k = 0; k < 3; ++k) Cc[k] += (float)colB[j][k] * confB;
+							for (int k = 0; k < 3; ++k) Nn[k] += normalB[k] * confB;
+							confidence += (double)confB;
+							continue;
+						}
+					}
+					if (ptz < depthB) { invImg[ninv] = Bid; invPix[ninv] = ib; ++ninv; }
+				}
+			}
+			if (nv < fp.nMinViewsFuse) {
+				for (int v = 0; v < nv; ++v) st_u32(&maps[vimg[v]].claim[vpix[v]], NO_ID);
+			} else {
+				st_u32(&A.claim[idx], 0u);
+				const double nrm = 1.0 / confidence;
+				for (int k = 0; k < 3; ++k) out.xyz[3 * (size_t)idx + k] = (float)(X[k] * nrm);
+				if (out.bgr) for (int k = 0; k < 3; ++k) {
+					const int c8 = (int)floorf(Cc[k] * (float)nrm + .5f);
+					out.bgr[3 * (size_t)idx + k] = (uint8_t)(c8 < 0 ? 0 : (c8 > 255 ? 255 : c8));
+				}
+				if (out.normal) {
+					const float n0 = Nn[0] * (float)nrm, n1 = Nn[1] * (float)nrm, n2 = Nn[2] * (float)nrm;
+					const float len = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
+					out.normal[3 * (size_t)idx] = n0 / len; out.normal[3 * (size_t)idx + 1] = n1 / len; out.normal[3 * (size_t)idx + 2] = n2 / len;
+				}
+				out.nviews[idx] = (uint32_t)nv;
+				out.flag[idx] = 1;
+				++accepted;
+				for (int v = 0; v < ninv; ++v) st_f32(&maps[invImg[v]].depth[invPix[v]], 0.f);
+			}
+		}
+		if (tail) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); }
+		else if (!grid_barrier(fp.barrier, target)) return;
+	}
 	if (accepted) atomicAdd(&counters[3], (unsigned long long)accepted);
+	if (blockIdx.x == 0 && threadIdx.x == 0) st_u32(fp.barrier + 2, r);
 }
 
 // ordered compaction of the accepted pixels of one pass into the cloud
@@ -397,20 +498,21 @@ void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsig
                         int nMinViewsAdjust, float thr, float* newDepth, float* newConf, unsigned long long* counters, hipStream_t s) {
 	hipLaunchKernelGGL(filter_vote_kernel, kGrid, kBlock, 0, s, ref, nbs, N, keys, adjust, nMinViews, nMinViewsAdjust, thr, newDepth, newConf, counters);
 }
-void launch_fuse_begin(const DevMap& A, uint32_t* pending, uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, pending, roundCnt, flag, counters);
+void launch_fuse_begin(const DevMap& A, const DevMap* maps, uint32_t* pending, uint32_t* roundCnt, int32_t* targets, uint8_t* flag,
+                       unsigned long long* counters, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, pending, roundCnt, targets, flag, counters);
 }
-// one round: bid, decide (+ split the list), clear the bids of the decided pixels
-void launch_fuse_round(const DevMap& A, const DevMap* maps, const uint32_t* pending, const uint32_t* roundCnt, uint32_t* nextPending,
-                       uint32_t* nextCnt, uint32_t* decidedList, float* decidedDepth, uint32_t* decidedCnt, float* oxyz, float* onormal,
-                       uint8_t* obgr, uint32_t* onv, uint8_t* oflag, int nMinViewsFuse, float thDepth, float normalError,
-                       unsigned long long* counters, int blocks, hipStream_t s) {
+// the whole image pass in one persistent launch; `blocks` must not exceed the number of workgroups the device keeps
+// resident at once (the rounds are separated by a grid barrier)
+void launch_fuse_pass(const DevMap& A, const DevMap* maps, uint32_t* list0, uint32_t* list1, const int32_t* targets, uint32_t* roundCnt, uint32_t* barrier,
+                      uint32_t ridBase, uint32_t roundCap, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
+                      int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, int blocks, hipStream_t s) {
 	FuseOut out{oxyz, onormal, obgr, onv, oflag};
-	const dim3 g(blocks < 1 ? 1 : blocks);
-	hipLaunchKernelGGL(fuse_bid_kernel, g, kBlock, 0, s, A, maps, pending, roundCnt);
-	hipLaunchKernelGGL(fuse_decide_kernel, g, kBlock, 0, s, A, maps, pending, roundCnt, nextPending, nextCnt, decidedList, decidedDepth,
-	                   decidedCnt, out, nMinViewsFuse, thDepth, normalError, counters);
-	hipLaunchKernelGGL(fuse_unbid_kernel, g, kBlock, 0, s, A, maps, decidedList, decidedDepth, decidedCnt);
+	FusePass fp;
+	fp.list[0] = list0; fp.list[1] = list1; fp.targets = targets; fp.tailCount = 1024; fp.roundCnt = roundCnt; fp.barrier = barrier; fp.ridBase = ridBase; fp.roundCap = roundCap;
+	fp.nMinViewsFuse = nMinViewsFuse; fp.thDepth = thDepth; fp.normalError = normalError;
+	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_pass_kernel<16>, dim3(blocks), dim3(256), 0, s, A, maps, fp, out, counters);
+	else hipLaunchKernelGGL(fuse_pass_kernel<32>, dim3(blocks), dim3(256), 0, s, A, maps, fp, out, counters);
 }
 size_t fuse_scan_temp_bytes(int n) {
 	size_t bytes = 0;

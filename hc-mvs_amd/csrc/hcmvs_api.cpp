@@ -37,7 +37,8 @@ struct View {
 	float *mDepth = nullptr, *mNormal = nullptr, *mConf = nullptr;
 	bool mapsOwned = false;
 	float dMin = 0.f, dMax = 0.f;
-	uint32_t *claim = nullptr, *bid = nullptr, *dNeighbors = nullptr;
+	uint32_t *claim = nullptr, *dNeighbors = nullptr;
+	unsigned long long* bid = nullptr; // [2][w*h], see DevMap
 	std::vector<uint32_t> neighbors;
 };
 
@@ -190,7 +191,7 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 static void free_maps(View& v) {
 	if (v.mapsOwned) for (void* p : {(void*)v.mDepth, (void*)v.mNormal, (void*)v.mConf}) if (p) (void)hipFree(p);
 	for (void* p : {(void*)v.claim, (void*)v.bid}) if (p) (void)hipFree(p);
-	v.mDepth = v.mNormal = v.mConf = nullptr; v.claim = v.bid = nullptr; v.mapsOwned = false;
+	v.mDepth = v.mNormal = v.mConf = nullptr; v.claim = nullptr; v.bid = nullptr; v.mapsOwned = false;
 }
 static void free_view(View& v) {
 	if (v.owned) { if (v.gray) (void)hipFree(v.gray); if (v.bgr) (void)hipFree(v.bgr); }
@@ -621,7 +622,7 @@ static int set_maps(hcmvs_ctx* c, uint32_t id, const float* depth, const float* 
 	}
 	v.dMin = dmin; v.dMax = dmax;
 	HIPCHK(c, hipMalloc(&v.claim, n * 4));
-	HIPCHK(c, hipMalloc(&v.bid, n * 4));
+	HIPCHK(c, hipMalloc(&v.bid, n * 16));
 	return HCMVS_OK;
 }
 int hcmvs_set_depthmap(hcmvs_ctx* c, uint32_t id, const float* depth, const float* normal, const float* conf, float d_min, float d_max) {
@@ -760,24 +761,24 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 		if (host[order[i]].nNeighbors > kFuseMaxViews - 1) return fail(c, HCMVS_ERR_INVALID, "fuse: view %u has too many neighbours", order[i]);
 	}
 	hipStream_t s = c->stream;
-	for (auto& m : host) if (m.depth) { launch_fill_u32(m.claim, 0xFFFFFFFFu, (size_t)m.w * m.h, s); launch_fill_u32(m.bid, 0xFFFFFFFFu, (size_t)m.w * m.h, s); }
+	for (auto& m : host) if (m.depth) { launch_fill_u32(m.claim, 0xFFFFFFFFu, (size_t)m.w * m.h, s); launch_fill_u64(m.bid, ~0ull, 2 * (size_t)m.w * m.h, s); }
 	// per-pass scratch (sized for the largest image) + device cloud
-	constexpr int kRoundCap = 1 << 16; // rounds of one image pass (one counter each; a round decides >= 1 pixel)
-	constexpr int kGroup = 8;          // rounds issued between two looks at the pending count
+	constexpr int kRoundCap = 1 << 18; // rounds of one image pass (one counter each; a round decides >= 1 pixel)
 	const size_t scanBytes = (fuse_scan_temp_bytes((int)maxArea) + 255) & ~(size_t)255;
 	size_t off = 0;
 	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-	const size_t oList0 = carve(maxArea * 4), oList1 = carve(maxArea * 4), oDec = carve(maxArea * 4), oDecD = carve(maxArea * 4),
-	             oCnt = carve((size_t)(kRoundCap + 1) * 4), oDCnt = carve((size_t)kRoundCap * 4), oFlag = carve(maxArea),
-	             oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
+	int maxNb = 1;
+	for (int i = 0; i < n_order; ++i) maxNb = std::max(maxNb, (int)host[order[i]].nNeighbors);
+	const size_t oList0 = carve(maxArea * 4), oList1 = carve(maxArea * 4), oTgt = carve(maxArea * 4 * (size_t)maxNb), oCnt = carve((size_t)(kRoundCap + 1) * 4), oBar = carve(64),
+	             oFlag = carve(maxArea), oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
 	             oXyz = carve(maxArea * 12), oNrm = carve(maxArea * 12), oBgr = carve(maxArea * 3), oNv = carve(maxArea * 4),
 	             oCX = carve(capacity * 12), oCN = carve(normal ? capacity * 12 : 0), oCB = carve(bgr ? capacity * 3 : 0), oCV = carve(n_views ? capacity * 4 : 0);
 	rc = ensure_scratch(c, off);
 	if (rc) return rc;
 	char* b = (char*)c->fuseScratch;
 	uint32_t* lists[2] = {(uint32_t*)(b + oList0), (uint32_t*)(b + oList1)};
-	uint32_t* decList = (uint32_t*)(b + oDec); float* decDepth = (float*)(b + oDecD);
-	uint32_t* roundCnt = (uint32_t*)(b + oCnt); uint32_t* decCnt = (uint32_t*)(b + oDCnt);
+	uint32_t* roundCnt = (uint32_t*)(b + oCnt); uint32_t* bar = (uint32_t*)(b + oBar);
+	int32_t* targets = (int32_t*)(b + oTgt);
 	uint8_t* flag = (uint8_t*)(b + oFlag);
 	uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos);
 	float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
@@ -785,32 +786,29 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	uint32_t* cV = n_views ? (uint32_t*)(b + oCV) : nullptr;
 	const float normalError = cosf(normal_diff_deg * normalweight * (3.14159274101257324f / 180.f)); // SceneDensify.cpp:3310
 	const float thDepth = depth_diff_threshold * depthweight;                                       // SceneDensify.cpp:3400
+	// as many workgroups as the device keeps resident at once (the grid barrier of the pass kernel relies on that)
+	hipDeviceProp_t prop;
+	HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+	const int nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
 	unsigned long long total = 0, depths = 0;
+	uint32_t ridBase = 1;
 	for (int oi = 0; oi < n_order; ++oi) { // best connected images first (SceneDensify.cpp:3302, order given by the caller)
 		const DevMap& A = host[order[oi]];
 		const int n = A.w * A.h;
 		HIPCHK(c, hipMemsetAsync(c->counters, 0, 64, s));
-		HIPCHK(c, hipMemsetAsync(roundCnt, 0, oFlag - oCnt, s)); // both counter arrays
-		launch_fuse_begin(A, lists[0], roundCnt, flag, c->counters, s);
-		uint32_t pending = 0;
-		HIPCHK(c, hipMemcpyAsync(&pending, roundCnt, 4, hipMemcpyDeviceToHost, s));
-		HIPCHK(c, hipStreamSynchronize(s));
-		int r = 0;
-		while (pending > 0) {
-			if (r + kGroup > kRoundCap) return fail(c, HCMVS_ERR_HIP, "fuse: image %u needs more than %d rounds (%u pixels pending)", A.id, kRoundCap, pending);
-			const int blocks = (int)std::min<uint32_t>(2048u, (pending + 255u) / 256u);
-			for (int k = 0; k < kGroup; ++k, ++r)
-				launch_fuse_round(A, c->dMaps, lists[r & 1], roundCnt + r, lists[(r + 1) & 1], roundCnt + r + 1, decList, decDepth, decCnt + r, pxyz,
-				                  cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, n_min_views_fuse, thDepth, normalError, c->counters, blocks, s);
-			uint32_t left = 0;
-			HIPCHK(c, hipMemcpyAsync(&left, roundCnt + r, 4, hipMemcpyDeviceToHost, s));
-			HIPCHK(c, hipStreamSynchronize(s));
-			if (left >= pending) return fail(c, HCMVS_ERR_HIP, "fuse: no progress in image %u (%u pixels pending)", A.id, pending);
-			pending = left;
-		}
+		HIPCHK(c, hipMemsetAsync(roundCnt, 0, oFlag - oCnt, s)); // round counters + barrier words
+		launch_fuse_begin(A, c->dMaps, lists[0], roundCnt, targets, flag, c->counters, s);
+		launch_fuse_pass(A, c->dMaps, lists[0], lists[1], targets, roundCnt, bar, ridBase, (uint32_t)kRoundCap, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv,
+		                 flag, n_min_views_fuse, thDepth, normalError, c->counters, nCU * (A.nNeighbors < 16 ? 2 : 1), s); // 216 / 256 VGPRs: 2 / 1 workgroups per CU
 		unsigned long long cnt[4];
+		uint32_t barWords[3] = {0, 0, 0};
 		HIPCHK(c, hipMemcpyAsync(cnt, c->counters, 32, hipMemcpyDeviceToHost, s));
+		HIPCHK(c, hipMemcpyAsync(barWords, bar, 12, hipMemcpyDeviceToHost, s));
 		HIPCHK(c, hipStreamSynchronize(s));
+		if (barWords[1] != 0) return fail(c, HCMVS_ERR_TIMEOUT, "fuse: grid barrier timed out in image %u", A.id);
+		if (barWords[2] + 2 >= (uint32_t)kRoundCap) return fail(c, HCMVS_ERR_HIP, "fuse: image %u needs more than %d rounds", A.id, kRoundCap);
+		ridBase += barWords[2] + 2;
+		if (getenv("HCMVS_FUSE_DEBUG")) fprintf(stderr, "fuse: image %u: %u rounds, %llu accepted\n", A.id, barWords[2], cnt[3]);
 		depths += cnt[0];
 		const unsigned long long accepted = cnt[3];
 		if (total + accepted > capacity) return fail(c, HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity);

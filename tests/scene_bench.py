@@ -60,10 +60,17 @@ print("scene: %d images %dx%d, %d sparse points, generated in %.1f s -> %s" % (N
 exe = os.path.join(ROOT, "hc-mvs_amd", "DensifyPointCloud")
 t1 = time.time()
 r = subprocess.run([exe, "-i", os.path.join(tmp, "scene.mvs"), "-o", os.path.join(tmp, "dense.mvs"), "--resolution-level", "0",
-                    "--number-views", "9", "--n-EstimationIters", str(SWEEPS), "--n-EstimationIters-external", "1", "--batch", "32", "-v", "2"],
-                   capture_output=True, text=True)
+                    "--number-views", "8", "--n-EstimationIters", str(SWEEPS), "--n-EstimationIters-external", "1", "--batch", "32", "-v", "3"],
+                   capture_output=True, text=True, env=dict(os.environ, HCMVS_FUSE_DEBUG='1'))
 dt = time.time() - t1
-print(r.stdout[-1500:]); print(r.stderr[-800:])
+rounds = [int(l.split(':')[2].split('rounds')[0]) for l in r.stderr.split('\n') if l.startswith('fuse: image')]
+print('fuse rounds per image: min %d median %d max %d total %d' % (min(rounds), sorted(rounds)[len(rounds)//2], max(rounds), sum(rounds)) if rounds else 'no fuse debug')
+r.stderr = '\n'.join(l for l in r.stderr.split('\n') if not l.startswith('fuse: image'))
+lines = r.stdout.split('\n')
+batch_ms = sorted(set(l.split('batch ')[1] for l in lines if 'batch ' in l))
+print('\n'.join(l for l in lines if 'batch ' not in l and 'paired with' not in l)[-1500:]); print('batches:', batch_ms); print(r.stderr[-800:])
+nsrc = [l.split('using')[1].split('images')[0].strip() for l in lines if 'estimated using' in l]
+import collections; print('source views per image:', dict(collections.Counter(nsrc)))
 print("driver wall time %.2f s for %d images (%.2f Mpix/s end to end incl. image loading, init, depth-map files, fuse, outputs)" % (
     dt, N, N * W * H / dt / 1e6))
 acc = []
