@@ -21,7 +21,6 @@ struct DevMap {
 	const float* conf;
 	const uint8_t* bgr;      // may be null
 	uint32_t* claim;         // SceneDensify.cpp:3313 arrDepthIdx: NO_ID or claimed
-	unsigned long long* bid; // [2][w*h] fusion rounds: (~round tag, lowest pending raster index) bidding for each pixel, by round parity
 	const uint32_t* neighbors; // device array of image ids, decreasing importance
 	float dMin, dMax;
 };
@@ -31,10 +30,28 @@ void launch_fill_u64(unsigned long long* p, unsigned long long v, size_t n, hipS
 void launch_filter_splat(const DevMap& ref, const DevMap& nb, unsigned long long* key, hipStream_t s);
 void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsigned long long* keys, int adjust, int nMinViews,
                         int nMinViewsAdjust, float thr, float* newDepth, float* newConf, unsigned long long* counters, hipStream_t s);
-void launch_fuse_begin(const DevMap& A, const DevMap* maps, uint32_t* pending, uint32_t* roundCnt, int32_t* targets, uint8_t* flag,
-                       unsigned long long* counters, hipStream_t s);
-void launch_fuse_pass(const DevMap& A, const DevMap* maps, uint32_t* list0, uint32_t* list1, const int32_t* targets, uint32_t* roundCnt, uint32_t* barrier,
-                      uint32_t ridBase, uint32_t roundCap, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
+// per-pass tables of image A (sized for the largest image / neighbour count of the call)
+struct FuseTables {
+	int32_t* targets;    // [w*h][nNeighbors]: pixel index A's pixel projects onto in neighbour q, -1 for none (SceneDensify.cpp:3387-3393)
+	uint32_t* cntT;      // [nNeighbors][stride]: number of pending pixels of A that project onto each neighbour pixel
+	uint32_t* offT;      // exclusive scan of cntT: start of that neighbour pixel's list in `bidders`
+	uint32_t* fillT;     // fill cursors while the lists are written
+	uint32_t* bidders;   // the lists: raster indices of A's pending pixels, per target
+	uint32_t* cntP;      // [2][stride]: per pixel of A, how many pixels share a target with it -- lower / higher raster index
+	uint32_t* offP;      // exclusive scan of cntP: start of the pixel's lower / higher list in `nbrList`
+	uint32_t* nbrList;   // those pixels (a pixel may appear more than once)
+	uint32_t* doneRound; // [w*h]: round in which the pixel was decided, FS_NOT_DONE before
+	uint32_t* queued;    // [w*h]: last round the pixel was put on a candidate list for
+	size_t stride;       // pixels reserved per neighbour map in cntT / offT / fillT
+};
+
+FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_t* fillT, uint32_t* bidders, uint32_t* cntP, uint32_t* offP,
+                       uint32_t* nbrList, uint32_t* doneRound, uint32_t* queued, size_t stride);
+void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
+                       uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters, hipStream_t s);
+void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* roundCnt, hipStream_t s);
+void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, uint32_t* list0, uint32_t* list1, uint32_t* roundCnt,
+                      uint32_t* barrier, uint32_t roundCap, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
                       int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, int blocks, hipStream_t s);
 size_t fuse_scan_temp_bytes(int n);
 void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,

@@ -13,15 +13,19 @@
  *     sequential rule "nearest wins, the later writer wins ties" exactly; the vote is embarrassingly
  *     parallel.  HBM-bound integer/float work, one thread per pixel, coalesced over the reference map.
  *   - Fuse: a pixel of image A interacts with other pixels of A only through the neighbour pixels it
- *     projects onto (its targets).  One persistent kernel per image pass runs rounds separated by a grid
- *     barrier: for every target the lowest raster index still pending holds the bid (64-bit atomicMin on
- *     (round tag, index)); exactly the pixels that own all their targets run the reference's body, the
- *     others bid again for the next round.  Pixels sharing a target are therefore decided in raster order
- *     and the cloud is identical to the sequential one, point order included (ordered compaction).
+ *     projects onto (its targets).  The pixels that project onto one neighbour pixel are listed per target
+ *     (CSR, built once per image pass); a pixel is ready when every lower raster index on all its targets
+ *     has been decided in an earlier round.  One persistent kernel per image pass runs the rounds, separated
+ *     by a grid barrier: the round's candidates that are ready run the reference's body and wake the higher
+ *     indices on their targets for the next round.  Pixels sharing a target are therefore decided in raster
+ *     order, the work is proportional to the pixels (not pixels x rounds) and the cloud is identical to the
+ *     sequential one, point order included (ordered compaction).
  *
  * Double precision follows the reference (Point3 = double); no contraction (-ffp-contract=off).
  */
 #include "fuse_common.h"
+
+#include <cstdlib>
 
 #include <hipcub/hipcub.hpp>
 
@@ -183,23 +187,16 @@ __device__ __forceinline__ void pixel_point(const DevMap& A, int idx, float dept
 }
 
 // ---- the image pass -----------------------------------------------------------------------------------------------
-// Pending pixels live in two device-side lists (their order is irrelevant: contention is settled by the raster index).
-// Bids are 64-bit keys (~round tag, raster index) in two arrays per map used alternately by round parity, so a bid of
-// a newer round always beats what an older round left behind and nothing has to be cleared:
-//   round r: a pending pixel that holds the bid of round r on all its targets is decided (the reference's body);
-//            the others bid for round r + 1 into the other array and stay on the list.  One grid barrier per round.
-// Everything another workgroup may have written in this launch (bids, claims, depths, the lists) is accessed with
-// agent-scope (sc1) atomics, which reach past the per-XCD L2; every wave drains its stores before the barrier.
+// Everything another workgroup may have written in this launch (round stamps, claims, depths, the lists) is accessed
+// with agent-scope (sc1) atomics, which reach past the per-XCD L2; every wave drains its stores before the barrier.
 
 #define FS_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#define FS_NOT_DONE 0xFFFFFFFFu
 typedef __attribute__((address_space(1))) uint32_t* g_u32p;
-typedef __attribute__((address_space(1))) unsigned long long* g_u64p;
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t* p) { return __hip_atomic_load((g_u32p)p, __ATOMIC_RELAXED, FS_SCOPE); }
 __device__ __forceinline__ void st_u32(uint32_t* p, uint32_t v) { __hip_atomic_store((g_u32p)p, v, __ATOMIC_RELAXED, FS_SCOPE); }
 __device__ __forceinline__ float ld_f32(const float* p) { return __uint_as_float(ld_u32((const uint32_t*)p)); }
 __device__ __forceinline__ void st_f32(float* p, float v) { st_u32((uint32_t*)p, __float_as_uint(v)); }
-__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* p) { return __hip_atomic_load((g_u64p)p, __ATOMIC_RELAXED, FS_SCOPE); }
-__device__ __forceinline__ unsigned long long bid_key(uint32_t round, uint32_t idx) { return ((unsigned long long)(0xFFFFFFFFu - round) << 32) | idx; }
 
 __device__ __forceinline__ void list_append(bool pred, int value, uint32_t* list, uint32_t* count) { // one atomic per wave
 	const unsigned long long m = __ballot(pred);
@@ -211,9 +208,9 @@ __device__ __forceinline__ void list_append(bool pred, int value, uint32_t* list
 	st_u32(&list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))], (uint32_t)value);
 }
 
-// also writes the targets of every pending pixel -- the pixel index it projects onto in each neighbour map, -1 for
-// none (SceneDensify.cpp:3387-3393) -- so that the rounds only chase indices
-__global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, uint32_t* pending, uint32_t* roundCnt, int32_t* targets, uint8_t* flag,
+// pending pixels of A (valid depth, not yet claimed by an earlier image) -> first candidate list, their targets and the
+// per-target counts
+__global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, uint32_t* pending, uint32_t* roundCnt, uint8_t* flag,
                                   unsigned long long* counters) {
 	const int n = A.w * A.h;
 	unsigned nd = 0;
@@ -226,6 +223,8 @@ __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, uint32_t* pendin
 				pend = A.claim[idx] == NO_ID;
 			}
 			flag[idx] = 0;
+			tb.doneRound[idx] = FS_NOT_DONE;
+			tb.queued[idx] = pend ? 1u : 0u;
 		}
 		if (pend) {
 			float point[3];
@@ -234,29 +233,65 @@ __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, uint32_t* pendin
 				const DevMap& B = maps[A.neighbors[q]];
 				float ptz; int ib = -1, xB, yB;
 				if (!B.depth || !project_target(B, point, ptz, ib, xB, yB)) ib = -1;
-				targets[(size_t)idx * A.nNeighbors + q] = ib;
+				tb.targets[(size_t)idx * A.nNeighbors + q] = ib;
+				if (ib >= 0) atomicAdd(&tb.cntT[q * tb.stride + ib], 1u);
 			}
 		}
-		list_append(pend, idx, pending, roundCnt);
+		list_append(pend, idx, pending, roundCnt + 1);
 	}
 	if (nd) atomicAdd(&counters[0], (unsigned long long)nd); // valid depths visited (SceneDensify.cpp:3359)
+}
+// write the per-target lists (any order inside a list)
+__global__ void fuse_fill_kernel(int nNb, FuseTables tb, const uint32_t* pending, const uint32_t* roundCnt) {
+	const int n = (int)roundCnt[1];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t idx = pending[i];
+		for (int q = 0; q < nNb; ++q) {
+			const int ib = tb.targets[(size_t)idx * nNb + q];
+			if (ib < 0) continue;
+			const size_t t = q * tb.stride + ib;
+			tb.bidders[tb.offT[t] + atomicAdd(&tb.fillT[t], 1u)] = idx;
+		}
+	}
+}
+
+// per pending pixel: the pixels sharing a target with it, split into lower (they block it) and higher raster indices
+// (it wakes them); pass 0 counts, pass 1 writes the lists at the scanned offsets
+__global__ void fuse_links_kernel(int nNb, FuseTables tb, const uint32_t* pending, const uint32_t* roundCnt, int write) {
+	const int n = (int)roundCnt[1];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t idx = pending[i];
+		uint32_t nLow = 0, nHigh = 0;
+		const uint32_t oLow = write ? tb.offP[idx] : 0u, oHigh = write ? tb.offP[tb.stride + idx] : 0u;
+		for (int q = 0; q < nNb; ++q) {
+			const int ib = tb.targets[(size_t)idx * nNb + q];
+			if (ib < 0) continue;
+			const size_t t = q * tb.stride + ib;
+			const uint32_t o = tb.offT[t], len = tb.cntT[t];
+			for (uint32_t k = 0; k < len; ++k) {
+				const uint32_t b = tb.bidders[o + k];
+				if (b < idx) { if (write) tb.nbrList[oLow + nLow] = b; ++nLow; }
+				else if (b > idx) { if (write) tb.nbrList[oHigh + nHigh] = b; ++nHigh; }
+			}
+		}
+		if (!write) { tb.cntP[idx] = nLow; tb.cntP[tb.stride + idx] = nHigh; }
+	}
 }
 
 struct FuseOut { // per pixel of the current image, compacted in raster order afterwards
 	float* xyz; float* normal; uint8_t* bgr; uint32_t* nviews; uint8_t* flag;
 };
 struct FusePass {
-	uint32_t* list[2];       // pending pixels, alternating by round parity
-	const int32_t* targets;  // [w*h][nNeighbors] of A, see fuse_begin_kernel
-	uint32_t* roundCnt;      // [kRoundCap + 1] pending pixels at the start of round r
+	uint32_t* list[2];       // candidate pixels of a round, alternating by round parity
+	FuseTables tb;
+	uint32_t* roundCnt;      // [roundCap + 1] candidates of round r (rounds count from 1)
 	uint32_t* barrier;       // [0] arrivals, [1] error flag, [2] rounds used
-	uint32_t ridBase;        // round tag of round 0 of this pass
 	uint32_t roundCap;
-	uint32_t tailCount;      // once this few pixels are pending, workgroup 0 finishes the pass alone (block barriers)
+	uint32_t tailCount;      // once a round has this few candidates, workgroup 0 finishes the pass alone (block barriers)
 	int nMinViewsFuse; float thDepth, normalError;
 };
 
-// all workgroups of the launch are resident (grid <= number of CUs): arrive, then wait for everybody
+// all workgroups of the launch are resident: arrive, then wait for everybody
 __device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t& target) {
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // my wave's stores are out
 	__syncthreads();
@@ -267,7 +302,7 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t& target) {
 		unsigned spins = 0;
 		while (ld_u32(bar) < target) {
 			__builtin_amdgcn_s_sleep(1);
-			if ((++spins & 1023u) == 0u && (ld_u32(bar + 1) != 0u || spins > (1u << 24))) { st_u32(bar + 1, 1u); failed = 1; break; }
+			if ((++spins & 1023u) == 0u && (ld_u32(bar + 1) != 0u || spins > (1u << 23))) { st_u32(bar + 1, 1u); failed = 1; break; }
 		}
 	}
 	__syncthreads();
@@ -275,13 +310,12 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t& target) {
 	return failed == 0;
 }
 
-// The neighbour maps' descriptors are staged in LDS once per launch and every per-pixel loop over the neighbours is
-// chunked: first the projections of a chunk, then all its loads back to back, then the (sequential) logic -- a round
-// then costs a couple of memory round trips instead of one per neighbour and table level.
-constexpr int kFuseChunk = 4;
+// The neighbour maps' descriptors are staged in LDS once per launch; the loop of the reference's body over the
+// neighbours is chunked: first the projections of a chunk, then all its loads back to back, then the (sequential) logic.
+constexpr int kFuseChunk = 8;
 
 // MAXV: capacity of the per-pixel view lists (the image itself + its neighbours); 16 covers the reference's cap of 12
-// neighbours (nMaxViews, DepthMap.cpp:73) with half the registers of the general 32
+// neighbours (nMaxViews, DepthMap.cpp:73) with fewer registers than the general 32
 template <int MAXV>
 __global__ __launch_bounds__(256) void fuse_pass_kernel(DevMap A, const DevMap* maps, FusePass fp, FuseOut out, unsigned long long* counters) {
 	__shared__ DevMap nbs[MAXV - 1];
@@ -296,24 +330,11 @@ __global__ __launch_bounds__(256) void fuse_pass_kernel(DevMap A, const DevMap* 
 		}
 		__syncthreads();
 	}
+	const FuseTables& tb = fp.tb;
 	const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gthreads = gridDim.x * blockDim.x;
 	uint32_t target = gridDim.x;
 	unsigned accepted = 0;
-	// round 0: everybody bids
-	{
-		const int n = (int)ld_u32(fp.roundCnt);
-		for (int i = gtid; i < n; i += gthreads) {
-			const int idx = (int)ld_u32(&fp.list[0][i]);
-			const unsigned long long key = bid_key(fp.ridBase, (uint32_t)idx);
-			const int32_t* tg = fp.targets + (size_t)idx * nNb;
-			for (int q = 0; q < nNb; ++q) {
-				const int ib = tg[q];
-				if (ib >= 0) atomicMin(&nbs[q].bid[ib], key);
-			}
-		}
-	}
-	if (!grid_barrier(fp.barrier, target)) return;
-	uint32_t r = 0;
+	uint32_t r = 1;
 	bool tail = false; // workgroup 0 alone, block barriers
 	for (;; ++r) {
 		const int n = (int)ld_u32(fp.roundCnt + r);
@@ -323,42 +344,28 @@ __global__ __launch_bounds__(256) void fuse_pass_kernel(DevMap A, const DevMap* 
 			tail = true;
 		}
 		const int tid = tail ? (int)threadIdx.x : gtid, nthreads = tail ? (int)blockDim.x : gthreads;
-		const size_t par = (size_t)(r & 1u), parNext = par ^ 1u;
-		const uint32_t* listIn = fp.list[par];
-		uint32_t* listOut = fp.list[parNext];
-		const int nPad = (n + 63) & ~63;
-		for (int i = tid; i < nPad; i += nthreads) {
-			const bool have = i < n;
-			const int idx = have ? (int)ld_u32(&listIn[i]) : 0;
-			bool ready = have;
-			const float depth = have ? A.depth[idx] : 0.f;
-			float point[3] = {0.f, 0.f, 0.f};
-			if (have) {
-				// do I hold this round's bid on every target?  (then no lower raster index is still undecided on any of them)
-				const unsigned long long key = bid_key(fp.ridBase + r, (uint32_t)idx);
-				const int32_t* tg = fp.targets + (size_t)idx * nNb;
-				for (int q0 = 0; q0 < nNb && ready; q0 += kFuseChunk) {
-					int ib[kFuseChunk];
+		const uint32_t* listIn = fp.list[r & 1u];
+		uint32_t* listOut = fp.list[(r + 1u) & 1u];
+		for (int i = tid; i < n; i += nthreads) {
+			const int idx = (int)ld_u32(&listIn[i]);
+			// ready: every lower raster index that shares a target with me was decided in an earlier round
+			bool ready = true;
+			{
+				const uint32_t o = tb.offP[idx], len = tb.cntP[idx];
+				for (uint32_t k0 = 0; k0 < len && ready; k0 += 8) {
+					uint32_t b[8], d[8];
 #pragma unroll
-					for (int j = 0; j < kFuseChunk; ++j) ib[j] = q0 + j < nNb ? tg[q0 + j] : -1;
-					unsigned long long got[kFuseChunk];
+					for (int j = 0; j < 8; ++j) b[j] = k0 + j < len ? tb.nbrList[o + k0 + j] : 0xFFFFFFFFu;
 #pragma unroll
-					for (int j = 0; j < kFuseChunk; ++j) got[j] = ib[j] >= 0 ? ld_u64(&nbs[q0 + j].bid[par * (size_t)nbs[q0 + j].w * nbs[q0 + j].h + ib[j]]) : key;
+					for (int j = 0; j < 8; ++j) d[j] = b[j] != 0xFFFFFFFFu ? ld_u32(&tb.doneRound[b[j]]) : 0u;
 #pragma unroll
-					for (int j = 0; j < kFuseChunk; ++j) ready = ready && got[j] == key;
-				}
-				if (!ready) { // bid for the next round
-					const unsigned long long nkey = bid_key(fp.ridBase + r + 1u, (uint32_t)idx);
-					for (int q = 0; q < nNb; ++q) {
-						const int ibq = tg[q];
-						if (ibq >= 0) atomicMin(&nbs[q].bid[parNext * (size_t)nbs[q].w * nbs[q].h + ibq], nkey);
-					}
-				} else {
-					pixel_point(A, idx, depth, point);
+					for (int j = 0; j < 8; ++j) ready = ready && d[j] < r;
 				}
 			}
-			list_append(have && !ready, idx, listOut, fp.roundCnt + r + 1);
-			if (!ready) continue;
+			if (!ready) continue; // whoever blocks me puts me on the list again when it is decided
+			const float depth = A.depth[idx];
+			float point[3];
+			pixel_point(A, idx, depth, point);
 			// the reference's body, SceneDensify.cpp:3364-3450
 			uint32_t vimg[MAXV]; int vpix[MAXV]; int nv = 0;
 			vimg[nv] = A.id; vpix[nv] = idx; ++nv;
@@ -451,6 +458,21 @@ __global__ __launch_bounds__(256) void fuse_pass_kernel(DevMap A, const DevMap* 
 				++accepted;
 				for (int v = 0; v < ninv; ++v) st_f32(&maps[invImg[v]].depth[invPix[v]], 0.f);
 			}
+			// decided: stamp the round and wake the higher raster indices on my targets for the next round
+			st_u32(&tb.doneRound[idx], r);
+			{
+				const uint32_t o = tb.offP[tb.stride + idx], len = tb.cntP[tb.stride + idx];
+				for (uint32_t k0 = 0; k0 < len; k0 += 8) {
+					uint32_t b[8], was[8];
+#pragma unroll
+					for (int j = 0; j < 8; ++j) b[j] = k0 + j < len ? tb.nbrList[o + k0 + j] : 0xFFFFFFFFu;
+#pragma unroll
+					for (int j = 0; j < 8; ++j) was[j] = b[j] != 0xFFFFFFFFu ? atomicMax(&tb.queued[b[j]], r + 1u) : 0xFFFFFFFFu;
+#pragma unroll
+					for (int j = 0; j < 8; ++j)
+						if (was[j] < r + 1u) st_u32(&listOut[atomicAdd(fp.roundCnt + r + 1, 1u)], b[j]);
+				}
+			}
 		}
 		if (tail) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); }
 		else if (!grid_barrier(fp.barrier, target)) return;
@@ -498,18 +520,35 @@ void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsig
                         int nMinViewsAdjust, float thr, float* newDepth, float* newConf, unsigned long long* counters, hipStream_t s) {
 	hipLaunchKernelGGL(filter_vote_kernel, kGrid, kBlock, 0, s, ref, nbs, N, keys, adjust, nMinViews, nMinViewsAdjust, thr, newDepth, newConf, counters);
 }
-void launch_fuse_begin(const DevMap& A, const DevMap* maps, uint32_t* pending, uint32_t* roundCnt, int32_t* targets, uint8_t* flag,
-                       unsigned long long* counters, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, pending, roundCnt, targets, flag, counters);
+FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_t* fillT, uint32_t* bidders, uint32_t* cntP, uint32_t* offP,
+                       uint32_t* nbrList, uint32_t* doneRound, uint32_t* queued, size_t stride) {
+	FuseTables tb;
+	tb.targets = targets; tb.cntT = cntT; tb.offT = offT; tb.fillT = fillT; tb.bidders = bidders; tb.cntP = cntP; tb.offP = offP; tb.nbrList = nbrList;
+	tb.doneRound = doneRound; tb.queued = queued; tb.stride = stride;
+	return tb;
+}
+// begin of an image pass: first candidate list (roundCnt[1]), targets, per-target lists, per-pixel link counts + offsets
+// (cntT / fillT / cntP must be zero).  fuse_links_fill writes the link lists once the host has checked their total size.
+void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
+                       uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, roundCnt, flag, counters);
+	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntT, tb.offT, (int)(tb.stride * (size_t)A.nNeighbors), s);
+	hipLaunchKernelGGL(fuse_fill_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, roundCnt);
+	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, roundCnt, 0);
+	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntP, tb.offP, (int)(2 * tb.stride), s);
+}
+void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* roundCnt, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, roundCnt, 1);
 }
 // the whole image pass in one persistent launch; `blocks` must not exceed the number of workgroups the device keeps
 // resident at once (the rounds are separated by a grid barrier)
-void launch_fuse_pass(const DevMap& A, const DevMap* maps, uint32_t* list0, uint32_t* list1, const int32_t* targets, uint32_t* roundCnt, uint32_t* barrier,
-                      uint32_t ridBase, uint32_t roundCap, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
+void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, uint32_t* list0, uint32_t* list1, uint32_t* roundCnt,
+                      uint32_t* barrier, uint32_t roundCap, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
                       int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, int blocks, hipStream_t s) {
 	FuseOut out{oxyz, onormal, obgr, onv, oflag};
 	FusePass fp;
-	fp.list[0] = list0; fp.list[1] = list1; fp.targets = targets; fp.tailCount = 1024; fp.roundCnt = roundCnt; fp.barrier = barrier; fp.ridBase = ridBase; fp.roundCap = roundCap;
+	fp.list[0] = list0; fp.list[1] = list1; fp.tb = tb;
+	fp.roundCnt = roundCnt; fp.barrier = barrier; fp.roundCap = roundCap; fp.tailCount = getenv("HCMVS_FUSE_TAIL") ? (uint32_t)atoi(getenv("HCMVS_FUSE_TAIL")) : 256u;
 	fp.nMinViewsFuse = nMinViewsFuse; fp.thDepth = thDepth; fp.normalError = normalError;
 	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_pass_kernel<16>, dim3(blocks), dim3(256), 0, s, A, maps, fp, out, counters);
 	else hipLaunchKernelGGL(fuse_pass_kernel<32>, dim3(blocks), dim3(256), 0, s, A, maps, fp, out, counters);

@@ -38,7 +38,6 @@ struct View {
 	bool mapsOwned = false;
 	float dMin = 0.f, dMax = 0.f;
 	uint32_t *claim = nullptr, *dNeighbors = nullptr;
-	unsigned long long* bid = nullptr; // [2][w*h], see DevMap
 	std::vector<uint32_t> neighbors;
 };
 
@@ -190,8 +189,8 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 
 static void free_maps(View& v) {
 	if (v.mapsOwned) for (void* p : {(void*)v.mDepth, (void*)v.mNormal, (void*)v.mConf}) if (p) (void)hipFree(p);
-	for (void* p : {(void*)v.claim, (void*)v.bid}) if (p) (void)hipFree(p);
-	v.mDepth = v.mNormal = v.mConf = nullptr; v.claim = nullptr; v.bid = nullptr; v.mapsOwned = false;
+	if (v.claim) (void)hipFree(v.claim);
+	v.mDepth = v.mNormal = v.mConf = nullptr; v.claim = nullptr; v.mapsOwned = false;
 }
 static void free_view(View& v) {
 	if (v.owned) { if (v.gray) (void)hipFree(v.gray); if (v.bgr) (void)hipFree(v.bgr); }
@@ -622,7 +621,6 @@ static int set_maps(hcmvs_ctx* c, uint32_t id, const float* depth, const float* 
 	}
 	v.dMin = dmin; v.dMax = dmax;
 	HIPCHK(c, hipMalloc(&v.claim, n * 4));
-	HIPCHK(c, hipMalloc(&v.bid, n * 16));
 	return HCMVS_OK;
 }
 int hcmvs_set_depthmap(hcmvs_ctx* c, uint32_t id, const float* depth, const float* normal, const float* conf, float d_min, float d_max) {
@@ -670,7 +668,7 @@ static void fill_devmap(uint32_t id, const View& v, DevMap& m) {
 		for (int j = 0; j < 3; ++j) m.P[i * 4 + j] = v.K[i * 3] * v.R[j] + v.K[i * 3 + 1] * v.R[3 + j] + v.K[i * 3 + 2] * v.R[6 + j];
 		m.P[i * 4 + 3] = v.K[i * 3] * t[0] + v.K[i * 3 + 1] * t[1] + v.K[i * 3 + 2] * t[2];
 	}
-	m.depth = v.mDepth; m.normal = v.mNormal; m.conf = v.mConf; m.bgr = v.bgr; m.claim = v.claim; m.bid = v.bid;
+	m.depth = v.mDepth; m.normal = v.mNormal; m.conf = v.mConf; m.bgr = v.bgr; m.claim = v.claim;
 	m.neighbors = v.dNeighbors; m.dMin = v.dMin; m.dMax = v.dMax;
 }
 // device table indexed by image id (views without maps have depth == null)
@@ -761,15 +759,26 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 		if (host[order[i]].nNeighbors > kFuseMaxViews - 1) return fail(c, HCMVS_ERR_INVALID, "fuse: view %u has too many neighbours", order[i]);
 	}
 	hipStream_t s = c->stream;
-	for (auto& m : host) if (m.depth) { launch_fill_u32(m.claim, 0xFFFFFFFFu, (size_t)m.w * m.h, s); launch_fill_u64(m.bid, ~0ull, 2 * (size_t)m.w * m.h, s); }
+	for (auto& m : host) if (m.depth) { launch_fill_u32(m.claim, 0xFFFFFFFFu, (size_t)m.w * m.h, s); }
 	// per-pass scratch (sized for the largest image) + device cloud
-	constexpr int kRoundCap = 1 << 18; // rounds of one image pass (one counter each; a round decides >= 1 pixel)
-	const size_t scanBytes = (fuse_scan_temp_bytes((int)maxArea) + 255) & ~(size_t)255;
+	constexpr int kRoundCap = 1 << 18; // rounds of one image pass (one counter each)
+	constexpr size_t kLinkFactor = 3;  // room for the per-pixel link lists, in units of (pixels x neighbours)
+	int maxNb = 1;
+	size_t stride = maxArea; // pixels reserved per neighbour map in the per-target tables
+	for (int i = 0; i < n_order; ++i) {
+		const DevMap& A = host[order[i]];
+		maxNb = std::max(maxNb, (int)A.nNeighbors);
+	}
+	for (const auto& m : host) if (m.depth) stride = std::max(stride, (size_t)m.w * m.h);
+	const size_t tblElems = stride * (size_t)maxNb;
+	if (tblElems > 0x7FFFFFFFull) return fail(c, HCMVS_ERR_CAPACITY, "fuse: %d neighbours of %zu pixels exceed the per-pass tables", maxNb, stride);
+	const size_t scanBytes = (std::max({fuse_scan_temp_bytes((int)maxArea), fuse_scan_temp_bytes((int)tblElems), fuse_scan_temp_bytes((int)(2 * stride))}) + 255) & ~(size_t)255;
 	size_t off = 0;
 	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-	int maxNb = 1;
-	for (int i = 0; i < n_order; ++i) maxNb = std::max(maxNb, (int)host[order[i]].nNeighbors);
-	const size_t oList0 = carve(maxArea * 4), oList1 = carve(maxArea * 4), oTgt = carve(maxArea * 4 * (size_t)maxNb), oCnt = carve((size_t)(kRoundCap + 1) * 4), oBar = carve(64),
+	const size_t oList0 = carve(maxArea * 4), oList1 = carve(maxArea * 4), oTgt = carve(maxArea * 4 * (size_t)maxNb),
+	             oCntT = carve(tblElems * 4), oFillT = carve(tblElems * 4), oCntP = carve(stride * 8), oOffT = carve(tblElems * 4), oOffP = carve(stride * 8),
+	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oNbr = carve(kLinkFactor * maxArea * 4 * (size_t)maxNb),
+	             oDone = carve(maxArea * 4), oQueued = carve(maxArea * 4), oCnt = carve((size_t)(kRoundCap + 1) * 4), oBar = carve(64),
 	             oFlag = carve(maxArea), oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
 	             oXyz = carve(maxArea * 12), oNrm = carve(maxArea * 12), oBgr = carve(maxArea * 3), oNv = carve(maxArea * 4),
 	             oCX = carve(capacity * 12), oCN = carve(normal ? capacity * 12 : 0), oCB = carve(bgr ? capacity * 3 : 0), oCV = carve(n_views ? capacity * 4 : 0);
@@ -779,6 +788,11 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	uint32_t* lists[2] = {(uint32_t*)(b + oList0), (uint32_t*)(b + oList1)};
 	uint32_t* roundCnt = (uint32_t*)(b + oCnt); uint32_t* bar = (uint32_t*)(b + oBar);
 	int32_t* targets = (int32_t*)(b + oTgt);
+	uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders),
+	         *doneRound = (uint32_t*)(b + oDone), *queued = (uint32_t*)(b + oQueued), *cntP = (uint32_t*)(b + oCntP), *offP = (uint32_t*)(b + oOffP),
+	         *nbrList = (uint32_t*)(b + oNbr);
+	const FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, cntP, offP, nbrList, doneRound, queued, stride);
+	const size_t linkCap = kLinkFactor * maxArea * (size_t)maxNb;
 	uint8_t* flag = (uint8_t*)(b + oFlag);
 	uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos);
 	float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
@@ -791,15 +805,24 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
 	const int nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
 	unsigned long long total = 0, depths = 0;
-	uint32_t ridBase = 1;
 	for (int oi = 0; oi < n_order; ++oi) { // best connected images first (SceneDensify.cpp:3302, order given by the caller)
 		const DevMap& A = host[order[oi]];
 		const int n = A.w * A.h;
 		HIPCHK(c, hipMemsetAsync(c->counters, 0, 64, s));
-		HIPCHK(c, hipMemsetAsync(roundCnt, 0, oFlag - oCnt, s)); // round counters + barrier words
-		launch_fuse_begin(A, c->dMaps, lists[0], roundCnt, targets, flag, c->counters, s);
-		launch_fuse_pass(A, c->dMaps, lists[0], lists[1], targets, roundCnt, bar, ridBase, (uint32_t)kRoundCap, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv,
-		                 flag, n_min_views_fuse, thDepth, normalError, c->counters, nCU * (A.nNeighbors < 16 ? 2 : 1), s); // 216 / 256 VGPRs: 2 / 1 workgroups per CU
+		HIPCHK(c, hipMemsetAsync(roundCnt, 0, oFlag - oCnt, s));                              // round counters + barrier words
+		HIPCHK(c, hipMemsetAsync(cntT, 0, (oOffT - oCntT), s));                               // per-target counts, fill cursors, per-pixel link counts
+		launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, lists[1], roundCnt, flag, c->counters, s);
+		uint32_t lastOff = 0, lastCnt = 0; // total size of the link lists = last offset + last count
+		HIPCHK(c, hipMemcpyAsync(&lastOff, offP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, s));
+		HIPCHK(c, hipMemcpyAsync(&lastCnt, cntP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, s));
+		HIPCHK(c, hipStreamSynchronize(s));
+		if ((size_t)lastOff + lastCnt > linkCap)
+			return fail(c, HCMVS_ERR_CAPACITY, "fuse: image %u has %zu pixel links (room for %zu): too many of its pixels project onto the same neighbour pixels",
+			            A.id, (size_t)lastOff + lastCnt, linkCap);
+		launch_fuse_links_fill(A, tb, lists[1], roundCnt, s);
+		launch_fuse_pass(A, c->dMaps, tb, lists[0], lists[1], roundCnt, bar, (uint32_t)kRoundCap,
+		                 pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, n_min_views_fuse, thDepth, normalError, c->counters,
+		                 getenv("HCMVS_FUSE_BLOCKS") ? std::min(nCU, std::max(1, atoi(getenv("HCMVS_FUSE_BLOCKS")))) : nCU, s);
 		unsigned long long cnt[4];
 		uint32_t barWords[3] = {0, 0, 0};
 		HIPCHK(c, hipMemcpyAsync(cnt, c->counters, 32, hipMemcpyDeviceToHost, s));
@@ -807,7 +830,6 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 		HIPCHK(c, hipStreamSynchronize(s));
 		if (barWords[1] != 0) return fail(c, HCMVS_ERR_TIMEOUT, "fuse: grid barrier timed out in image %u", A.id);
 		if (barWords[2] + 2 >= (uint32_t)kRoundCap) return fail(c, HCMVS_ERR_HIP, "fuse: image %u needs more than %d rounds", A.id, kRoundCap);
-		ridBase += barWords[2] + 2;
 		if (getenv("HCMVS_FUSE_DEBUG")) fprintf(stderr, "fuse: image %u: %u rounds, %llu accepted\n", A.id, barWords[2], cnt[3]);
 		depths += cnt[0];
 		const unsigned long long accepted = cnt[3];
