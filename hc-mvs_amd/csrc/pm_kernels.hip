@@ -202,6 +202,14 @@ struct RegStore {
 	static constexpr int MAXM = 64 / S;
 	float A[9], Hm[3];
 	float py[MAXM], w[MAXM], tw[MAXM];
+	float (*stage)[8][8]; // S == 8: [3][column][row] LDS of this wave, the hand-over between the patch and the scorer lane layouts
+	int seg;
+	// S == 8: the lane that computed tap (row, col) hands it to the scorer lanes of column col
+	__device__ __forceinline__ void put_patch64(int row, int col, float py_, float w_, float tw_) {
+		stage[0][col][row] = py_; stage[1][col][row] = w_; stage[2][col][row] = tw_; // same-wave LDS accesses are ordered
+#pragma unroll
+		for (int m = 0; m < MAXM; ++m) { py[m] = stage[0][seg][m]; w[m] = stage[1][seg][m]; tw[m] = stage[2][seg][m]; }
+	}
 	__device__ __forceinline__ void put_view(const HC_GLOBAL DevView* dv, int) {
 #pragma unroll
 		for (int i = 0; i < 9; ++i) A[i] = dv->A[i];
@@ -231,7 +239,8 @@ template <int S>
 struct WavePark { // LDS of one wave of a row worker
 	static constexpr int MAXM = 64 / S;
 	float4 vh[64 / S][3];     // per view group: A[0..8], Hm[0..2]
-	float pw[3 * MAXM][64];   // py | w | tw, see LdsStore
+	float pw[S == 8 ? 1 : 3 * MAXM][64]; // S != 8: py | w | tw per lane, see LdsStore
+	float ps[3][8][8];        // S == 8: py | w | tw as [column][row], read by every view group
 	float cl[9][kMaxSlots];   // smoothness neighbours, slot k at [.][k]: X0 X1 X2 | n0 n1 n2 | k0 k1 k2 (see Close)
 	float4 hl[8][64 / S][3];  // homographies of the (hypothesis, view) pairs of the current chunk of eight hypotheses
 	float4 acc[8][64 / S];    // their ZNCC sums: sum, sumSq, num, 1 if a tap left the image
@@ -275,6 +284,14 @@ struct LdsStore {
 	__device__ __forceinline__ void put_patch(const float (&py_)[MAXM], const float (&w_)[MAXM], const float (&tw_)[MAXM]) {
 		put_arr(0, py_); put_arr(MAXM, w_); put_arr(2 * MAXM, tw_);
 	}
+	__device__ __forceinline__ void put_patch64(int row, int col, float py_, float w_, float tw_) { // S == 8
+		pk->ps[0][col][row] = py_; pk->ps[1][col][row] = w_; pk->ps[2][col][row] = tw_;
+	}
+	__device__ __forceinline__ void get_col(int k, int os, float (&v)[MAXM]) const { // S == 8: eight rows of my column
+		const float4* q = (const float4*)&pk->ps[k][os][0];
+		const float4 a = q[0], b = q[1];
+		v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+	}
 	// the index is laundered so that the reads stay inside the evaluation (hoisting them would undo the parking)
 	__device__ __forceinline__ int opaque(int v) const { asm volatile("" : "+v"(v)); return v; }
 	__device__ __forceinline__ void get_view(float (&A_)[9], float (&Hm_)[3]) const {
@@ -283,10 +300,18 @@ struct LdsStore {
 		A_[0] = a.x; A_[1] = a.y; A_[2] = a.z; A_[3] = a.w; A_[4] = b.x; A_[5] = b.y; A_[6] = b.z; A_[7] = b.w; A_[8] = cc.x;
 		Hm_[0] = cc.y; Hm_[1] = cc.z; Hm_[2] = cc.w;
 	}
-	__device__ __forceinline__ void get_py(float (&o)[MAXM]) const { get_arr(0, opaque(lane), o); }
+	__device__ __forceinline__ void get_py(float (&o)[MAXM]) const {
+		if constexpr (S == 8) get_col(0, opaque(lane & 7), o);
+		else get_arr(0, opaque(lane), o);
+	}
 	__device__ __forceinline__ void get_w(float (&w_)[MAXM], float (&tw_)[MAXM]) const {
-		const int ol = opaque(lane);
-		get_arr(MAXM, ol, w_); get_arr(2 * MAXM, ol, tw_);
+		if constexpr (S == 8) {
+			const int os = opaque(lane & 7);
+			get_col(1, os, w_); get_col(2, os, tw_);
+		} else {
+			const int ol = opaque(lane);
+			get_arr(MAXM, ol, w_); get_arr(2 * MAXM, ol, tw_);
+		}
 	}
 };
 
@@ -341,11 +366,17 @@ __device__ __forceinline__ void load_patch_inputs(const EstConst& c, const LaneC
 	gcfptr ref = (gcfptr)c.ref;
 	const int a = patch_halfwin(c, in.tx);
 	in.center = ref[y * c.W + x];
+	if constexpr (S == 8) { // one tap of the patch per lane: lane = 8 * row + column (lanes past the patch repeat its last row / column)
+		const int row = L.lane >> 3, col = L.lane & 7;
+		const int i = -a + 2 * (row < a ? row : a), j = -a + 2 * (col < a ? col : a);
+		in.I[0] = ref[__mul24(y + i, c.W) + (x + j)];
+	} else {
 #pragma unroll
-	for (int m = 0; m < MAXM; ++m) {
-		int i, j;
-		tap_offset<S>(a, L.seg, m, i, j);
-		in.I[m] = ref[__mul24(y + i, c.W) + (x + j)];
+		for (int m = 0; m < MAXM; ++m) {
+			int i, j;
+			tap_offset<S>(a, L.seg, m, i, j);
+			in.I[m] = ref[__mul24(y + i, c.W) + (x + j)];
+		}
 	}
 }
 
@@ -390,16 +421,37 @@ __device__ __forceinline__ void fill_patch_n(const EstConst& c, const LaneCtx<S>
 	P.x = x; P.y = y; P.a = a;
 	st.put_patch(Ppy, Pw, Ptw);
 }
+// 5..8 source views (S == 8): every tap of the (a + 1)^2 patch gets its own lane for the weights (lane = 8 * row + column;
+// lanes past the patch add exactly +0), the three sums are 64-lane butterflies, and the results are handed to the
+// scorer's layout (a segment = one column, all view groups alike) through 768 bytes of LDS.
+template <class ST>
+__device__ __forceinline__ void fill_patch_64(const EstConst& c, const LaneCtx<8>& L, int x, int y, int a, const PixIn<8>& in, Patch<8>& P, ST& st) {
+	const int row = L.lane >> 3, col = L.lane & 7;
+	const bool valid = row <= a && col <= a;
+	const int i = -a + 2 * (row < a ? row : a), j = -a + 2 * (col < a ? col : a);
+	const float sigmaColor = -1.f / (2.f * HC_SQ(0.2f));
+	const float sigmaSpatial = -1.f / (2.f * (float)HC_SQ(a));
+	const float I = in.I[0];
+	const float wColor = HC_SQ(I - in.center) * sigmaColor;
+	const float wSpatial = (float)(HC_SQ(j) + HC_SQ(i)) * sigmaSpatial;
+	const float we = pm_expf(wColor + wSpatial);
+	const float w = valid ? we : 0.f;
+	const float swi = group_sum<64>(I * w), sw = group_sum<64>(w);
+	const float tm = swi / sw;
+	const float t = I - tm;
+	const float tw = w * t;
+	P.sumW = sw;
+	P.invSumW = 1.0f / sw;
+	P.normSq0 = group_sum<64>(tw * t);
+	P.x = x; P.y = y; P.a = a;
+	P.px0 = (float)(x - a + 2 * (L.seg < a ? L.seg : a));
+	st.put_patch64(row, col, (float)(y + i), w, tw);
+}
 template <int S, class ST>
 __device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& L, int x, int y, const PixIn<S>& in, Patch<S>& P, ST& st) {
 	const int a = patch_halfwin(c, in.tx);
-	if constexpr (S == 8) {
-		if (a == 6) fill_patch_n<S, 7>(c, L, x, y, a, in, P, st);
-		else if (a == 5) fill_patch_n<S, 6>(c, L, x, y, a, in, P, st);
-		else fill_patch_n<S, 8>(c, L, x, y, a, in, P, st);
-	} else {
-		fill_patch_n<S, 64 / S>(c, L, x, y, a, in, P, st);
-	}
+	if constexpr (S == 8) fill_patch_64(c, L, x, y, a, in, P, st);
+	else fill_patch_n<S, 64 / S>(c, L, x, y, a, in, P, st);
 }
 
 // smoothness neighbours (DepthMap.h:376-382 NeighborEstimate): slot k lives in lane k
@@ -1225,7 +1277,9 @@ template <int S>
 __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long long* evalsOut) {
 	LaneCtx<S> L;
 	lane_init<S>(c, L);
+	__shared__ float stage[4][3][8][8]; // one hand-over area per wave (launch_bounds 256)
 	RegStore<S> st;
+	st.stage = stage[threadIdx.x >> 6]; st.seg = L.seg;
 	st.put_view(as_global(c.views) + (L.vact ? L.view : 0), L.seg);
 	const int nrows = c.H - 2 * kHalfWindow, ncols = c.W - 2 * kHalfWindow;
 	const int total = nrows * ncols;
@@ -1287,7 +1341,9 @@ __global__ void probe_patch_kernel(EstConst c, PixIn<S> in, Patch<S>* out, RegSt
 	LaneCtx<S> L;
 	lane_init<S>(c, L);
 	Patch<S> P;
+	__shared__ float stage[3][8][8];
 	RegStore<S> st;
+	st.stage = stage; st.seg = L.seg;
 	fill_patch<S>(c, L, 100, 100, in, P, st);
 	out[threadIdx.x] = P;
 	so[threadIdx.x] = st;

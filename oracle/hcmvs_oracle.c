@@ -405,6 +405,29 @@ static void fill_patch(const est_ctx* c, pix_state* ps, int x, int y) {
 	} else {
 		const int S = c->S, MAXM = 64 / S, nside = ps->nside;
 		float pa[64], pb[64];
+		if (S == 8) {
+			/* 5..8 source views: the kernels give every tap of the patch its own lane (lane = 8 * row + column, lanes past
+			 * the patch add exactly +0) and sum the 64 lanes with the xor butterfly */
+			for (int l = 0; l < 64; ++l) {
+				const int row = l >> 3, col = l & 7;
+				pa[l] = pb[l] = 0.f;
+				if (row >= nside || col >= nside) continue;
+				const int k = row * nside + col;
+				pa[l] = I[k] * ps->w[k]; pb[l] = ps->w[k];
+			}
+			const float swi = butterfly_sum(pa, 64), sw = butterfly_sum(pb, 64);
+			const float tm = swi / sw;
+			for (int l = 0; l < 64; ++l) {
+				const int row = l >> 3, col = l & 7;
+				pa[l] = 0.f;
+				if (row >= nside || col >= nside) continue;
+				const int k = row * nside + col;
+				const float t = I[k] - tm;
+				ps->tw[k] = ps->w[k] * t;
+				pa[l] = ps->tw[k] * t;
+			}
+			ps->sumW = sw; ps->normSq0 = butterfly_sum(pa, 64);
+		} else {
 		for (int s = 0; s < S; ++s) {
 			float sa = 0, sb = 0;
 			for (int m = 0; m < MAXM; ++m) {
@@ -430,7 +453,9 @@ static void fill_patch(const est_ctx* c, pix_state* ps, int x, int y) {
 			pa[s] = sa;
 		}
 		ps->sumW = sw; ps->normSq0 = butterfly_sum(pa, S);
+		}
 	}
+
 	/* DM.cpp:517, Camera.h:299-304 */
 	if (c->p.arith_mode == HCOR_ARITH_DEVICE) {
 		ps->X0[0] = ((double)x - ref->K[2]) * c->ifx;
