@@ -1112,19 +1112,22 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			}
 			phase = again ? PH_PICK : PH_DONE;
 		} else {
+			// the sequential scan stops at the first valid trial that beats the estimate (DepthMap.cpp:1484): found with
+			// one ballot; the trials before it were scored and rejected, the ones behind it are regenerated
 			int tnext = nR;
-			for (int t = t0; t < nR; ++t) {
-				if (!((vmask >> t) & 1ull)) continue;
-				const float nconf = rlf(all, t);
-				++evals; // the sequential algorithm scores exactly the valid trials it reaches
-				if (conf > nconf) {
-					conf = nconf; depth = rlf(hd, t); n0 = rlf(h0, t); n1 = rlf(h1, t); n2 = rlf(h2, t);
-					p0 = rlf(hq0, t); p1 = rlf(hq1, t);
-					++idxScaleRange;
-					scaleRange = 1.f / (float)(1u << idxScaleRange);
-					tnext = t + 1; // later trials used the old estimate: regenerate them
-					break;
-				}
+			const unsigned long long range = ((1ull << nR) - 1ull) & ~((1ull << t0) - 1ull);
+			const unsigned long long live = vmask & range;
+			const unsigned long long better = __ballot(conf > all) & live;
+			if (better) {
+				const int t = __builtin_ctzll(better);
+				evals += (unsigned)__builtin_popcountll(live & ((2ull << t) - 1ull)); // the valid trials the sequential algorithm reaches
+				conf = rlf(all, t); depth = rlf(hd, t); n0 = rlf(h0, t); n1 = rlf(h1, t); n2 = rlf(h2, t);
+				p0 = rlf(hq0, t); p1 = rlf(hq1, t);
+				++idxScaleRange;
+				scaleRange = 1.f / (float)(1u << idxScaleRange);
+				tnext = t + 1; // later trials used the old estimate: regenerate them
+			} else {
+				evals += (unsigned)__builtin_popcountll(live);
 			}
 			t0 = tnext;
 			if (t0 >= nR) phase = PH_DONE;
