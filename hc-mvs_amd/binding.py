@@ -50,7 +50,7 @@ SYMBOLS = ["hcmvs_default_params", "hcmvs_create", "hcmvs_destroy", "hcmvs_last_
            "hcmvs_synchronize", "hcmvs_upload_view", "hcmvs_set_view_device", "hcmvs_release_view",
            "hcmvs_get_gradient_map", "hcmvs_estimate", "hcmvs_estimate_device", "hcmvs_estimate_batch_device", "hcmvs_get_stats",
            "hcmvs_splat_init", "hcmvs_triangulate_init", "hcmvs_triangulate_points", "hcmvs_set_depthmap", "hcmvs_set_depthmap_device", "hcmvs_get_depthmap",
-           "hcmvs_set_neighbors", "hcmvs_filter", "hcmvs_fuse"]
+           "hcmvs_set_neighbors", "hcmvs_filter", "hcmvs_set_fuse_order", "hcmvs_fuse"]
 
 
 def triangulate_points(w, h, K, R, Cc, points_xyz, avg_depth=0.0, add_corners=True):
@@ -109,6 +109,7 @@ def lib():
         L.hcmvs_set_depthmap_device.argtypes = [vp, C.c_uint32, vp, vp, vp, C.c_float, C.c_float]
         L.hcmvs_get_depthmap.argtypes = [vp, C.c_uint32, fp, fp, fp]
         L.hcmvs_set_neighbors.argtypes = [vp, C.c_uint32, u32p, C.c_int32]
+        L.hcmvs_set_fuse_order.argtypes = [vp, C.c_int32]
         L.hcmvs_filter.argtypes = [vp, C.c_uint32, u32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, fp, fp,
                                    u64p, u64p]
         L.hcmvs_fuse.argtypes = [vp, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint64,
@@ -264,6 +265,10 @@ class Context:
     def set_neighbors(self, vid, ids):
         arr = (C.c_uint32 * max(len(ids), 1))(*ids)
         self._chk(lib().hcmvs_set_neighbors(self._h, vid, arr, len(ids)))
+
+    def set_fuse_order(self, mode):
+        """0: raster order (bit-exact with the reference's sequential fusion), 1: hashed order (few rounds)"""
+        self._chk(lib().hcmvs_set_fuse_order(self._h, int(mode)))
 
     def filter(self, ref_id, neighbor_ids, adjust=True, n_min_views=2, n_min_views_adjust=1, depth_diff_threshold=0.01):
         """FilterDepthMap: returns (new_depth, new_conf, n_processed, n_discarded)"""

@@ -48,8 +48,8 @@ struct FuseTables {
 FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_t* fillT, uint32_t* bidders, uint32_t* cntP, uint32_t* offP,
                        uint32_t* nbrList, uint32_t* doneRound, uint32_t* queued, size_t stride);
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
-                       uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters, hipStream_t s);
-void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* roundCnt, hipStream_t s);
+                       uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters, int order, hipStream_t s);
+void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* roundCnt, int order, hipStream_t s);
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, uint32_t* list0, uint32_t* list1, uint32_t* roundCnt,
                       uint32_t* barrier, uint32_t roundCap, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
                       int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, int blocks, hipStream_t s);

@@ -257,7 +257,9 @@ __global__ void fuse_fill_kernel(int nNb, FuseTables tb, const uint32_t* pending
 
 // per pending pixel: the pixels sharing a target with it, split into lower (they block it) and higher raster indices
 // (it wakes them); pass 0 counts, pass 1 writes the lists at the scanned offsets
-__global__ void fuse_links_kernel(int nNb, FuseTables tb, const uint32_t* pending, const uint32_t* roundCnt, int write) {
+// order: 0 = raster order (the reference's), 1 = a fixed pseudo-random order (a bijective hash of the raster index)
+__device__ __forceinline__ uint32_t fuse_prio(uint32_t idx, int order) { return order ? idx * 0x9E3779B1u : idx; }
+__global__ void fuse_links_kernel(int nNb, FuseTables tb, const uint32_t* pending, const uint32_t* roundCnt, int write, int order) {
 	const int n = (int)roundCnt[1];
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint32_t idx = pending[i];
@@ -270,8 +272,9 @@ __global__ void fuse_links_kernel(int nNb, FuseTables tb, const uint32_t* pendin
 			const uint32_t o = tb.offT[t], len = tb.cntT[t];
 			for (uint32_t k = 0; k < len; ++k) {
 				const uint32_t b = tb.bidders[o + k];
-				if (b < idx) { if (write) tb.nbrList[oLow + nLow] = b; ++nLow; }
-				else if (b > idx) { if (write) tb.nbrList[oHigh + nHigh] = b; ++nHigh; }
+				if (b == idx) continue;
+				if (fuse_prio(b, order) < fuse_prio(idx, order)) { if (write) tb.nbrList[oLow + nLow] = b; ++nLow; }
+				else { if (write) tb.nbrList[oHigh + nHigh] = b; ++nHigh; }
 			}
 		}
 		if (!write) { tb.cntP[idx] = nLow; tb.cntP[tb.stride + idx] = nHigh; }
@@ -530,15 +533,15 @@ FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_
 // begin of an image pass: first candidate list (roundCnt[1]), targets, per-target lists, per-pixel link counts + offsets
 // (cntT / fillT / cntP must be zero).  fuse_links_fill writes the link lists once the host has checked their total size.
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
-                       uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters, hipStream_t s) {
+                       uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters, int order, hipStream_t s) {
 	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, roundCnt, flag, counters);
 	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntT, tb.offT, (int)(tb.stride * (size_t)A.nNeighbors), s);
 	hipLaunchKernelGGL(fuse_fill_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, roundCnt);
-	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, roundCnt, 0);
+	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, roundCnt, 0, order);
 	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntP, tb.offP, (int)(2 * tb.stride), s);
 }
-void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* roundCnt, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, roundCnt, 1);
+void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* roundCnt, int order, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, roundCnt, 1, order);
 }
 // the whole image pass in one persistent launch; `blocks` must not exceed the number of workgroups the device keeps
 // resident at once (the rounds are separated by a grid barrier)

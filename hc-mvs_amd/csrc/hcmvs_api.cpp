@@ -71,6 +71,7 @@ struct hcmvs_ctx {
 	int lastSweeps = 0;
 	bool haveStats = false;
 	int sweepLag = 1;
+	int fuseOrder = 0; // hcmvs_set_fuse_order
 	int xcdAffinity = 1; // rows of an image prefer the workgroups of one XCD (HCMVS_XCD_AFFINITY=0 turns it off)
 	// filter / fuse scratch
 	DevMap* dMaps = nullptr; size_t capMaps = 0;
@@ -741,6 +742,13 @@ int hcmvs_filter(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* nbr, int32_t N, 
 	return HCMVS_OK;
 }
 
+int hcmvs_set_fuse_order(hcmvs_ctx* c, int32_t mode) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (mode != 0 && mode != 1) return fail(c, HCMVS_ERR_INVALID, "set_fuse_order: mode %d not in {0, 1}", mode);
+	c->fuseOrder = mode;
+	return HCMVS_OK;
+}
+
 int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
                float normal_diff_deg, float depthweight, float normalweight, uint64_t capacity, float* xyz, float* normal,
                uint8_t* bgr, uint32_t* n_views, uint64_t* n_points, uint64_t* n_depths) {
@@ -811,7 +819,7 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 		HIPCHK(c, hipMemsetAsync(c->counters, 0, 64, s));
 		HIPCHK(c, hipMemsetAsync(roundCnt, 0, oFlag - oCnt, s));                              // round counters + barrier words
 		HIPCHK(c, hipMemsetAsync(cntT, 0, (oOffT - oCntT), s));                               // per-target counts, fill cursors, per-pixel link counts
-		launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, lists[1], roundCnt, flag, c->counters, s);
+		launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, lists[1], roundCnt, flag, c->counters, c->fuseOrder, s);
 		uint32_t lastOff = 0, lastCnt = 0; // total size of the link lists = last offset + last count
 		HIPCHK(c, hipMemcpyAsync(&lastOff, offP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, s));
 		HIPCHK(c, hipMemcpyAsync(&lastCnt, cntP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, s));
@@ -819,7 +827,7 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 		if ((size_t)lastOff + lastCnt > linkCap)
 			return fail(c, HCMVS_ERR_CAPACITY, "fuse: image %u has %zu pixel links (room for %zu): too many of its pixels project onto the same neighbour pixels",
 			            A.id, (size_t)lastOff + lastCnt, linkCap);
-		launch_fuse_links_fill(A, tb, lists[1], roundCnt, s);
+		launch_fuse_links_fill(A, tb, lists[1], roundCnt, c->fuseOrder, s);
 		launch_fuse_pass(A, c->dMaps, tb, lists[0], lists[1], roundCnt, bar, (uint32_t)kRoundCap,
 		                 pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, n_min_views_fuse, thDepth, normalError, c->counters,
 		                 getenv("HCMVS_FUSE_BLOCKS") ? std::min(nCU, std::max(1, atoi(getenv("HCMVS_FUSE_BLOCKS")))) : nCU, s);

@@ -40,6 +40,7 @@ struct Options { // DensifyPointCloud.cpp:139-198 (defaults from there)
 	float photometricFlow = 0.5f, depthweight = 1.f, normalweight = 1.f;
 	int initTriangulate = 1;      // 1: Delaunay init from the sparse points, 0: read the previous level's maps (SceneDensify.cpp:522-553)
 	int minViewsTrustPoint = 2;   // < 2: splat the sparse points instead (SceneDensify.cpp:783-808)
+	int fuseOrder = 0;            // hcmvs_set_fuse_order: 0 reference raster order (exact), 1 hashed order (few dependent rounds)
 	int device = 0, batch = 8;
 	uint32_t seed = 1234;
 };
@@ -393,6 +394,7 @@ int main(int argc, char** argv) {
 	geti("--n-propagatehalfwin", o.propagateHalfWin); geti("--n-propagatestep", o.propagateStep);
 	getf("--n-photometric_flow", o.photometricFlow); getf("--depthweight", o.depthweight); getf("--normalweight", o.normalweight);
 	geti("--n-initTriangulate", o.initTriangulate); geti("--min-views-trust-point", o.minViewsTrustPoint);
+	geti("--fuse-order", o.fuseOrder);
 	geti("--device", o.device); geti("--batch", o.batch);
 	if (kv.count("--seed")) o.seed = (uint32_t)strtoul(kv["--seed"].c_str(), nullptr, 10);
 	for (const char* k : {"--n-opticalflow", "--n-viewspread", "--use-semantic", "--n-nOptimize", "--n-usegeoconsistency", "--n-usepartconsistency"})
@@ -560,6 +562,7 @@ int main(int argc, char** argv) {
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return images[a].neighbors.size() > images[b].neighbors.size(); });
 	std::vector<float> xyz(capacity * 3), nrm(capacity * 3); std::vector<uint8_t> bgr(capacity * 3); std::vector<uint32_t> nviews(capacity);
 	uint64_t nPoints = 0, nDepths = 0;
+	CHK(hcmvs_set_fuse_order(ctx, o.fuseOrder));
 	CHK(hcmvs_fuse(ctx, order.data(), (int32_t)order.size(), std::min<int>(o.numberViewsFuse, (int)images.size()), 0.01f, 25.f, o.depthweight,
 	               o.normalweight, capacity, xyz.data(), nrm.data(), bgr.data(), nviews.data(), &nPoints, &nDepths));
 	xyz.resize(nPoints * 3); nrm.resize(nPoints * 3); bgr.resize(nPoints * 3);

@@ -173,6 +173,14 @@ int hcmvs_filter(hcmvs_ctx* ctx, uint32_t ref_id, const uint32_t* neighbor_ids, 
                  int32_t n_min_views, int32_t n_min_views_adjust, float depth_diff_threshold, float* out_depth,
                  float* out_conf, uint64_t* n_processed, uint64_t* n_discarded);
 
+/* Order in which the pixels of ONE image are visited by hcmvs_fuse (the image order is always the caller's).
+ * 0 (default): raster order, the reference's (SceneDensify.cpp:3355-3358); the cloud equals the sequential one bit for
+ *    bit, but neighbouring pixels that share target pixels form dependence chains thousands of rounds long.
+ * 1: a fixed pseudo-random order (a bijective hash of the raster index): the same greedy rule visits the pixels in
+ *    another order, the chains are O(log n) rounds, and the cloud differs from the reference's within the tolerance
+ *    the north star states (point count within 1 %); the output is still written in raster order and deterministic. */
+int hcmvs_set_fuse_order(hcmvs_ctx* ctx, int32_t mode);
+
 /* void DepthMapsData::FuseDepthMaps(PointCloud&, bool, bool) (SceneDensify.cpp:3265-3495).  order: image ids,
  * best connected first (SceneDensify.cpp:3302).  Output host buffers hold `capacity` points: xyz 3 f32, normal
  * 3 f32 or NULL, bgr 3 u8 (B,G,R) or NULL, n_views u32 or NULL.  *n_points / *n_depths are the numbers the

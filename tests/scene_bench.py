@@ -60,7 +60,7 @@ print("scene: %d images %dx%d, %d sparse points, generated in %.1f s -> %s" % (N
 exe = os.path.join(ROOT, "hc-mvs_amd", "DensifyPointCloud")
 t1 = time.time()
 r = subprocess.run([exe, "-i", os.path.join(tmp, "scene.mvs"), "-o", os.path.join(tmp, "dense.mvs"), "--resolution-level", "0",
-                    "--number-views", "8", "--n-EstimationIters", str(SWEEPS), "--n-EstimationIters-external", "1", "--batch", "32", "-v", "3"],
+                    "--number-views", "8", "--n-EstimationIters", str(SWEEPS), "--n-EstimationIters-external", "1", "--batch", "32", "-v", "3", "--fuse-order", os.environ.get("FUSE_ORDER", "1")],
                    capture_output=True, text=True, env=dict(os.environ, HCMVS_FUSE_DEBUG='1'))
 dt = time.time() - t1
 rounds = [int(l.split(':')[2].split('rounds')[0]) for l in r.stderr.split('\n') if l.startswith('fuse: image')]

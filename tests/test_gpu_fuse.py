@@ -66,3 +66,30 @@ def test_filter_bit_exact(ctx, adjust):
         assert np.array_equal(gd, d) and np.array_equal(gc, c)
     with pytest.raises(binding.HcmvsError):
         ctx.filter(0, maps[0]["neighbors"][:1], adjust=adjust, n_min_views=2)
+
+
+@pytest.mark.parametrize("kw", [dict(noise=0.003, outliers=0.05, holes=0.1), dict(w=144, h=112, f=130.0, n_views=7, noise=0.002, outliers=0.03)])
+def test_fuse_hashed_order_within_tolerance(ctx, kw):
+    """hcmvs_set_fuse_order(1): the same greedy rule with the pixels of an image visited in a hashed order.  Not the
+    reference's cloud bit for bit, but within the tolerance the north star states (point count within 1 %), and
+    deterministic."""
+    maps, order = make_maps(**kw)
+    want = O.fuse_depthmaps(maps, order, 200000)
+    try:
+        ctx.set_fuse_order(1)
+        upload(ctx, maps)
+        a = ctx.fuse(order, 200000)
+        upload(ctx, maps)
+        b = ctx.fuse(order, 200000)
+    finally:
+        ctx.set_fuse_order(0)
+    assert a["n_points"] == b["n_points"] and np.array_equal(a["xyz"], b["xyz"]) and np.array_equal(a["n_views"], b["n_views"])
+    assert abs(a["n_points"] - want["n_points"]) <= 0.01 * want["n_points"]
+    assert abs(a["n_depths"] - want["n_depths"]) <= 0.01 * want["n_depths"]   # later images see other invalidations
+    # the clouds describe the same surface: nearly every point of one has a point of the other within a small distance
+    from scipy.spatial import cKDTree
+    d, _ = cKDTree(want["xyz"]).query(a["xyz"])
+    scale = np.linalg.norm(want["xyz"].max(0) - want["xyz"].min(0))
+    assert (d < 2e-3 * scale).mean() > 0.97
+    with pytest.raises(binding.HcmvsError):
+        ctx.set_fuse_order(2)
