@@ -64,20 +64,24 @@ def fuse_throughput(ctx, n_views=8):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from fusion_scene import make_maps
     maps, order = make_maps(w=W, h=H, f=FOCAL, n_views=n_views, noise=0.002, outliers=0.03, holes=0.05)
-    best = None
-    for _ in range(2):
-        for i, m in enumerate(maps):
-            ctx.upload_view(9000 + i, m["gray"], m["K"], m["R"], m["C"], bgr=m["bgr"])
-            ctx.set_depthmap(9000 + i, m["depth"], m["normal"], m["conf"], m["d_min"], m["d_max"])
-            ctx.set_neighbors(9000 + i, [9000 + j for j in m["neighbors"][:8]])
-        t0 = time.perf_counter()
-        got = ctx.fuse([9000 + i for i in order], W * H * n_views // 2)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, got["n_points"], got["n_depths"])
-    dt, npts, ndep = best
-    return {"points_per_s": round(npts / dt), "depths_per_s": round(ndep / dt), "ms": round(dt * 1e3, 2), "points": int(npts),
-            "views": "%d x %dx%d" % (n_views, W, H)}
+    out = {"views": "%d x %dx%d" % (n_views, W, H)}
+    for mode, name in ((0, "raster_order"), (1, "hashed_order")):  # hcmvs_set_fuse_order: 0 = the reference's order, bit-exact
+        ctx.set_fuse_order(mode)
+        best = None
+        for _ in range(2):
+            for i, m in enumerate(maps):
+                ctx.upload_view(9000 + i, m["gray"], m["K"], m["R"], m["C"], bgr=m["bgr"])
+                ctx.set_depthmap(9000 + i, m["depth"], m["normal"], m["conf"], m["d_min"], m["d_max"])
+                ctx.set_neighbors(9000 + i, [9000 + j for j in m["neighbors"][:8]])
+            t0 = time.perf_counter()
+            got = ctx.fuse([9000 + i for i in order], W * H * n_views // 2)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, got["n_points"], got["n_depths"])
+        dt, npts, ndep = best
+        out[name] = {"points_per_s": round(npts / dt), "depths_per_s": round(ndep / dt), "ms": round(dt * 1e3, 2), "points": int(npts)}
+    ctx.set_fuse_order(0)
+    return out
 
 
 def pmc_value(batch, what):
