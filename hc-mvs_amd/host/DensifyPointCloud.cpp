@@ -447,10 +447,15 @@ int main(int argc, char** argv) {
 	hcmvs_ctx* ctx = nullptr;
 	if (hcmvs_create(o.device, &ctx) != HCMVS_OK) { fprintf(stderr, "error: no usable MI355X device (there is no CPU path)\n"); return EXIT_FAILURE; }
 	std::vector<uint32_t> todo;
+	for (auto& im : images)
+		if (im.valid) CHK(hcmvs_upload_view(ctx, im.id, im.w, im.h, im.gray.data(), im.bgr.data(), im.cam.K, im.cam.R, im.cam.C));
+	std::vector<char> selected(images.size(), 0);
+#pragma omp parallel for schedule(dynamic, 1)
+	for (long i = 0; i < (long)images.size(); ++i) // every image writes only its own lists (SceneDensify.cpp:3590-3634 is an OpenMP loop too)
+		if (images[i].valid) selected[i] = select_views(images, verts, (uint32_t)i, 12, o.numberViews) ? 1 : 0;
 	for (auto& im : images) {
 		if (!im.valid) continue;
-		CHK(hcmvs_upload_view(ctx, im.id, im.w, im.h, im.gray.data(), im.bgr.data(), im.cam.K, im.cam.R, im.cam.C));
-		if (!select_views(images, verts, im.id, 12, o.numberViews)) {
+		if (!selected[im.id]) {
 			if (o.verbosity > 1) printf("Reference image %3u has not enough images in view\n", im.id);
 			continue;
 		}
@@ -466,41 +471,61 @@ int main(int argc, char** argv) {
 	//   nMinViewsTrustPoint < 2      splat of the sparse points (SceneDensify.cpp:783-808)
 	//   initTriangulate != 0         Delaunay triangulation of the sparse points (DepthMapsData::InitDepthMap, DepthMap.cpp:1796-1936)
 	//   initTriangulate == 0         the previous (coarser) level's maps from the working folder, resized (SceneDensify.cpp:527-553)
-	for (uint32_t id : todo) {
-		ImageData& im = images[id];
-		std::vector<float> pts;
-		for (uint32_t idx : im.points) { pts.push_back(verts[idx].X[0]); pts.push_back(verts[idx].X[1]); pts.push_back(verts[idx].X[2]); }
-		const size_t n = (size_t)im.w * im.h;
-		std::vector<float> d(n), nn(3 * n, 0.f);
-		if (o.minViewsTrustPoint < 2) {
-			CHK(hcmvs_splat_init(ctx, id, pts.data(), (int32_t)im.points.size(), d.data(), nn.data(), &im.dMin, &im.dMax));
-		} else if (o.initTriangulate) {
-			CHK(hcmvs_triangulate_init(ctx, id, pts.data(), (int32_t)im.points.size(), 0.f, 1, d.data(), nn.data(), &im.dMin, &im.dMax));
-		} else {
-			char nm[64];
-			snprintf(nm, sizeof nm, "/depth%04u.dmap", id);
-			int pw = 0, ph = 0;
-			std::vector<float> pd, pn;
-			if (!load_dmap(o.workdir + nm, pw, ph, pd, pn)) { fprintf(stderr, "error: can not read the previous level's '%s%s'\n", o.workdir.c_str(), nm); return EXIT_FAILURE; }
-			if (o.verbosity > 2) printf("read  :  %s%s (%dx%d -> %dx%d)\n", o.workdir.c_str(), nm, pw, ph, im.w, im.h);
-			resize_cubic(pd, pw, ph, 1, d, im.w, im.h);
-			resize_cubic(pn, pw, ph, 3, nn, im.w, im.h);
-			// depth range of the resized map (SceneDensify.cpp:544-553; taken over the valid depths only, the cubic
-			// kernel overshoots next to holes and a non-positive bound would poison the random-depth range)
-			float lo = 3.402823466e+38f, hi = 0.f;
-			for (size_t k = 0; k < n; ++k) {
-				if (!(d[k] > 0.f)) { d[k] = 0.f; continue; }
-				lo = std::min(lo, d[k]); hi = std::max(hi, d[k]);
-				float* q = &nn[3 * k];
-				const float len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
-				if (len > 0.f) { q[0] /= len; q[1] /= len; q[2] /= len; }
+	// the host part (triangulation / resize) of up to 16 images at a time runs on all cores, like the reference's OpenMP
+	// loop over the images (SceneDensify.cpp:3651-3667); the uploads follow in order
+	for (size_t c0 = 0; c0 < todo.size(); c0 += 16) {
+		const size_t c1 = std::min(todo.size(), c0 + 16);
+		std::vector<std::vector<float>> dAll(c1 - c0), nAll(c1 - c0);
+		std::vector<int> failed(c1 - c0, 0);
+#pragma omp parallel for schedule(dynamic, 1)
+		for (long k = (long)c0; k < (long)c1; ++k) {
+			ImageData& im = images[todo[k]];
+			const uint32_t id = im.id;
+			std::vector<float> pts;
+			for (uint32_t idx : im.points) { pts.push_back(verts[idx].X[0]); pts.push_back(verts[idx].X[1]); pts.push_back(verts[idx].X[2]); }
+			const size_t n = (size_t)im.w * im.h;
+			std::vector<float>& d = dAll[k - c0];
+			std::vector<float>& nn = nAll[k - c0];
+			d.assign(n, 0.f); nn.assign(3 * n, 0.f);
+			if (o.minViewsTrustPoint < 2) {
+				if (hcmvs_splat_init(ctx, id, pts.data(), (int32_t)im.points.size(), d.data(), nn.data(), &im.dMin, &im.dMax) != HCMVS_OK) failed[k - c0] = 1;
+			} else if (o.initTriangulate) {
+				if (hcmvs_triangulate_points(im.w, im.h, im.cam.K, im.cam.R, im.cam.C, pts.data(), (int32_t)im.points.size(), 0.f, 1, d.data(), nn.data(),
+				                             &im.dMin, &im.dMax) != HCMVS_OK) failed[k - c0] = 1;
+			} else {
+				char nm[64];
+				snprintf(nm, sizeof nm, "/depth%04u.dmap", id);
+				int pw = 0, ph = 0;
+				std::vector<float> pd, pn;
+				if (!load_dmap(o.workdir + nm, pw, ph, pd, pn)) { failed[k - c0] = 2; continue; }
+				if (o.verbosity > 2) printf("read  :  %s%s (%dx%d -> %dx%d)\n", o.workdir.c_str(), nm, pw, ph, im.w, im.h);
+				resize_cubic(pd, pw, ph, 1, d, im.w, im.h);
+				resize_cubic(pn, pw, ph, 3, nn, im.w, im.h);
+				// depth range of the resized map (SceneDensify.cpp:544-553; taken over the valid depths only, the cubic
+				// kernel overshoots next to holes and a non-positive bound would poison the random-depth range)
+				float lo = 3.402823466e+38f, hi = 0.f;
+				for (size_t q_ = 0; q_ < n; ++q_) {
+					if (!(d[q_] > 0.f)) { d[q_] = 0.f; continue; }
+					lo = std::min(lo, d[q_]); hi = std::max(hi, d[q_]);
+					float* q = &nn[3 * q_];
+					const float len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+					if (len > 0.f) { q[0] /= len; q[1] /= len; q[2] /= len; }
+				}
+				if (!(hi > 0.f)) { failed[k - c0] = 3; continue; }
+				im.dMin = lo * 0.9f; im.dMax = hi * 1.1f;
 			}
-			if (!(hi > 0.f)) { fprintf(stderr, "error: '%s%s' holds no valid depth\n", o.workdir.c_str(), nm); return EXIT_FAILURE; }
-			im.dMin = lo * 0.9f; im.dMax = hi * 1.1f;
 		}
-		HIPOK(hipMalloc(&im.dDepth, n * 4)); HIPOK(hipMalloc(&im.dNormal, n * 12)); HIPOK(hipMalloc(&im.dConf, n * 4));
-		HIPOK(hipMemcpy(im.dDepth, d.data(), n * 4, hipMemcpyHostToDevice)); HIPOK(hipMemcpy(im.dNormal, nn.data(), n * 12, hipMemcpyHostToDevice));
-		HIPOK(hipMemset(im.dConf, 0, n * 4));
+		for (size_t k = c0; k < c1; ++k) {
+			ImageData& im = images[todo[k]];
+			if (failed[k - c0] == 2) { fprintf(stderr, "error: can not read the previous level's '%s/depth%04u.dmap'\n", o.workdir.c_str(), im.id); return EXIT_FAILURE; }
+			if (failed[k - c0] == 3) { fprintf(stderr, "error: '%s/depth%04u.dmap' holds no valid depth\n", o.workdir.c_str(), im.id); return EXIT_FAILURE; }
+			if (failed[k - c0]) { fprintf(stderr, "error: initialisation of image %u failed (%s)\n", im.id, hcmvs_last_error(ctx)); return EXIT_FAILURE; }
+			const size_t n = (size_t)im.w * im.h;
+			HIPOK(hipMalloc(&im.dDepth, n * 4)); HIPOK(hipMalloc(&im.dNormal, n * 12)); HIPOK(hipMalloc(&im.dConf, n * 4));
+			HIPOK(hipMemcpy(im.dDepth, dAll[k - c0].data(), n * 4, hipMemcpyHostToDevice));
+			HIPOK(hipMemcpy(im.dNormal, nAll[k - c0].data(), n * 12, hipMemcpyHostToDevice));
+			HIPOK(hipMemset(im.dConf, 0, n * 4));
+		}
 	}
 	const double tInit = now_s();
 	// outer iterations over all images (SceneDensify.cpp:3684), images of equal source count batched per launch
