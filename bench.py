@@ -34,14 +34,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 def cpu_baseline(n_threads):
     """The CPU oracle (restatement of the reference algorithm, reference arithmetic) on a bounded sample of
-    the same workload: 960x540, 8 source views, 7x7, 8 sweeps, row-pipelined over n_threads host threads."""
+    the same workload: ONE unit of it (1920x1080, 8 source views, 7x7, 8 sweeps), row-pipelined over n_threads host
+    threads (about 15 s on 16 cores)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
     synth = importlib.import_module("hc-mvs_amd.synth")
-    w, h = 960, 540
-    views = synth.make_views(w, h, FOCAL / 2, N_SRC, seed=2)
-    pts = synth.sparse_points(views, 500)
+    w, h = W, H
+    views = synth.make_views(w, h, FOCAL, N_SRC, seed=2)
+    pts = synth.sparse_points(views, 2000)
     L = O.lib()
     ref = O.make_view(views[0])
     d0 = np.zeros((h, w), np.float32); n0 = np.zeros((h, w, 3), np.float32)
@@ -54,7 +55,7 @@ def cpu_baseline(n_threads):
     O.estimate(views, p, dmin.value, dmax.value, d0, n0)
     dt = time.time() - t0
     return {"value": round(w * h / dt / 1e6, 4), "unit": "Mpix/s", "cores": n_threads, "kind": "port",
-            "sample": "960x540 synthetic scene, 8 source views, 7x7 taps, 8 sweeps, one full estimate (%.1f s)" % dt}
+            "sample": "one unit of the workload: %dx%d synthetic scene, 8 source views, 7x7 taps, 8 sweeps, one full estimate (%.1f s)" % (w, h, dt)}
 
 
 def fuse_throughput(ctx, n_views=8):
