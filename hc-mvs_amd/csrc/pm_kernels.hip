@@ -642,8 +642,12 @@ __device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>
 // of hypothesis t.
 template <int S>
 __device__ __forceinline__ float score_chunk(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const LdsStore<S>& st, float v0, float v1,
-                                             float F, float hd, float h0, float h1, float h2, unsigned long long todo, int base,
-                                             int fallback, float mine, unsigned& issued) {
+                                             float F, float hd, float h0, float h1, float h2, unsigned long long todoIn, int baseIn,
+                                             int fallbackIn, float mine, unsigned& issued) {
+	// the list of hypotheses is the same in every lane: keep it (and the loop over it) on the scalar unit
+	const unsigned long long todo = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(todoIn >> 32)) << 32) |
+	                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)todoIn);
+	const int base = __builtin_amdgcn_readfirstlane(baseIn), fallback = __builtin_amdgcn_readfirstlane(fallbackIn);
 	constexpr int NV = 64 / S;               // views (lane groups) of a wave
 	constexpr int HP = S < 8 ? S : 8;        // hypotheses per pair-pass (lane = g * NV + v)
 	WavePark<S>* pk = st.pk;
@@ -1158,7 +1162,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
                                                         int iter, int lag, int affinity) {
 	__shared__ RowShared<NW> sh;
 	__shared__ WavePark<S> park[NW];
-	const int wv = threadIdx.x >> 6;
+	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, and the compiler should know it
 	const bool rev = (iter & 1) != 0; // dir = RB2LT on odd iterations, DepthMap.cpp:418
 	unsigned evals = 0, issued = 0;
 	unsigned long long taps = 0; // patch taps of the sequential algorithm's evaluations (per source view)
