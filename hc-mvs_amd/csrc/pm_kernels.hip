@@ -1052,8 +1052,12 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		} else if (phase == PH_RAND) {
 			r0 = 0; r1 = nR; planeOwn = false; // the smoothness plane is whatever the propagation left (DepthMap.cpp:1450-1463)
 			if (lane < nR) {
-				hd = random_depth(c, rand_unit(rk, 3u * lane));
-				random_normal(G, rand_unit(rk, 3u * lane + 1u), rand_unit(rk, 3u * lane + 2u), h0, h1, h2);
+				// few pixels ever get here; the laundered key keeps this (loop-invariant, speculatable) arithmetic from being
+				// hoisted in front of the rounds of every pixel
+				uint32_t rkr = rk;
+				asm volatile("" : "+v"(rkr));
+				hd = random_depth(c, rand_unit(rkr, 3u * lane));
+				random_normal(G, rand_unit(rkr, 3u * lane + 1u), rand_unit(rkr, 3u * lane + 2u), h0, h1, h2);
 				hv = true;
 			}
 		} else {
