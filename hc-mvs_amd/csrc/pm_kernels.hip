@@ -590,8 +590,10 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 		b2 = fmaf(val, vw, b2);
 		cnum = fmaf(val, Ptw[m], cnum);
 	}
-	viewBad = (__ballot(bad) & L.groupMask) != 0ull;
-	sum = group_sum<S>(a); sumSq = group_sum<S>(b2); num = group_sum<S>(cnum);
+	// a tap outside the image (or a degenerate warp) must turn the view's score into thRobust: the lane poisons its
+	// partial sum, the NaN survives the butterfly and fails the `nrmSq > 0` test of view_score
+	viewBad = false;
+	sum = group_sum<S>(bad ? __builtin_nanf("") : a); sumSq = group_sum<S>(b2); num = group_sum<S>(cnum);
 }
 
 // DepthMap.cpp:597-615, 890-893: score of one view from its ZNCC sums, times the smoothness factor of the hypothesis
