@@ -117,11 +117,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    # rehearsal switches (not for measurements): all ranks on device 0 with the gloo backend, to exercise the N > 1 code
+    # path on a one-GPU box
+    if os.environ.get("HCMVS_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("HCMVS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
 
     binding = importlib.import_module("hc-mvs_amd.binding")  # imports torch first: one HIP runtime per process
