@@ -524,7 +524,20 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 		}
 		bool nan = false;
 		// perspective divide: ONE IEEE reciprocal per group of up to four taps (1/z_i = (1/prod z) * prod_{j!=i} z_j)
-		if constexpr (MAXM >= 4) {
+		if constexpr (S == 8) { // one reciprocal for the (up to) eight steps of the lane; steps past the patch repeat the last row
+			constexpr int last = MAXM - 1;
+			const float z4 = Xz[4 < last ? 4 : last], z5 = Xz[5 < last ? 5 : last], z6 = Xz[6 < last ? 6 : last], z7 = Xz[last];
+			const float p01 = Xz[0] * Xz[1], p23 = Xz[2] * Xz[3], p45 = z4 * z5, p67 = z6 * z7;
+			const float pa = p01 * p23, pb = p45 * p67;
+			const float r = 1.0f / (pa * pb);
+			nan = nan || !(fabsf(r) < __builtin_huge_valf()); // a zero / non-finite denominator poisons the lane
+			const float ra = r * pb, rb = r * pa;
+			const float r01 = ra * p23, r23 = ra * p01, r45 = rb * p67, r67 = rb * p45;
+			iz[0] = r01 * Xz[1]; iz[1] = r01 * Xz[0]; iz[2] = r23 * Xz[3]; iz[3] = r23 * Xz[2];
+			iz[4] = r45 * z5; iz[5] = r45 * z4;
+			if constexpr (MAXM > 6) iz[6] = r67 * z7;
+			if constexpr (MAXM > 7) iz[7] = r67 * z6;
+		} else if constexpr (MAXM >= 4) {
 #pragma unroll
 			for (int g = 0; g < MAXM; g += 4) {
 				constexpr int last = MAXM - 1;

@@ -588,7 +588,15 @@ static float score_view_dev(const est_ctx* c, const pix_state* ps, int v, float 
 			Xy[m] = fmaf(H[4], py, fmaf(H[3], px, H[5]));
 			Xz[m] = fmaf(H[7], py, fmaf(H[6], px, H[8])); /* steps past the patch repeat the clamped tap */
 		}
-		if (MAXM >= 4) { /* one IEEE reciprocal per group of four taps */
+		if (S == 8) { /* 5..8 views: one IEEE reciprocal for the eight steps of a lane (steps past the patch repeat the last row) */
+			const float q01 = Xz[0] * Xz[1], q23 = Xz[2] * Xz[3], q45 = Xz[4] * Xz[5], q67 = Xz[6] * Xz[7];
+			const float qa = q01 * q23, qb = q45 * q67;
+			const float r = 1.0f / (qa * qb);
+			const float ra = r * qb, rb = r * qa;
+			const float r01 = ra * q23, r23 = ra * q01, r45 = rb * q67, r67 = rb * q45;
+			iz[0] = r01 * Xz[1]; iz[1] = r01 * Xz[0]; iz[2] = r23 * Xz[3]; iz[3] = r23 * Xz[2];
+			iz[4] = r45 * Xz[5]; iz[5] = r45 * Xz[4]; iz[6] = r67 * Xz[7]; iz[7] = r67 * Xz[6];
+		} else if (MAXM >= 4) { /* one IEEE reciprocal per group of four taps */
 			for (int g = 0; g < MAXM; g += 4) {
 				const float q01 = Xz[g] * Xz[g + 1], q23 = Xz[g + 2] * Xz[g + 3];
 				const float r = 1.0f / (q01 * q23);
