@@ -24,7 +24,7 @@
  *   - Rows are handed out by an atomic ticket in dependency order, so a waiting worker always waits on one
  *     that is already running: no deadlock for any grid size or dispatch order.  Every spin is bounded.
  *
- * Arithmetic is an explicitly specified IEEE sequence (explicit fmaf, one IEEE reciprocal per four taps,
+ * Arithmetic is an explicitly specified IEEE sequence (explicit fmaf, one IEEE reciprocal per lane and evaluation,
  * pm_math.h transcendental functions); compile with -ffp-contract=off.
  */
 #include "pm_common.h"
