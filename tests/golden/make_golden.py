@@ -18,3 +18,10 @@ np.savez_compressed(os.path.join(HERE, "estimate_96x80_v3.npz"),
                     R=np.stack([v["R"] for v in views]), C=np.stack([v["C"] for v in views]),
                     d0=d0, n0=n0, dmin=dmin.value, dmax=dmax.value, seed=4321, depth=d, normal=n, conf=c, evals=ev)
 print("written", ev, (d > 0).mean())
+
+# the same scene in the DEVICE association (the IEEE operation sequence of the gfx950 kernels; it changes whenever the
+# kernels' association changes -- regenerate then): the bits the GPU must reproduce through the C-ABI
+pd = O.default_params(adapthalfwin=6, n_estimation_iters=3, seed=4321, arith_mode=O.ARITH_DEVICE, order=O.ORDER_ROWS, n_threads=4)
+dd, dn, dc, dev_ = O.estimate(views, pd, dmin.value, dmax.value, d0, n0)
+np.savez_compressed(os.path.join(HERE, "estimate_96x80_v3_device.npz"), depth=dd, normal=dn, conf=dc, evals=dev_)
+print("written (device association)", dev_, (dd > 0).mean())

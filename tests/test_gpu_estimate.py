@@ -248,3 +248,18 @@ def test_batch_mixed_view_counts(ctx):
         _compare(g, O.estimate(views, po, k[5], k[6], k[3], k[4])[:3])
     with pytest.raises(binding.HcmvsError):
         _batch_run(ctx, torch, [_scene(96, 80, 90.0, 3, seed=74), _scene(96, 80, 90.0, 8, seed=75)], pg, [0, 1])
+
+
+def test_matches_committed_golden(ctx):
+    """the kernels against the committed golden fixture of the device association (tests/golden/, generated by
+    make_golden.py from the oracle): depth, normal, score maps and the evaluation count, bit for bit"""
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gdir, "estimate_96x80_v3.npz"))
+    gd = np.load(os.path.join(gdir, "estimate_96x80_v3_device.npz"))
+    for i in range(len(g["gray"])):
+        ctx.upload_view(i, g["gray"][i], g["K"][i], g["R"][i], g["C"][i])
+    pg = binding.default_params(adapthalfwin=6, n_estimation_iters=3, seed=int(g["seed"]))
+    got = ctx.estimate(0, list(range(1, len(g["gray"]))), pg, float(g["dmin"]), float(g["dmax"]), g["d0"], g["n0"])
+    assert ctx.stats().evals == int(gd["evals"])
+    _compare(got, (gd["depth"], gd["normal"], gd["conf"]))

@@ -98,3 +98,15 @@ def test_golden_fixture():
     d, n, c, ev = O.estimate(views, p, float(g["dmin"]), float(g["dmax"]), g["d0"], g["n0"])
     assert ev == int(g["evals"])
     assert np.array_equal(d, g["depth"]) and np.array_equal(n, g["normal"]) and np.array_equal(c, g["conf"])
+
+
+def test_golden_fixture_device_association():
+    """the oracle's DEVICE association (the operation sequence of the kernels) against its committed bits
+    (tests/golden/estimate_96x80_v3_device.npz); the GPU is held to the same file in tests/test_gpu_estimate.py"""
+    g = np.load(GOLD)
+    gd = np.load(GOLD.replace(".npz", "_device.npz"))
+    views = [dict(gray=g["gray"][i], K=g["K"][i], R=g["R"][i], C=g["C"][i]) for i in range(len(g["gray"]))]
+    p = O.default_params(adapthalfwin=6, n_estimation_iters=3, seed=int(g["seed"]), arith_mode=O.ARITH_DEVICE, order=O.ORDER_ROWS, n_threads=3)
+    d, n, c, ev = O.estimate(views, p, float(g["dmin"]), float(g["dmax"]), g["d0"], g["n0"])
+    assert ev == int(gd["evals"])
+    assert np.array_equal(d, gd["depth"]) and np.array_equal(n, gd["normal"]) and np.array_equal(c, gd["conf"])
