@@ -872,6 +872,8 @@ __device__ __forceinline__ int wait_progress(HC_GLOBAL int32_t* word, int need, 
 template <int S>
 struct RowPipe {
 	uint8_t tx1;      // gradient-map byte of the next column (kept raw so that nothing waits on the load)
+	uint8_t tx2;      // S == 8: ... and of the one after it
+	float nI, nC;     // S == 8: reference-image tap / centre of the NEXT pixel, loaded a whole pixel ahead
 	int known;        // columns the previous logical row is known to have finished
 	int poll;         // progress value of an in-flight poll
 	int pendingPub;   // > 0: results up to this column are stored but not yet published
@@ -924,7 +926,7 @@ __device__ __forceinline__ void slot_setup(const EstConst& c, int lane, int x, i
 template <int S>
 __device__ __forceinline__ void prefetch_static(const EstConst& c, const LaneCtx<S>& L, int x, int y, int q, bool rev, PixIn<S>& in) {
 	slot_setup<S>(c, L.lane, x, y, rev, in);
-	load_patch_inputs<S>(c, L, x, y, in);
+	if constexpr (S != 8) load_patch_inputs<S>(c, L, x, y, in); // S == 8: the sweep loads them one pixel ahead
 	const int idx = y * c.W + x;
 	in.cur = load_dn(&c.dn[idx]);
 	in.curConf = load_f(&c.conf[idx]);
@@ -1243,14 +1245,34 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 			pp.fail = pp.known < 0;
 		}
 		const int x0 = rev ? c.W - 1 - kHalfWindow : kHalfWindow;
+		const int dx = rev ? -1 : 1;
 		pp.tx1 = as_global(c.gra)[y * c.W + x0];
+		if constexpr (S == 8) { // the patch inputs travel one pixel ahead of the pixel being processed, the gradient byte two
+			PixIn<S> first;
+			first.tx = (float)pp.tx1;
+			load_patch_inputs<S>(c, L, x0, y, first);
+			pp.nI = first.I[0]; pp.nC = first.center;
+			pp.tx2 = ncols > 1 ? as_global(c.gra)[y * c.W + x0 + dx] : (uint8_t)0;
+		}
 		for (int q = 0; q < ncols && !pp.fail; ++q) {
 			const int x = rev ? c.W - 1 - kHalfWindow - q : kHalfWindow + q;
 			// all loads of this pixel that do not depend on other rows go out in one batch ...
 			PixIn<S> in;
 			in.tx = (float)pp.tx1;
 			prefetch_static<S>(c, L, x, y, q, rev, in);
-			if (q + 1 < ncols) pp.tx1 = as_global(c.gra)[y * c.W + (rev ? x - 1 : x + 1)];
+			if constexpr (S == 8) {
+				in.I[0] = pp.nI; in.center = pp.nC;
+				if (q + 1 < ncols) { // next pixel's patch inputs (its gradient byte arrived a pixel ago)
+					PixIn<S> nxt;
+					nxt.tx = (float)pp.tx2;
+					load_patch_inputs<S>(c, L, x + dx, y, nxt);
+					pp.nI = nxt.I[0]; pp.nC = nxt.center;
+				}
+				pp.tx1 = pp.tx2;
+				if (q + 2 < ncols) pp.tx2 = as_global(c.gra)[y * c.W + x + 2 * dx];
+			} else {
+				if (q + 1 < ncols) pp.tx1 = as_global(c.gra)[y * c.W + x + dx];
+			}
 			if (pp.known >= q + 1) prefetch_up<S>(c, in);
 			// ... and the patch weights are computed while they (and the previous row) arrive
 			Patch<S> P;
