@@ -77,6 +77,7 @@ struct hcmvs_ctx {
 	DevMap* dMaps = nullptr; size_t capMaps = 0;
 	unsigned long long* counters = nullptr;
 	void* fuseScratch = nullptr; size_t capFuseScratch = 0;
+	bool errPending = false; // an estimate was enqueued since the error word was last read
 	int wavesPerRow = 0; // 0 = automatic: 2 waves per row for small batches (latency), 1 when >= 3 images fill the chip
 };
 
@@ -217,6 +218,18 @@ void hcmvs_destroy(hcmvs_ctx* c) {
 
 const char* hcmvs_last_error(const hcmvs_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+// A sweep worker that gave up waiting on its predecessor row leaves the error word set (pm_kernels.hip wait_progress):
+// every synchronising entry point reports it, so a caller of the asynchronous *_device entries learns of it without a
+// separate hcmvs_get_stats.  The stream must be idle.
+static int check_sweep_error(hcmvs_ctx* c) {
+	if (!c->errPending) return HCMVS_OK;
+	int32_t flags[2] = {0, 0};
+	HIPCHK(c, hipMemcpy(flags, c->sync, sizeof flags, hipMemcpyDeviceToHost));
+	c->errPending = false;
+	if (flags[1] != 0) return fail(c, HCMVS_ERR_TIMEOUT, "sweep worker timed out waiting for its predecessor row; the maps of the last estimate are incomplete");
+	return HCMVS_OK;
+}
+
 int hcmvs_set_stream(hcmvs_ctx* c, void* stream) {
 	if (!c) return HCMVS_ERR_INVALID;
 	c->stream = stream ? (hipStream_t)stream : c->ownStream;
@@ -226,7 +239,7 @@ int hcmvs_synchronize(hcmvs_ctx* c) {
 	if (!c) return HCMVS_ERR_INVALID;
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
-	return HCMVS_OK;
+	return check_sweep_error(c);
 }
 
 static int set_view(hcmvs_ctx* c, uint32_t id, int w, int h, const float* gray, const uint8_t* bgr, const double* K,
@@ -349,6 +362,8 @@ static int build_item(hcmvs_ctx* c, int slot, const hcmvs_batch_item& it, const 
 	if (rc) return rc;
 	memset(&k, 0, sizeof k);
 	k.W = ref.w; k.H = ref.h; k.V = n_src;
+	k.border = p->adapthalfwin > kHalfWindow ? p->adapthalfwin : kHalfWindow; // nSizeHalfWindow generalised (pm_common.h)
+	if (ref.w < 2 * k.border + 2 || ref.h < 2 * k.border + 2) return fail(c, HCMVS_ERR_INVALID, "estimate: view %u (%dx%d) has no pixel inside the %d px border", it.ref_id, ref.w, ref.h, k.border);
 	k.adapthalfwin = p->adapthalfwin; k.nRandomIters = p->n_random_iters; k.itExternal = p->it_external;
 	k.propHalfwin = p->propagate_halfwin; k.propStep = p->propagate_step;
 	k.ref = ref.gray; k.gra = ref.gra; k.views = c->dViews + (size_t)slot * kMaxViews;
@@ -426,7 +441,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 	if (!c) return HCMVS_ERR_INVALID;
 	if (!items || !p) return fail(c, HCMVS_ERR_INVALID, "estimate: null argument");
 	if (n_items < 1 || n_items > kMaxBatch) return fail(c, HCMVS_ERR_INVALID, "estimate: batch size %d not in 1..%d", n_items, kMaxBatch);
-	if (p->adapthalfwin < 1 || p->adapthalfwin > kHalfWindow) return fail(c, HCMVS_ERR_INVALID, "estimate: adapthalfwin %d not in 1..7", p->adapthalfwin);
+	if (p->adapthalfwin < 1 || p->adapthalfwin > kMaxHalfWindow) return fail(c, HCMVS_ERR_INVALID, "estimate: adapthalfwin %d not in 1..%d", p->adapthalfwin, kMaxHalfWindow);
 	if (p->n_estimation_iters < 0 || p->n_random_iters < 0 || p->n_random_iters > 20)
 		return fail(c, HCMVS_ERR_INVALID, "estimate: bad iteration counts");
 	HIPCHK(c, hipSetDevice(c->device));
@@ -436,7 +451,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 			return fail(c, HCMVS_ERR_INVALID, "estimate: the items of a batch must use source-view counts of one class (1, 2, 3-4, 5-8 or 9-16)");
 		int rc = build_item(c, i, items[i], p, c->hItems[i]);
 		if (rc) return rc;
-		const int rows = c->hItems[i].H - 2 * kHalfWindow;
+		const int rows = c->hItems[i].H - 2 * c->hItems[i].border;
 		if (rows > maxRows) maxRows = rows;
 		totalRows += rows;
 	}
@@ -463,8 +478,8 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 	for (int iter = 0; iter < p->n_estimation_iters; ++iter) {
 		HIPCHK(c, hipMemsetAsync(c->sync + 16, 0, sizeof(int32_t) * kMaxBatch, s)); // the tickets; the error word stays sticky
 		for (int i = 0; i < n_items; ++i)
-			HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * kHalfWindow) * kProgressStride * sizeof(int32_t), s));
-		launch_sweep(c->dItems, n_items, maxRows, totalRows, items[0].n_src, sy, iter, c->sweepLag,
+			HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * c->hItems[i].border) * kProgressStride * sizeof(int32_t), s));
+		launch_sweep(c->dItems, n_items, maxRows, totalRows, items[0].n_src, p->adapthalfwin > kHalfWindow, sy, iter, c->sweepLag,
 		             c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : 2), c->xcdAffinity, s);
 	}
 	HIPCHK(c, hipEventRecord(c->ev[2], s));
@@ -474,6 +489,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 	HIPCHK(c, hipGetLastError());
 	c->lastSweeps = p->n_estimation_iters;
 	c->haveStats = true;
+	c->errPending = true;
 	return HCMVS_OK;
 }
 
@@ -503,10 +519,8 @@ int hcmvs_get_stats(hcmvs_ctx* c, hcmvs_stats* out) {
 	HIPCHK(c, hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[3]));
 	out->n_sweeps = c->lastSweeps;
 	out->ms_sweep_avg = c->lastSweeps > 0 ? out->ms_sweeps / (float)c->lastSweeps : 0.f;
-	int32_t flags[2] = {0, 0};
-	HIPCHK(c, hipMemcpy(flags, c->sync, sizeof flags, hipMemcpyDeviceToHost));
-	if (flags[1] != 0) return fail(c, HCMVS_ERR_TIMEOUT, "sweep worker timed out waiting for its predecessor row");
-	return HCMVS_OK;
+	c->errPending = true;
+	return check_sweep_error(c);
 }
 
 int hcmvs_estimate(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* src_ids, int32_t n_src, const hcmvs_params* p, float d_min,

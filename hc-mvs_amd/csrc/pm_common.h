@@ -10,6 +10,12 @@
 namespace hcmvs {
 
 constexpr int kHalfWindow = 7;      // nSizeHalfWindow, DepthMap.h:354 (fixed border, DepthMap.cpp:442-447)
+// The reference fixes nSizeHalfWindow = 7 / nTexels = 64 at compile time (DepthMap.h:354-358).  Patches beyond that
+// (BASELINE.json configs[4]: 11 x 11 taps, adapthalfwin 10) generalise the two constants: the border every pass keeps
+// clear follows the half window, EstConst::border = max(7, adapthalfwin).
+constexpr int kMaxHalfWindow = 10;
+constexpr int kBigTaps = (kMaxHalfWindow + 1) * (kMaxHalfWindow + 1); // 121
+constexpr int kBigSlots = 128;      // tap slots of the big-patch tables (taps dealt round-robin to the lanes of a view group)
 constexpr int kMaxViews = 16;
 constexpr int kMaxSlots = 32;       // neighbour slots of one pixel (cross pattern: 4 * ceil(halfwin/step))
 constexpr int kProgressStride = 16; // ints between the progress words of consecutive rows (64 B)
@@ -25,6 +31,7 @@ struct DevView {
 // uniform constants of one EstimateDepthMap call (DepthMap.cpp:386-439 DepthEstimator ctor)
 struct EstConst {
 	int32_t W, H, V;
+	int32_t border;         // max(kHalfWindow, adapthalfwin): pixels closer than this to an edge are not estimated
 	int32_t adapthalfwin, nRandomIters, itExternal, propHalfwin, propStep;
 	const float* ref;
 	const uint8_t* gra;
@@ -60,7 +67,7 @@ void launch_gradient_map(const uint8_t* g8, uint8_t* gra, int W, int H, hipStrea
 void launch_median3(const float* in, float* out, int W, int H, hipStream_t s);
 void launch_score_pass(const EstConst& c, const float* depthIn, const float* normalIn, unsigned long long* evals,
                        hipStream_t s);
-void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int lag,
+void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int lag,
                   int wavesPerRow, int affinity, hipStream_t s);
 void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s);
 

@@ -203,6 +203,7 @@ struct RegStore {
 	float A[9], Hm[3];
 	float py[MAXM], w[MAXM], tw[MAXM];
 	float (*stage)[8][8]; // S == 8: [3][column][row] LDS of this wave, the hand-over between the patch and the scorer lane layouts
+	float (*bw)[kBigSlots]; // big-patch kernels: [4][slot] px | py | w | tw of this wave (LDS), see fill_patch_big
 	int seg;
 	// S == 8: the lane that computed tap (row, col) hands it to the scorer lanes of column col
 	__device__ __forceinline__ void put_patch64(int row, int col, float py_, float w_, float tw_) {
@@ -250,6 +251,7 @@ struct LdsStore {
 	static constexpr int MAXM = 64 / S;
 	static constexpr bool V4 = MAXM % 4 == 0; // 16-byte LDS accesses when a lane holds whole groups of four taps
 	WavePark<S>* pk;
+	float (*bw)[kBigSlots]; // big-patch kernels: [4][slot] px | py | w | tw of this wave (LDS), see fill_patch_big
 	int lane, view;
 	__device__ __forceinline__ void put_view(const HC_GLOBAL DevView* dv, int seg) {
 		if (seg == 0) {
@@ -447,9 +449,56 @@ __device__ __forceinline__ void fill_patch_64(const EstConst& c, const LaneCtx<8
 	P.px0 = (float)(x - a + 2 * (L.seg < a ? L.seg : a));
 	st.put_patch64(row, col, (float)(y + i), w, tw);
 }
+// Patches beyond the reference's 64 taps (a > 7; DepthMap.h:354-358 generalised, see pm_common.h): the (a + 1)^2 taps, in
+// the reference's order (rows outer, columns inner, DepthMap.cpp:486-494), are dealt round-robin to the S lanes of a view
+// group -- tap k = m * S + seg -- and every view group computes the same weights.  The per-tap tables (tap position,
+// weight, centred weighted texel) go to LDS, slot k; slots past the patch repeat its last tap with zero weights.
 template <int S, class ST>
+__device__ __forceinline__ void fill_patch_big(const EstConst& c, const LaneCtx<S>& L, int x, int y, int a, float center, Patch<S>& P, ST& st) {
+	constexpr int MB = (kBigTaps + S - 1) / S;
+	const int nside = a + 1, nt = nside * nside;
+	gcfptr ref = (gcfptr)c.ref;
+	const float sigmaColor = -1.f / (2.f * HC_SQ(0.2f));
+	const float sigmaSpatial = -1.f / (2.f * (float)HC_SQ(a));
+	float (*bw)[kBigSlots] = st.bw;
+	float sa = 0.f, sb = 0.f;
+	for (int m = 0; m < MB; ++m) {
+		const int k = m * S + L.seg;
+		const bool valid = k < nt;
+		const int kk = valid ? k : nt - 1;
+		const int row = kk / nside, col = kk - row * nside;
+		const int i = -a + 2 * row, j = -a + 2 * col;
+		const float I = ref[__mul24(y + i, c.W) + (x + j)];
+		const float wColor = HC_SQ(I - center) * sigmaColor;
+		const float wSpatial = (float)(HC_SQ(j) + HC_SQ(i)) * sigmaSpatial;
+		const float we = pm_expf(wColor + wSpatial);
+		const float w = valid ? we : 0.f;
+		sa = fmaf(I, w, sa);
+		sb = sb + w;
+		bw[0][k] = (float)(x + j); bw[1][k] = (float)(y + i); bw[2][k] = w; bw[3][k] = I; // I parked until the mean is known
+	}
+	const float swi = group_sum<S>(sa), sw = group_sum<S>(sb);
+	const float tm = swi / sw;
+	sa = 0.f;
+	for (int m = 0; m < MB; ++m) {
+		const int k = m * S + L.seg;
+		const float t = bw[3][k] - tm;
+		const float tw = bw[2][k] * t;
+		sa = fmaf(tw, t, sa);
+		bw[3][k] = tw;
+	}
+	P.sumW = sw;
+	P.invSumW = 1.0f / sw;
+	P.normSq0 = group_sum<S>(sa);
+	P.x = x; P.y = y; P.a = a;
+	P.px0 = 0.f;
+}
+template <int S, bool BIG, class ST>
 __device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& L, int x, int y, const PixIn<S>& in, Patch<S>& P, ST& st) {
 	const int a = patch_halfwin(c, in.tx);
+	if constexpr (BIG) {
+		if (a > kHalfWindow) { fill_patch_big<S>(c, L, x, y, a, in.center, P, st); return; }
+	}
 	if constexpr (S == 8) fill_patch_64(c, L, x, y, a, in, P, st);
 	else fill_patch_n<S, 64 / S>(c, L, x, y, a, in, P, st);
 }
@@ -609,6 +658,59 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 	sum = group_sum<S>(bad ? __builtin_nanf("") : a); sumSq = group_sum<S>(b2); num = group_sum<S>(cnum);
 }
 
+// score_taps for the patches of fill_patch_big: tap k = m * S + seg from the LDS tables, one IEEE reciprocal per tap, four
+// taps in flight at a time; same poisoning of the partial sum when a tap leaves the image
+template <int S, class ST>
+__device__ __forceinline__ void score_taps_big(const EstConst& c, const LaneCtx<S>& L, const ST& st, const float (&H)[9], float& sum, float& sumSq,
+                                               float& num, bool& viewBad) {
+	constexpr int MB = (kBigTaps + S - 1) / S, CH = 4;
+	const float (*bw)[kBigSlots] = st.bw;
+	const HC_GLOBAL char* imgBase = as_global(c.imgBase);
+	const unsigned pitch = (unsigned)L.iw << 2;
+	float a = 0.f, b2 = 0.f, cnum = 0.f;
+	bool bad = false;
+	for (int m0 = 0; m0 < MB; m0 += CH) {
+		float fx[CH], fy[CH];
+		unsigned off[CH];
+#pragma unroll
+		for (int u = 0; u < CH; ++u) {
+			const int m = m0 + u < MB ? m0 + u : MB - 1; // MB % CH != 0: the spare steps repeat the last one and are not accumulated
+			const int k = m * S + L.seg;
+			const float px = bw[0][k], py = bw[1][k];
+			const float Xx = fmaf(H[1], py, fmaf(H[0], px, H[2]));
+			const float Xy = fmaf(H[4], py, fmaf(H[3], px, H[5]));
+			const float Xz = fmaf(H[7], py, fmaf(H[6], px, H[8]));
+			const float iz = 1.0f / Xz;
+			const float qx = Xx * iz, qy = Xy * iz;
+			bad = bad || !(qx >= 1.f && qy >= 1.f && qx <= L.wmax && qy <= L.hmax); // Types.h:1633-1635; a NaN fails it
+			const int lx = (int)__builtin_amdgcn_fmed3f(qx, 0.f, L.wmax), ly = (int)__builtin_amdgcn_fmed3f(qy, 0.f, L.hmax);
+			fx[u] = __builtin_amdgcn_fractf(qx);
+			fy[u] = __builtin_amdgcn_fractf(qy);
+			off[u] = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 2);
+		}
+		f32x2 tv[CH], bv[CH];
+#pragma unroll
+		for (int u = 0; u < CH; ++u) {
+			tv[u] = *(const HC_GLOBAL f32x2*)(imgBase + off[u]);
+			bv[u] = *(const HC_GLOBAL f32x2*)(imgBase + (off[u] + pitch));
+		}
+#pragma unroll
+		for (int u = 0; u < CH; ++u) {
+			if (m0 + u >= MB) continue;
+			const int k = (m0 + u) * S + L.seg;
+			const float t = fmaf(fx[u], tv[u].y - tv[u].x, tv[u].x);
+			const float b = fmaf(fx[u], bv[u].y - bv[u].x, bv[u].x);
+			const float val = fmaf(fy[u], b - t, t);
+			const float vw = val * bw[2][k];
+			a = a + vw;
+			b2 = fmaf(val, vw, b2);
+			cnum = fmaf(val, bw[3][k], cnum);
+		}
+	}
+	viewBad = false;
+	sum = group_sum<S>(bad ? __builtin_nanf("") : a); sumSq = group_sum<S>(b2); num = group_sum<S>(cnum);
+}
+
 // DepthMap.cpp:597-615, 890-893: score of one view from its ZNCC sums, times the smoothness factor of the hypothesis
 __device__ __forceinline__ float view_score(const EstConst& c, float sum, float sumSq, float num, bool viewBad, float invSumW,
                                             float normSq0, float smoothF) {
@@ -627,7 +729,7 @@ __device__ __forceinline__ float two_best(const EstConst& c, float m1, float m2)
 }
 
 // one hypothesis, everything in one go (init-score pass)
-template <int S, class ST>
+template <int S, bool BIG, class ST>
 __device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const ST& st, float v0, float v1,
                                              float smoothF, float depth, float n0, float n1, float n2) {
 	float vA[9], vHm[3], H[9];
@@ -635,7 +737,9 @@ __device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>
 	make_homography(c, vA, vHm, v0, v1, depth, n0, n1, n2, H);
 	float sum, sumSq, num;
 	bool viewBad;
-	if constexpr (S == 8) {
+	if (BIG && P.a > kHalfWindow) {
+		score_taps_big<S>(c, L, st, H, sum, sumSq, num, viewBad);
+	} else if constexpr (S == 8) {
 		if (P.a == 6) score_taps<S, 7>(c, L, P, st, H, sum, sumSq, num, viewBad);
 		else if (P.a == 5) score_taps<S, 6>(c, L, P, st, H, sum, sumSq, num, viewBad);
 		else score_taps<S, 8>(c, L, P, st, H, sum, sumSq, num, viewBad);
@@ -655,7 +759,7 @@ __device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>
 //   (3) the per-view scores and the two-best-views means of the whole chunk, one (hypothesis, view) pair per lane
 // (1) and (3) cost one instruction stream per chunk instead of one per hypothesis.  Lane t of the result gets the score
 // of hypothesis t.
-template <int S>
+template <int S, bool BIG>
 __device__ __forceinline__ float score_chunk(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const LdsStore<S>& st, float v0, float v1,
                                              float F, float hd, float h0, float h1, float h2, unsigned long long todoIn, int baseIn,
                                              int fallbackIn, float mine, unsigned& issued) {
@@ -698,12 +802,15 @@ __device__ __forceinline__ float score_chunk(const EstConst& c, const LaneCtx<S>
 			}
 			float sum, sumSq, num;
 			bool viewBad;
-			score_taps<S, NR>(c, L, P, st, H, sum, sumSq, num, viewBad);
+			if constexpr (NR == 0) score_taps_big<S>(c, L, st, H, sum, sumSq, num, viewBad);
+			else score_taps<S, NR>(c, L, P, st, H, sum, sumSq, num, viewBad);
 			++issued;
 			if (L.seg == 0) pk->acc[g][L.view] = make_float4(sum, sumSq, num, viewBad ? 1.f : 0.f);
 		}
 	};
-	if constexpr (S == 8) {
+	if (BIG && P.a > kHalfWindow) {
+		taps_of(std::integral_constant<int, 0>()); // the big-patch scorer
+	} else if constexpr (S == 8) {
 		if (P.a == 6) taps_of(std::integral_constant<int, 7>());
 		else if (P.a == 5) taps_of(std::integral_constant<int, 6>());
 		else taps_of(std::integral_constant<int, 8>());
@@ -897,7 +1004,7 @@ __device__ __forceinline__ void slot_setup(const EstConst& c, int lane, int x, i
 		if (x > phw && y > phw && x < W - phw && y < H - phw) {
 			const int ni = phw >= 1 ? (phw - 1) / step + 1 : 0;
 			if (lane < 4 * ni) { i = 1 + (lane >> 2) * step; slot = true; }
-		} else if (x > kHalfWindow && y > kHalfWindow && x < W - kHalfWindow && y < H - kHalfWindow) {
+		} else if (x > c.border && y > c.border && x < W - c.border && y < H - c.border) {
 			if (lane < 4) { i = 1; slot = true; }
 		}
 		const int t = lane & 3;
@@ -910,7 +1017,7 @@ __device__ __forceinline__ void slot_setup(const EstConst& c, int lane, int x, i
 			const int d = rev ? ((lane + 2) & 3) : lane; // 0 left, 1 up, 2 right, 3 down
 			nx = x + (d == 0 ? -1 : (d == 2 ? 1 : 0));
 			ny = y + (d == 1 ? -1 : (d == 3 ? 1 : 0));
-			slot = d == 0 ? x > kHalfWindow : (d == 1 ? y > kHalfWindow : (d == 2 ? x < W - kHalfWindow : y < H - kHalfWindow));
+			slot = d == 0 ? x > c.border : (d == 1 ? y > c.border : (d == 2 ? x < W - c.border : y < H - c.border));
 			sprop = lane < 2;
 		}
 	}
@@ -962,7 +1069,7 @@ __device__ __forceinline__ float share_scores(RowShared<NW>& sh, int& par, int l
 // factors of a wave's share come from one smooth_pass, the share is scored hypothesis by hypothesis, the scores are
 // exchanged through LDS and every wave replays the reference's sequential accept logic (DepthMap.cpp:1425, 1455,
 // 1484).  Refinement trials depend on earlier accepts: after an accepted trial the later ones are regenerated.
-template <int S, int NW>
+template <int S, int NW, bool BIG>
 __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S>& L, RowShared<NW>& sh, int& par, int wv,
                                               int x, int y, int q, int iter, const PixIn<S>& in, const Patch<S>& P,
                                               const LdsStore<S>& st, RowPipe<S>& pp, unsigned& evals, unsigned& issued STAMP_ARGS) {
@@ -1110,7 +1217,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			const int top = base + 8 < hi ? base + 8 : hi;
 			const unsigned long long todo = vmask & ((1ull << top) - 1ull) & ~((1ull << base) - 1ull); // top <= 32
 			STAMP(4)
-			if (todo) mine = score_chunk<S>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, todo, base, __builtin_ctzll(todo), mine, issued);
+			if (todo) mine = score_chunk<S, BIG>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, todo, base, __builtin_ctzll(todo), mine, issued);
 		}
 		STAMP(7)
 		const float all = share_scores<NW>(sh, par, lane, lo, hi, mine);
@@ -1178,11 +1285,15 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 
 // One launch sweeps a BATCH of independent reference images: ticket t -> (row t / nItems of image t % nItems), so the
 // rows of every image are still handed out in dependence order while the images fill each other's wavefront ramps.
-template <int S, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 ? 3 : 1, S >= 8 ? 3 : 2))) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
+#ifndef HCMVS_OCC
+#define HCMVS_OCC 3 // waves per SIMD the register allocation of the 5..8-view sweep worker is held to (diagnostic builds vary it)
+#endif
+template <int S, int NW, bool BIG>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 && !BIG ? HCMVS_OCC : 1, S >= 8 && !BIG ? HCMVS_OCC : 2))) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
                                                         int iter, int lag, int affinity) {
 	__shared__ RowShared<NW> sh;
 	__shared__ WavePark<S> park[NW];
+	__shared__ float bigTab[BIG ? NW : 1][4][BIG ? kBigSlots : 1]; // big-patch kernels: per-tap tables of fill_patch_big
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, and the compiler should know it
 	const bool rev = (iter & 1) != 0; // dir = RB2LT on odd iterations, DepthMap.cpp:418
 	unsigned evals = 0, issued = 0;
@@ -1211,7 +1322,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 					cand = k - nHome;
 					cand += cand / (G - 1) + (cand % (G - 1) >= home ? 1 : 0); // skip the indices congruent to home
 				}
-				const int nrows_ = items[cand].H - 2 * kHalfWindow;
+				const int nrows_ = items[cand].H - 2 * items[cand].border;
 				HC_GLOBAL int32_t* tk = as_global(sy.ticket) + cand;
 				if (__hip_atomic_load(tk, __ATOMIC_RELAXED, HC_SCOPE) >= nrows_) continue;
 				const int r_ = atomicAdd(sy.ticket + cand, 1);
@@ -1225,15 +1336,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 		if (itemIdx < 0) break;
 		const int r = __builtin_amdgcn_readfirstlane(sh.row);
 		const EstConst& c = items[itemIdx];
-		const int nrows = c.H - 2 * kHalfWindow, ncols = c.W - 2 * kHalfWindow;
+		const int bd = c.border;
+		const int nrows = c.H - 2 * bd, ncols = c.W - 2 * bd;
 		(void)nrows;
 		LaneCtx<S> L;
 		lane_init<S>(c, L);
 		LdsStore<S> st;
 		st.pk = &park[wv]; st.lane = L.lane; st.view = L.view;
+		st.bw = (float (*)[kBigSlots])(BIG ? &bigTab[BIG ? wv : 0][0][0] : nullptr);
 		st.put_view(as_global(c.views) + (L.vact ? L.view : 0), L.seg);
 		pp.ncols = ncols;
-		const int y = rev ? c.H - 1 - kHalfWindow - r : kHalfWindow + r;
+		const int y = rev ? c.H - 1 - bd - r : bd + r;
 		pp.r = r; pp.y = y;
 		pp.upWord = as_global(c.progress) + (size_t)(r > 0 ? r - 1 : 0) * kProgressStride;
 		pp.myWord = as_global(c.progress) + (size_t)r * kProgressStride;
@@ -1244,7 +1357,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 			pp.known = wait_progress(pp.upWord, need, pp.err);
 			pp.fail = pp.known < 0;
 		}
-		const int x0 = rev ? c.W - 1 - kHalfWindow : kHalfWindow;
+		const int x0 = rev ? c.W - 1 - bd : bd;
 		const int dx = rev ? -1 : 1;
 		pp.tx1 = as_global(c.gra)[y * c.W + x0];
 		if constexpr (S == 8) { // the patch inputs travel one pixel ahead of the pixel being processed, the gradient byte two
@@ -1255,7 +1368,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 			pp.tx2 = ncols > 1 ? as_global(c.gra)[y * c.W + x0 + dx] : (uint8_t)0;
 		}
 		for (int q = 0; q < ncols && !pp.fail; ++q) {
-			const int x = rev ? c.W - 1 - kHalfWindow - q : kHalfWindow + q;
+			const int x = rev ? c.W - 1 - bd - q : bd + q;
 			// all loads of this pixel that do not depend on other rows go out in one batch ...
 			PixIn<S> in;
 			in.tx = (float)pp.tx1;
@@ -1276,7 +1389,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 			if (pp.known >= q + 1) prefetch_up<S>(c, in);
 			// ... and the patch weights are computed while they (and the previous row) arrive
 			Patch<S> P;
-			fill_patch<S>(c, L, x, y, in, P, st);
+			fill_patch<S, BIG>(c, L, x, y, in, P, st);
 			STAMP(1)
 			if (pp.known < q + 1) { // the previous row must have finished this column
 				pp.known = wait_progress(pp.upWord, q + 1, pp.err);
@@ -1285,7 +1398,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 			}
 			STAMP(0)
 			const unsigned e0 = evals;
-			process_pixel<S, NW>(c, L, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
+			process_pixel<S, NW, BIG>(c, L, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
 			taps += (unsigned long long)(evals - e0) * (unsigned)((P.a + 1) * (P.a + 1));
 		}
 		if (pp.fail) break;
@@ -1310,7 +1423,7 @@ __global__ void import_kernel(EstConst c, const float* depthIn, const float* nor
 	const int n = c.W * c.H;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const int x = i % c.W, y = i / c.W;
-		const bool inb = x >= kHalfWindow && y >= kHalfWindow && x < c.W - kHalfWindow && y < c.H - kHalfWindow;
+		const bool inb = x >= c.border && y >= c.border && x < c.W - c.border && y < c.H - c.border;
 		if (inb) {
 			c.dn[i] = make_float4(depthIn[i], normalIn[3 * i], normalIn[3 * i + 1], normalIn[3 * i + 2]);
 			c.conf[i] = 2.f;
@@ -1321,15 +1434,17 @@ __global__ void import_kernel(EstConst c, const float* depthIn, const float* nor
 	}
 }
 
-template <int S>
+template <int S, bool BIG>
 __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long long* evalsOut) {
 	LaneCtx<S> L;
 	lane_init<S>(c, L);
 	__shared__ float stage[4][3][8][8]; // one hand-over area per wave (launch_bounds 256)
+	__shared__ float bigTab[BIG ? 4 : 1][4][BIG ? kBigSlots : 1];
 	RegStore<S> st;
 	st.stage = stage[threadIdx.x >> 6]; st.seg = L.seg;
+	st.bw = (float (*)[kBigSlots])(BIG ? &bigTab[BIG ? (threadIdx.x >> 6) : 0][0][0] : nullptr);
 	st.put_view(as_global(c.views) + (L.vact ? L.view : 0), L.seg);
-	const int nrows = c.H - 2 * kHalfWindow, ncols = c.W - 2 * kHalfWindow;
+	const int nrows = c.H - 2 * c.border, ncols = c.W - 2 * c.border;
 	const int total = nrows * ncols;
 	const int wavesPerBlock = blockDim.x >> 6;
 	const int gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), nw = gridDim.x * wavesPerBlock;
@@ -1337,14 +1452,14 @@ __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long lo
 	unsigned long long taps = 0;
 	const uint32_t stream0 = (uint32_t)c.itExternal * 64u;
 	for (int p = gw; p < total; p += nw) {
-		const int x = kHalfWindow + p % ncols, y = kHalfWindow + p / ncols;
+		const int x = c.border + p % ncols, y = c.border + p / ncols;
 		const int idx = y * c.W + x;
 		const uint32_t rk = rand_key(c.seed, (uint32_t)idx, stream0);
 		PixIn<S> in;
 		in.tx = (float)c.gra[idx];
 		load_patch_inputs<S>(c, L, x, y, in);
 		Patch<S> P;
-		fill_patch<S>(c, L, x, y, in, P, st);
+		fill_patch<S, BIG>(c, L, x, y, in, P, st);
 		PixelGeom G;
 		pixel_geom(c, x, y, G);
 		const float4 cur = c.dn[idx];
@@ -1355,7 +1470,7 @@ __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long lo
 		} else if (dot3(n0, n1, n2, G.v0, G.v1, 1.f) >= 0.f) {
 			random_normal(G, rand_unit(rk, 1u), rand_unit(rk, 2u), n0, n1, n2);
 		}
-		const float s = score_pixel<S>(c, L, P, st, G.v0, G.v1, 1.f, d, n0, n1, n2);
+		const float s = score_pixel<S, BIG>(c, L, P, st, G.v0, G.v1, 1.f, d, n0, n1, n2);
 		++evals;
 		taps += (unsigned)((P.a + 1) * (P.a + 1));
 		if (L.lane == 0) {
@@ -1376,7 +1491,7 @@ template <int S>
 __global__ void probe_score_kernel(EstConst c, Patch<S> P, RegStore<S> st, float F, float d, float n0, float n1, float n2, float* out) {
 	LaneCtx<S> L;
 	lane_init<S>(c, L);
-	out[threadIdx.x] = score_pixel<S>(c, L, P, st, 0.1f, 0.2f, F, d, n0, n1, n2);
+	out[threadIdx.x] = score_pixel<S, false>(c, L, P, st, 0.1f, 0.2f, F, d, n0, n1, n2);
 }
 template __global__ void probe_score_kernel<8>(EstConst, Patch<8>, RegStore<8>, float, float, float, float, float, float*);
 __global__ void probe_smooth_kernel(EstConst c, Close C, float* out) {
@@ -1392,7 +1507,7 @@ __global__ void probe_patch_kernel(EstConst c, PixIn<S> in, Patch<S>* out, RegSt
 	__shared__ float stage[3][8][8];
 	RegStore<S> st;
 	st.stage = stage; st.seg = L.seg;
-	fill_patch<S>(c, L, 100, 100, in, P, st);
+	fill_patch<S, false>(c, L, 100, 100, in, P, st);
 	out[threadIdx.x] = P;
 	so[threadIdx.x] = st;
 }
@@ -1498,20 +1613,25 @@ void launch_median3(const float* in, float* out, int W, int H, hipStream_t s) {
 	hipLaunchKernelGGL(median3_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(64, 4), 0, s, in, out, W, H);
 }
 
+template <bool BIG>
+static void launch_score_big(const EstConst& c, unsigned long long* evals, hipStream_t s) {
+	const dim3 grid(4096), block(256);
+	switch (segments_for(c.V)) {
+	case 64: hipLaunchKernelGGL((score_kernel<64, BIG>), grid, block, 0, s, c, evals); break;
+	case 32: hipLaunchKernelGGL((score_kernel<32, BIG>), grid, block, 0, s, c, evals); break;
+	case 16: hipLaunchKernelGGL((score_kernel<16, BIG>), grid, block, 0, s, c, evals); break;
+	case 8: hipLaunchKernelGGL((score_kernel<8, BIG>), grid, block, 0, s, c, evals); break;
+	default: hipLaunchKernelGGL((score_kernel<4, BIG>), grid, block, 0, s, c, evals); break;
+	}
+}
 void launch_score_pass(const EstConst& c, const float* depthIn, const float* normalIn, unsigned long long* evals,
                        hipStream_t s) {
 	hipLaunchKernelGGL(import_kernel, dim3(2048), dim3(256), 0, s, c, depthIn, normalIn);
-	const dim3 grid(4096), block(256);
-	switch (segments_for(c.V)) {
-	case 64: hipLaunchKernelGGL(score_kernel<64>, grid, block, 0, s, c, evals); break;
-	case 32: hipLaunchKernelGGL(score_kernel<32>, grid, block, 0, s, c, evals); break;
-	case 16: hipLaunchKernelGGL(score_kernel<16>, grid, block, 0, s, c, evals); break;
-	case 8: hipLaunchKernelGGL(score_kernel<8>, grid, block, 0, s, c, evals); break;
-	default: hipLaunchKernelGGL(score_kernel<4>, grid, block, 0, s, c, evals); break;
-	}
+	if (c.adapthalfwin > kHalfWindow) launch_score_big<true>(c, evals, s);
+	else launch_score_big<false>(c, evals, s);
 }
 
-template <int NW>
+template <int NW, bool BIG>
 static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int lag,
                             int affinity, hipStream_t s) {
 	// one workgroup per row; rows beyond the resident set are picked up through the ticket
@@ -1519,20 +1639,25 @@ static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int
 	if (grid < 1) return;
 	const dim3 g(grid), b(64 * NW);
 	switch (segments_for(V)) {
-	case 64: hipLaunchKernelGGL((sweep_kernel<64, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
-	case 32: hipLaunchKernelGGL((sweep_kernel<32, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
-	case 16: hipLaunchKernelGGL((sweep_kernel<16, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
-	case 8: hipLaunchKernelGGL((sweep_kernel<8, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
-	default: hipLaunchKernelGGL((sweep_kernel<4, NW>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
+	case 64: hipLaunchKernelGGL((sweep_kernel<64, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
+	case 32: hipLaunchKernelGGL((sweep_kernel<32, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
+	case 16: hipLaunchKernelGGL((sweep_kernel<16, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
+	case 8: hipLaunchKernelGGL((sweep_kernel<8, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
+	default: hipLaunchKernelGGL((sweep_kernel<4, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
 	}
 }
-void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int lag,
+void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int lag,
                   int wavesPerRow, int affinity, hipStream_t s) {
+	if (bigPatch) { // patches beyond 64 taps: one or two waves per row
+		if (wavesPerRow >= 2) launch_sweep_nw<2, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s);
+		else launch_sweep_nw<1, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s);
+		return;
+	}
 	switch (wavesPerRow) {
-	case 1: launch_sweep_nw<1>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
-	case 3: launch_sweep_nw<3>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
-	case 4: launch_sweep_nw<4>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
-	default: launch_sweep_nw<2>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
+	case 1: launch_sweep_nw<1, false>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
+	case 3: launch_sweep_nw<3, false>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
+	case 4: launch_sweep_nw<4, false>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
+	default: launch_sweep_nw<2, false>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
 	}
 }
 

@@ -42,6 +42,8 @@ struct Options { // DensifyPointCloud.cpp:139-198 (defaults from there)
 	int minViewsTrustPoint = 2;   // < 2: splat the sparse points instead (SceneDensify.cpp:783-808)
 	int fuseOrder = 1;            // hcmvs_set_fuse_order: 1 hashed order (few dependent rounds; point count within 1 % of the
 	                              // reference's), 0 reference raster order (bit-exact cloud, ~10x slower on dense scenes)
+	int estimateColors = 2, estimateNormals = 2;   // 2: during fusion, 1: after it (DepthMap.cpp:2125-2269), 0: none
+	int maxResolution = 3200, minResolution = 640;  // DensifyPointCloud.cpp:144-145
 	int device = 0, batch = 8;
 	uint32_t seed = 1234;
 };
@@ -376,11 +378,34 @@ int main(int argc, char** argv) {
 	const double tStart = now_s();
 	Options o;
 	std::map<std::string, std::string> kv;
+	// every option of the reference's table (DensifyPointCloud.cpp:71-198) plus the ones of this driver; all take a value.
+	// Unknown options are an error (boost::program_options throws on them, DensifyPointCloud.cpp:222-233).
+	static const char* const kKnown[] = {
+		"-i", "--input-file", "-o", "--output-file", "-w", "--working-folder", "-c", "--config-file", "--dense-config-file", "--archive-type",
+		"--process-priority", "--max-threads", "-v", "--verbosity", "--resolution-level", "--max-resolution", "--min-resolution",
+		"--number-views", "--number-views-fuse", "--ignore-mask-label", "--use-semantic", "--estimate-colors", "--estimate-normals",
+		"--sample-mesh", "--filter-point-cloud", "--fusion-mode", "--depthweight", "--normalweight", "--semantic-multiplier",
+		"--sigma-texture", "--sigma-prior", "--ransac-epsilon", "--n-nOptimize", "--ransac-cluster", "--ransac-min-points",
+		"--project-labels", "--ransac-probability", "--n-EstimationIters", "--n-EstimationIters-external", "--n-photo2geo",
+		"--n-txthreshold", "--n-maxgeo_proportion", "--n-para_part", "--n-para_part2", "--n-txthreshold2", "--n-para_tapa",
+		"--n-para_tapa2", "--n-para_prior", "--n-para_prior2", "--n-photometric_flow", "--n-usepartconsistency",
+		"--n-usegeoconsistency", "--n-initTriangulate", "--n-viewspread", "--n-opticalflow", "--n-adapthalfwin",
+		"--n-propagatehalfwin", "--n-propagatestep",
+		// this driver's own
+		"--min-views-trust-point", "--fuse-order", "--device", "--batch", "--seed", "--restore-hypothesis", "--n-postfilter"};
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i], val;
+		if (a == "-h" || a == "--help") { kv["--help"] = "1"; continue; }
 		const size_t eq = a.find('=');
-		if (eq != std::string::npos) { val = a.substr(eq + 1); a = a.substr(0, eq); }
-		else if (i + 1 < argc && argv[i + 1][0] != '-') val = argv[++i];
+		bool haveVal = false;
+		if (eq != std::string::npos) { val = a.substr(eq + 1); a = a.substr(0, eq); haveVal = true; }
+		bool known = false;
+		for (const char* k : kKnown) known = known || a == k;
+		if (!known) { fprintf(stderr, "error: unrecognised option '%s'\n", a.c_str()); return EXIT_FAILURE; }
+		if (!haveVal) { // the value is the next argument, whatever it starts with (negative numbers are values)
+			if (i + 1 >= argc) { fprintf(stderr, "error: the required argument for option '%s' is missing\n", a.c_str()); return EXIT_FAILURE; }
+			val = argv[++i];
+		}
 		kv[a] = val;
 	}
 	auto geti = [&](const char* k, int& v) { if (kv.count(k)) v = atoi(kv[k].c_str()); };
@@ -398,10 +423,17 @@ int main(int argc, char** argv) {
 	geti("--fuse-order", o.fuseOrder);
 	geti("--device", o.device); geti("--batch", o.batch);
 	if (kv.count("--seed")) o.seed = (uint32_t)strtoul(kv["--seed"].c_str(), nullptr, 10);
+	geti("--estimate-colors", o.estimateColors); geti("--estimate-normals", o.estimateNormals);
+	geti("--max-resolution", o.maxResolution); geti("--min-resolution", o.minResolution);
 	for (const char* k : {"--n-opticalflow", "--n-viewspread", "--use-semantic", "--n-nOptimize", "--n-usegeoconsistency", "--n-usepartconsistency"})
 		if (kv.count(k) && atoi(kv[k].c_str()) != 0 && o.verbosity > 1)
 			fprintf(stderr, "note: %s is not available in this build (defined subset); treated as 0\n", k);
-	if (o.input.empty()) {
+	if (kv.count("--filter-point-cloud") && atoi(kv["--filter-point-cloud"].c_str()) < 0) {
+		fprintf(stderr, "error: --filter-point-cloud < 0 (visibility filter of an existing cloud, DensifyPointCloud.cpp:406-414) is not available\n");
+		return EXIT_FAILURE;
+	}
+	if (kv.count("--sample-mesh") && atof(kv["--sample-mesh"].c_str()) != 0) { fprintf(stderr, "error: --sample-mesh is not available\n"); return EXIT_FAILURE; }
+	if (o.input.empty() || kv.count("--help")) {
 		fprintf(stderr, "usage: DensifyPointCloud -i scene.mvs [-o out.mvs] [-w dir] [--resolution-level n] [--number-views n] "
 		                "[--n-EstimationIters n] [--n-EstimationIters-external n] [--n-adapthalfwin n] [--fusion-mode 0|1] ...\n");
 		return EXIT_FAILURE;
@@ -461,7 +493,15 @@ int main(int argc, char** argv) {
 			continue;
 		}
 		todo.push_back(im.id);
-		if (o.verbosity > 2) { printf("Reference image %3u paired with %zu views:", im.id, im.srcs.size()); for (uint32_t s : im.srcs) printf(" %u", s); printf("\n"); }
+		if (o.verbosity > 2) { // SceneDensify.cpp:376-384
+			printf("Reference image %3u paired with %zu views:", im.id, im.srcs.size());
+			for (uint32_t s : im.srcs) {
+				float scl = 1.f;
+				for (const auto& nb : im.neighbors) if (nb.id == s) scl = nb.scale;
+				printf(" %3u(%.2fscl)", s, scl);
+			}
+			printf(" (%zu shared points)\n", im.points.size());
+		}
 	}
 	hcmvs_params prm;
 	hcmvs_default_params(&prm);
@@ -578,7 +618,7 @@ int main(int argc, char** argv) {
 		for (const auto& x : im.neighbors) if (std::find(todo.begin(), todo.end(), x.id) != todo.end()) nb.push_back(x.id);
 		if (nb.size() > 31) nb.resize(31);
 		CHK(hcmvs_set_neighbors(ctx, id, nb.data(), (int32_t)nb.size()));
-		capacity += (uint64_t)(n / 2);
+		capacity += (uint64_t)(o.numberViewsFuse >= 2 ? n / 2 : n); // a fused point claims at least number-views-fuse pixels
 	}
 	const double tSaved = now_s();
 	if (o.verbosity > 1) printf("Depth-maps saved in %.2f s\n", tSaved - tEstimated);

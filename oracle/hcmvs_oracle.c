@@ -335,15 +335,25 @@ typedef struct {
 	float planeN[3], planeD;
 } pix_state;
 
-static inline int border_ok(const hcor_view* ref, int x, int y) { /* DM.cpp:442-447 */
-	return x - HCOR_HALF_WINDOW >= 0 && y - HCOR_HALF_WINDOW >= 0 && x + HCOR_HALF_WINDOW < ref->width &&
-	       y + HCOR_HALF_WINDOW < ref->height;
+/* nSizeHalfWindow generalised (hcmvs_oracle.h): 7 for every patch the reference supports, adapthalfwin beyond that */
+static inline int border_of(const hcor_params* p) { return p->adapthalfwin > HCOR_HALF_WINDOW ? p->adapthalfwin : HCOR_HALF_WINDOW; }
+static inline int border_ok(const est_ctx* c, int x, int y) { /* DM.cpp:442-447 */
+	const int b = border_of(&c->p);
+	return x - b >= 0 && y - b >= 0 && x + b < c->ref->width && y + b < c->ref->height;
 }
 
 /* device association: tap handled by segment seg at step m (same mapping as the kernels' tap_offset) */
 static int dev_tap(int S, int a, int seg, int m, int* ti, int* tj) {
 	const int nside = a + 1;
 	int row, col;
+	if (a > HCOR_HALF_WINDOW) {
+		/* patches beyond the reference's 64 taps: the taps in the reference's order (rows outer, columns inner,
+		 * DM.cpp:486-494) are dealt round-robin to the S lanes of a view group, tap k = m * S + seg */
+		const int k = m * S + seg, nt = nside * nside;
+		const int kk = k < nt ? k : nt - 1;
+		*ti = kk / nside; *tj = kk % nside;
+		return k < nt;
+	}
 	if (S >= 8) {
 		const int RH = 64 / S;
 		col = seg & 7;
@@ -403,9 +413,9 @@ static void fill_patch(const est_ctx* c, pix_state* ps, int x, int y) {
 		}
 		ps->sumW = sw; ps->normSq0 = nrm;
 	} else {
-		const int S = c->S, MAXM = 64 / S, nside = ps->nside;
+		const int S = c->S, big = a > HCOR_HALF_WINDOW, MAXM = big ? (HCOR_MAX_TAPS + S - 1) / S : 64 / S, nside = ps->nside;
 		float pa[64], pb[64];
-		if (S == 8) {
+		if (S == 8 && !big) {
 			/* 5..8 source views: the kernels give every tap of the patch its own lane (lane = 8 * row + column, lanes past
 			 * the patch add exactly +0) and sum the 64 lanes with the xor butterfly */
 			for (int l = 0; l < 64; ++l) {
@@ -571,14 +581,14 @@ static float score_view_dev(const est_ctx* c, const pix_state* ps, int v, float 
 	const hcor_view* im = &c->srcs[v];
 	float H[9];
 	device_H(c, ps, v, depth, normal, H);
-	const int a = ps->a, nside = ps->nside, S = c->S;
-	const int MAXM = 64 / S; /* taps per lane; lanes past the patch repeat the last tap with zero weight */
+	const int a = ps->a, nside = ps->nside, S = c->S, big = a > HCOR_HALF_WINDOW;
+	const int MAXM = big ? (HCOR_MAX_TAPS + S - 1) / S : 64 / S; /* taps per lane; lanes past the patch repeat the last tap with zero weight */
 	float p0[64], p1[64], p2[64];
 	int ok = 1;
 	for (int s = 0; s < S; ++s) {
-		float Xx[64], Xy[64], Xz[64], iz[64];
-		int kk[64];
-		int vv[64];
+		float Xx[HCOR_MAX_TAPS], Xy[HCOR_MAX_TAPS], Xz[HCOR_MAX_TAPS], iz[HCOR_MAX_TAPS];
+		int kk[HCOR_MAX_TAPS];
+		int vv[HCOR_MAX_TAPS];
 		for (int m = 0; m < MAXM; ++m) {
 			int ti, tj;
 			vv[m] = dev_tap(S, a, s, m, &ti, &tj);
@@ -588,7 +598,9 @@ static float score_view_dev(const est_ctx* c, const pix_state* ps, int v, float 
 			Xy[m] = fmaf(H[4], py, fmaf(H[3], px, H[5]));
 			Xz[m] = fmaf(H[7], py, fmaf(H[6], px, H[8])); /* steps past the patch repeat the clamped tap */
 		}
-		if (S == 8) { /* 5..8 views: one IEEE reciprocal for the eight steps of a lane (steps past the patch repeat the last row) */
+		if (big) { /* beyond 64 taps: one IEEE reciprocal per tap */
+			for (int m = 0; m < MAXM; ++m) iz[m] = 1.0f / Xz[m];
+		} else if (S == 8) { /* 5..8 views: one IEEE reciprocal for the eight steps of a lane (steps past the patch repeat the last row) */
 			const float q01 = Xz[0] * Xz[1], q23 = Xz[2] * Xz[3], q45 = Xz[4] * Xz[5], q67 = Xz[6] * Xz[7];
 			const float qa = q01 * q23, qb = q45 * q67;
 			const float r = 1.0f / (qa * qb);
@@ -791,7 +803,7 @@ float hcor_interpolate_pixel(const hcor_view* ref, int x, int y, int nx, int ny,
 static void score_one(est_ctx* c, int x, int y, float* depth, float* normal, float* conf) {
 	const int W = c->ref->width;
 	const int idx = y * W + x;
-	if (!border_ok(c->ref, x, y)) {
+	if (!border_ok(c, x, y)) {
 		depth[idx] = 0; normal[3 * idx] = normal[3 * idx + 1] = normal[3 * idx + 2] = 0; conf[idx] = 2.f;
 		return;
 	}
@@ -834,8 +846,8 @@ static void add_close(const est_ctx* c, pix_state* ps, int nx, int ny, float nd,
 /* DM.cpp:1050-1501 ProcessPixel (DENSE_REFINE_ITER, DENSE_SMOOTHNESS_PLANE) */
 static void process_pixel(est_ctx* c, int x, int y, int iter, float* depthMap, float* normalMap, float* confMap) {
 	const hcor_view* ref = c->ref;
-	const int W = ref->width, H = ref->height, hw7 = HCOR_HALF_WINDOW;
-	if (!border_ok(ref, x, y)) return;
+	const int W = ref->width, H = ref->height, hw7 = border_of(&c->p);
+	if (!border_ok(c, x, y)) return;
 	pix_state ps;
 	fill_patch(c, &ps, x, y);
 	const int rev = (iter % 2) != 0; /* dir = RB2LT for odd iterations, DM.cpp:418 */
@@ -1040,7 +1052,7 @@ void hcor_pass_end(const hcor_params* p, int W, int H, float* depth, float* norm
 int hcor_estimate(const hcor_view* ref, const hcor_view* srcs, int V, const uint8_t* gra, const hcor_params* p,
                   float dMin, float dMax, float* depth, float* normal, float* conf, uint64_t* evals) {
 	if (V < 1 || V > HCOR_MAX_VIEWS) return 1;
-	if (p->adapthalfwin < 1 || p->adapthalfwin > HCOR_HALF_WINDOW) return 1;
+	if (p->adapthalfwin < 1 || p->adapthalfwin > HCOR_MAX_HALF_WINDOW) return 1;
 	const int W = ref->width, H = ref->height;
 	if (evals) *evals = 0;
 	if (p->median_blur) {

@@ -26,8 +26,13 @@ extern "C" {
 #endif
 
 #define HCOR_MAX_VIEWS 16
-#define HCOR_MAX_TAPS 64     /* nTexels, DM.h:358 */
-#define HCOR_HALF_WINDOW 7   /* nSizeHalfWindow, DM.h:354 */
+/* The reference fixes nSizeHalfWindow = 7 and nTexels = 64 at compile time (DM.h:354-358), i.e. --n-adapthalfwin <= 7.
+ * BASELINE.json configs[4] asks for an 11x11 patch (adapthalfwin 10, 121 taps): SURVEY.md 8d item 5 has the restatement
+ * generalise the two constants.  The patch loops (DM.cpp:486-494, 554-577) are already written for any `a`; what follows the
+ * constant is the border every pass keeps clear (DM.cpp:442-447 uses nSizeHalfWindow): max(7, adapthalfwin). */
+#define HCOR_MAX_HALF_WINDOW 10
+#define HCOR_MAX_TAPS 121    /* (HCOR_MAX_HALF_WINDOW + 1)^2; the reference's nTexels is 64, DM.h:358 */
+#define HCOR_HALF_WINDOW 7   /* nSizeHalfWindow, DM.h:354: the border for adapthalfwin <= 7 */
 #define HCOR_MAX_NEIGHBORS 32
 
 enum { HCOR_ARITH_REFERENCE = 0, HCOR_ARITH_DEVICE = 1 };
@@ -43,7 +48,7 @@ typedef struct {
 
 /* replaces the OPTDENSE globals (DM.cpp:67-143) for this path */
 typedef struct {
-	int adapthalfwin;           /* --n-adapthalfwin, <= 7 (DM.cpp:455-461) */
+	int adapthalfwin;           /* --n-adapthalfwin (DM.cpp:455-461); reference <= 7, generalised to <= HCOR_MAX_HALF_WINDOW */
 	int n_estimation_iters;     /* --n-EstimationIters: inner sweeps (SD.cpp:949) */
 	int it_external;            /* outer iteration this call is (SD.cpp:758) */
 	int n_external_iters;       /* --n-EstimationIters-external: pass C runs when it_external == n-1 */

@@ -70,6 +70,35 @@ def test_estimate_bit_exact(ctx, n_src, ahw):
     assert (got[0] > 0).mean() > 0.3
 
 
+@pytest.mark.parametrize("n_src,ahw", [(8, 10), (3, 9), (1, 8), (2, 10), (10, 10), (6, 8)])
+def test_estimate_bit_exact_beyond_64_taps(ctx, n_src, ahw):
+    """patches beyond the reference's nTexels = 64 (DepthMap.h:354-358 generalised; BASELINE.json configs[4] uses 11 x 11):
+    half windows 8..10, every lane layout, border = half window; pixels with a strong gradient still use the 6 x 6 patch"""
+    views, pts = _scene(120, 96, 100.0, n_src, seed=80 + n_src + ahw)
+    _upload(ctx, views)
+    d0, n0, dmin, dmax = ctx.splat_init(0, pts)
+    pg, po = _params(adapthalfwin=ahw, n_estimation_iters=2, seed=7 + ahw)
+    got = ctx.estimate(0, list(range(1, n_src + 1)), pg, dmin, dmax, d0, n0)
+    st = ctx.stats()
+    do, no, co, ev = O.estimate(views, po, dmin, dmax, d0, n0)
+    assert st.evals == ev
+    _compare(got, (do, no, co))
+    assert (got[0][:ahw] == 0).all() and (got[0][:, :ahw] == 0).all() and (got[0][ahw:-ahw, ahw:-ahw] > 0).mean() > 0.3
+    gra = ctx.gradient_map(0)[ahw:-ahw, ahw:-ahw]
+    assert 0.02 < (gra > 100).mean() < 0.98     # both patch sizes occur
+
+
+def test_big_patch_cross_pattern_in_a_batch(ctx):
+    """11 x 11 patch + outer-iteration cross pattern + batch of two images with two waves per row"""
+    torch = pytest.importorskip("torch")
+    scenes = [_scene(104, 88, 95.0, 5, seed=91), _scene(88, 104, 95.0, 5, seed=92)]
+    pg, po = _params(adapthalfwin=10, n_estimation_iters=2, seed=17, it_external=1, n_external_iters=3, propagate_halfwin=5, propagate_step=2)
+    got, keep = _batch_run(ctx, torch, scenes, pg, [0, 3])
+    for si, ((views, pts), g, k) in enumerate(zip(scenes, got, keep)):
+        po.seed = 17 + [0, 3][si]
+        _compare(g, O.estimate(views, po, k[5], k[6], k[3], k[4])[:3])
+
+
 def test_outer_iterations_cross_pattern(ctx):
     """it_external >= 1 uses the cross propagation pattern (DepthMap.cpp:1064-1274) and no end pass until
     the last outer iteration; maps are handed from one call to the next."""
@@ -111,7 +140,7 @@ def test_errors_are_reported(ctx):
     with pytest.raises(binding.HcmvsError) as e:
         ctx.estimate(0, [99], pg, dmin, dmax, d0, n0)
     assert e.value.code == binding.ERR_INVALID and "99" in str(e.value)
-    pg.adapthalfwin = 9
+    pg.adapthalfwin = 11                      # the generalised patch goes up to 11 x 11 taps (half window 10)
     with pytest.raises(binding.HcmvsError):
         ctx.estimate(0, [1], pg, dmin, dmax, d0, n0)
 
@@ -201,7 +230,7 @@ def test_ragged_and_minimum_sizes(ctx):
 
 
 def test_full_size_schedule_invariance():
-    """BASELINE.json configs[1] at full size (1920x1080, 8 source views, 7x7): the oracle cannot run this in seconds, so
+    """BASELINE.json configs[1] at full size (1920x1080, 8 source views, 7x7, 8 sweeps): the oracle cannot run this in seconds, so
     parity is shown through properties that do not depend on the size -- the maps must not depend on how the rows are
     scheduled (one image alone with two waves per row == the same image inside a batch with one wave per row and XCD
     affinity), the evaluation count per pixel-sweep is the algorithm's (2 propagations + 6 refinements, fewer where a
@@ -212,27 +241,28 @@ def test_full_size_schedule_invariance():
         W, H = 1920, 1080
         scenes = [_scene(W, H, 1600.0, 8, seed=61, n_pts=2000), _scene(W, H, 1600.0, 8, seed=62, n_pts=2000),
                   _scene(W, H, 1600.0, 8, seed=63, n_pts=2000)]
-        pg = binding.default_params(adapthalfwin=6, n_estimation_iters=3, seed=4321)
+        SWEEPS = 8                      # the configuration BASELINE.json's metric is quoted on
+        pg = binding.default_params(adapthalfwin=6, n_estimation_iters=SWEEPS, seed=4321)
         got3, keep = _batch_run(c, torch, scenes, pg, [0, 1, 2])
         evals3 = c.stats().evals
         # item 1 alone (two waves per row, no interleaving)
         views, pts = scenes[1]
         k = keep[1]
-        pg1 = binding.default_params(adapthalfwin=6, n_estimation_iters=3, seed=4321 + 1)
+        pg1 = binding.default_params(adapthalfwin=6, n_estimation_iters=SWEEPS, seed=4321 + 1)
         ids = list(range(1000 + 9, 1000 + 18))
         alone = c.estimate(ids[0], ids[1:], pg1, k[5], k[6], k[3], k[4])
         evals1 = c.stats().evals
         for g, a, n in zip(got3[1], alone, ("depth", "normal", "conf")):
             assert np.array_equal(g, a), n
         P = (W - 14) * (H - 14)
-        per_px_sweep = (evals1 / P - 1) / 3
+        per_px_sweep = (evals1 / P - 1) / SWEEPS
         assert 6.5 < per_px_sweep <= 8.0
         assert abs(evals3 / 3 - evals1) / evals1 < 0.05
         d = alone[0]
         valid = d > 0
         gt = views[0]["depth"]
-        assert valid.mean() > 0.85
-        assert (np.abs(d - gt)[valid] / gt[valid] < 0.01).mean() > 0.9
+        assert valid.mean() > 0.9
+        assert (np.abs(d - gt)[valid] / gt[valid] < 0.01).mean() > 0.95
     finally:
         c.close()
 

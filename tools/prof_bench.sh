@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tests/prof_bench.sh <tag> : rocprofv3 kernel-trace stats + HBM PMC passes of `python3 bench.py`
+# usage: tools/prof_bench.sh <tag> : rocprofv3 kernel-trace stats + HBM PMC passes of `python3 bench.py`
 TAG=$1
 export TMPDIR=/tmp
 R=$PWD

@@ -1,6 +1,6 @@
 """ad-hoc: FilterDepthMap throughput (reference SceneDensify.cpp:3006-3259) on a ring of 1080p views"""
 import importlib, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fusion_scene import make_maps

@@ -1,7 +1,7 @@
 """ad-hoc: FuseDepthMaps throughput on a ring of N 1080p views (ground-truth maps + noise/outliers/holes), GPU vs the
 CPU oracle on a reduced sample"""
 import importlib, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fusion_scene import make_maps
