@@ -39,19 +39,18 @@ struct FuseTables {
 	uint32_t* bidders;   // the lists: raster indices of A's pending pixels, per target
 	uint32_t* cntP;      // [2][stride]: per pixel of A, how many pixels share a target with it -- lower / higher raster index
 	uint32_t* offP;      // exclusive scan of cntP: start of the pixel's lower / higher list in `nbrList`
-	uint32_t* nbrList;   // those pixels (a pixel may appear more than once)
-	uint32_t* doneRound; // [w*h]: round in which the pixel was decided, FS_NOT_DONE before
-	uint32_t* queued;    // [w*h]: last round the pixel was put on a candidate list for
+	uint32_t* nbrList;   // those pixels (a pixel may appear more than once); the lower half of cntP is the countdown of the pass
 	size_t stride;       // pixels reserved per neighbour map in cntT / offT / fillT
 };
 
 FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_t* fillT, uint32_t* bidders, uint32_t* cntP, uint32_t* offP,
-                       uint32_t* nbrList, uint32_t* doneRound, uint32_t* queued, size_t stride);
+                       uint32_t* nbrList, size_t stride);
+// ctl: 8 words, zero before the pass: [0] queue tail, [1] queue head, [2] pixels decided, [3] error flag, [4] pending pixels
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
-                       uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters, int order, hipStream_t s);
-void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* roundCnt, int order, hipStream_t s);
-void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, uint32_t* list0, uint32_t* list1, uint32_t* roundCnt,
-                      uint32_t* barrier, uint32_t roundCap, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
+                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, hipStream_t s);
+void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, hipStream_t s);
+void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl,
+                      float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
                       int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, int blocks, hipStream_t s);
 size_t fuse_scan_temp_bytes(int n);
 void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,

@@ -14,12 +14,14 @@
  *     parallel.  HBM-bound integer/float work, one thread per pixel, coalesced over the reference map.
  *   - Fuse: a pixel of image A interacts with other pixels of A only through the neighbour pixels it
  *     projects onto (its targets).  The pixels that project onto one neighbour pixel are listed per target
- *     (CSR, built once per image pass); a pixel is ready when every lower raster index on all its targets
- *     has been decided in an earlier round.  One persistent kernel per image pass runs the rounds, separated
- *     by a grid barrier: the round's candidates that are ready run the reference's body and wake the higher
- *     indices on their targets for the next round.  Pixels sharing a target are therefore decided in raster
- *     order, the work is proportional to the pixels (not pixels x rounds) and the cloud is identical to the
- *     sequential one, point order included (ordered compaction).
+ *     (CSR, built once per image pass); a pixel may run once every lower raster index on all its targets has
+ *     been decided.  The image pass is a DATAFLOW over that dependence graph: every pixel carries a countdown
+ *     of its undecided blockers; a worker that decides a pixel runs the reference's body, drains its stores,
+ *     decrements the countdowns of the higher indices on its targets and hands the ones that reach zero on --
+ *     the first to itself, the others through an append-only queue the idle lanes poll.  No grid barrier and
+ *     no co-residency assumption: one dependent hop costs a body plus one atomic instead of a whole round.
+ *     Pixels sharing a target are decided in raster order, so the cloud is identical to the sequential one,
+ *     point order included (ordered compaction).
  *
  * Double precision follows the reference (Point3 = double); no contraction (-ffp-contract=off).
  */
@@ -223,8 +225,6 @@ __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, u
 				pend = A.claim[idx] == NO_ID;
 			}
 			flag[idx] = 0;
-			tb.doneRound[idx] = FS_NOT_DONE;
-			tb.queued[idx] = pend ? 1u : 0u;
 		}
 		if (pend) {
 			float point[3];
@@ -285,33 +285,12 @@ struct FuseOut { // per pixel of the current image, compacted in raster order af
 	float* xyz; float* normal; uint8_t* bgr; uint32_t* nviews; uint8_t* flag;
 };
 struct FusePass {
-	uint32_t* list[2];       // candidate pixels of a round, alternating by round parity
 	FuseTables tb;
-	uint32_t* roundCnt;      // [roundCap + 1] candidates of round r (rounds count from 1)
-	uint32_t* barrier;       // [0] arrivals, [1] error flag, [2] rounds used
-	uint32_t roundCap;
-	uint32_t tailCount;      // once a round has this few candidates, workgroup 0 finishes the pass alone (block barriers)
+	uint32_t* queue;         // [pending] append-only ready queue, FS_EMPTY until written
+	uint32_t* ctl;           // [0] queue tail, [1] queue head, [2] pixels decided, [3] error flag, [4] pending (set by fuse_begin)
 	int nMinViewsFuse; float thDepth, normalError;
 };
-
-// all workgroups of the launch are resident: arrive, then wait for everybody
-__device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t& target) {
-	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // my wave's stores are out
-	__syncthreads();
-	__shared__ int failed;
-	if (threadIdx.x == 0) {
-		failed = 0;
-		__hip_atomic_fetch_add((g_u32p)bar, 1u, __ATOMIC_RELAXED, FS_SCOPE);
-		unsigned spins = 0;
-		while (ld_u32(bar) < target) {
-			__builtin_amdgcn_s_sleep(1);
-			if ((++spins & 1023u) == 0u && (ld_u32(bar + 1) != 0u || spins > (1u << 23))) { st_u32(bar + 1, 1u); failed = 1; break; }
-		}
-	}
-	__syncthreads();
-	target += gridDim.x;
-	return failed == 0;
-}
+#define FS_EMPTY 0xFFFFFFFFu
 
 // The neighbour maps' descriptors are staged in LDS once per launch; the loop of the reference's body over the
 // neighbours is chunked: first the projections of a chunk, then all its loads back to back, then the (sequential) logic.
@@ -320,7 +299,8 @@ constexpr int kFuseChunk = 8;
 // MAXV: capacity of the per-pixel view lists (the image itself + its neighbours); 16 covers the reference's cap of 12
 // neighbours (nMaxViews, DepthMap.cpp:73) with fewer registers than the general 32
 template <int MAXV>
-__global__ __launch_bounds__(256) void fuse_pass_kernel(DevMap A, const DevMap* maps, FusePass fp, FuseOut out, unsigned long long* counters) {
+__global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* maps, FusePass fp, FuseOut out, const uint32_t* pending,
+                                                        unsigned long long* counters) {
 	__shared__ DevMap nbs[MAXV - 1];
 	const int nNb = A.nNeighbors;
 	{
@@ -334,38 +314,37 @@ __global__ __launch_bounds__(256) void fuse_pass_kernel(DevMap A, const DevMap* 
 		__syncthreads();
 	}
 	const FuseTables& tb = fp.tb;
-	const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gthreads = gridDim.x * blockDim.x;
-	uint32_t target = gridDim.x;
-	unsigned accepted = 0;
-	uint32_t r = 1;
-	bool tail = false; // workgroup 0 alone, block barriers
-	for (;; ++r) {
-		const int n = (int)ld_u32(fp.roundCnt + r);
-		if (n == 0 || r + 1 >= fp.roundCap) break;
-		if (!tail && (uint32_t)n <= fp.tailCount) {
-			if (blockIdx.x != 0) break; // every workgroup reads the same count: all but one leave together
-			tail = true;
-		}
-		const int tid = tail ? (int)threadIdx.x : gtid, nthreads = tail ? (int)blockDim.x : gthreads;
-		const uint32_t* listIn = fp.list[r & 1u];
-		uint32_t* listOut = fp.list[(r + 1u) & 1u];
-		for (int i = tid; i < n; i += nthreads) {
-			const int idx = (int)ld_u32(&listIn[i]);
-			// ready: every lower raster index that shares a target with me was decided in an earlier round
-			bool ready = true;
-			{
-				const uint32_t o = tb.offP[idx], len = tb.cntP[idx];
-				for (uint32_t k0 = 0; k0 < len && ready; k0 += 8) {
-					uint32_t b[8], d[8];
-#pragma unroll
-					for (int j = 0; j < 8; ++j) b[j] = k0 + j < len ? tb.nbrList[o + k0 + j] : 0xFFFFFFFFu;
-#pragma unroll
-					for (int j = 0; j < 8; ++j) d[j] = b[j] != 0xFFFFFFFFu ? ld_u32(&tb.doneRound[b[j]]) : 0u;
-#pragma unroll
-					for (int j = 0; j < 8; ++j) ready = ready && d[j] < r;
-				}
+	const uint32_t nPending = fp.ctl[4];
+	uint32_t* const qTail = fp.ctl, *const qHead = fp.ctl + 1, *const nDone = fp.ctl + 2, *const errFlag = fp.ctl + 3;
+	// seed: the pending pixels nobody blocks
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nPending; i += gridDim.x * blockDim.x) {
+		const uint32_t idx = pending[i];
+		if (tb.cntP[idx] == 0u) st_u32(&fp.queue[atomicAdd(qTail, 1u)], idx);
+	}
+	unsigned accepted = 0, decided = 0;
+	uint32_t item = FS_EMPTY, slot = FS_EMPTY; // the pixel I run next; the queue slot I wait on
+	bool finished = false;
+	unsigned spins = 0;
+	for (;;) {
+		if (!finished && item == FS_EMPTY) {
+			if (slot == FS_EMPTY) slot = atomicAdd(qHead, 1u);
+			if (slot < nPending) {
+				const uint32_t v = ld_u32(&fp.queue[slot]);
+				if (v != FS_EMPTY) { item = v; slot = FS_EMPTY; spins = 0; }
 			}
-			if (!ready) continue; // whoever blocks me puts me on the list again when it is decided
+			if (item == FS_EMPTY) {
+				// nothing for me yet: pixels handed on directly never pass through the queue, so the end of the pass is
+				// "every pending pixel decided", not "my slot is past the end"
+				if (decided) { atomicAdd(nDone, decided); decided = 0; }
+				if (ld_u32(nDone) >= nPending || ld_u32(errFlag) != 0u) finished = true;
+				else if (++spins > (1u << 22)) { st_u32(errFlag, 1u); finished = true; } // bounded: never hang the device
+			}
+		}
+		if (__ballot(!finished) == 0ull) break;
+		if (__ballot(item != FS_EMPTY) == 0ull) { __builtin_amdgcn_s_sleep(8); continue; }
+		if (item != FS_EMPTY) {
+			const int idx = (int)item;
+			item = FS_EMPTY;
 			const float depth = A.depth[idx];
 			float point[3];
 			pixel_point(A, idx, depth, point);
@@ -461,27 +440,29 @@ __global__ __launch_bounds__(256) void fuse_pass_kernel(DevMap A, const DevMap* 
 				++accepted;
 				for (int v = 0; v < ninv; ++v) st_f32(&maps[invImg[v]].depth[invPix[v]], 0.f);
 			}
-			// decided: stamp the round and wake the higher raster indices on my targets for the next round
-			st_u32(&tb.doneRound[idx], r);
+			// decided: my stores must be out before anybody I release looks at them
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			++decided;
 			{
 				const uint32_t o = tb.offP[tb.stride + idx], len = tb.cntP[tb.stride + idx];
 				for (uint32_t k0 = 0; k0 < len; k0 += 8) {
 					uint32_t b[8], was[8];
 #pragma unroll
-					for (int j = 0; j < 8; ++j) b[j] = k0 + j < len ? tb.nbrList[o + k0 + j] : 0xFFFFFFFFu;
+					for (int j = 0; j < 8; ++j) b[j] = k0 + j < len ? tb.nbrList[o + k0 + j] : FS_EMPTY;
 #pragma unroll
-					for (int j = 0; j < 8; ++j) was[j] = b[j] != 0xFFFFFFFFu ? atomicMax(&tb.queued[b[j]], r + 1u) : 0xFFFFFFFFu;
+					for (int j = 0; j < 8; ++j) was[j] = b[j] != FS_EMPTY ? atomicSub(&tb.cntP[b[j]], 1u) : 0u;
 #pragma unroll
 					for (int j = 0; j < 8; ++j)
-						if (was[j] < r + 1u) st_u32(&listOut[atomicAdd(fp.roundCnt + r + 1, 1u)], b[j]);
+						if (was[j] == 1u) { // I was its last blocker: it is mine if I have nothing yet, otherwise anybody's
+							if (item == FS_EMPTY) item = b[j];
+							else st_u32(&fp.queue[atomicAdd(qTail, 1u)], b[j]);
+						}
 				}
 			}
 		}
-		if (tail) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); }
-		else if (!grid_barrier(fp.barrier, target)) return;
 	}
+	if (decided) atomicAdd(nDone, decided);
 	if (accepted) atomicAdd(&counters[3], (unsigned long long)accepted);
-	if (blockIdx.x == 0 && threadIdx.x == 0) st_u32(fp.barrier + 2, r);
 }
 
 // ordered compaction of the accepted pixels of one pass into the cloud
@@ -524,37 +505,35 @@ void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsig
 	hipLaunchKernelGGL(filter_vote_kernel, kGrid, kBlock, 0, s, ref, nbs, N, keys, adjust, nMinViews, nMinViewsAdjust, thr, newDepth, newConf, counters);
 }
 FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_t* fillT, uint32_t* bidders, uint32_t* cntP, uint32_t* offP,
-                       uint32_t* nbrList, uint32_t* doneRound, uint32_t* queued, size_t stride) {
+                       uint32_t* nbrList, size_t stride) {
 	FuseTables tb;
 	tb.targets = targets; tb.cntT = cntT; tb.offT = offT; tb.fillT = fillT; tb.bidders = bidders; tb.cntP = cntP; tb.offP = offP; tb.nbrList = nbrList;
-	tb.doneRound = doneRound; tb.queued = queued; tb.stride = stride;
+	tb.stride = stride;
 	return tb;
 }
-// begin of an image pass: first candidate list (roundCnt[1]), targets, per-target lists, per-pixel link counts + offsets
-// (cntT / fillT / cntP must be zero).  fuse_links_fill writes the link lists once the host has checked their total size.
+// begin of an image pass: the pending list (its length in ctl[4]), targets, per-target lists, per-pixel link counts + offsets
+// (cntT / fillT / cntP must be zero).  fuse_links_fill writes the link lists once the host has sized them.
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
-                       uint32_t* roundCnt, uint8_t* flag, unsigned long long* counters, int order, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, roundCnt, flag, counters);
+                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, ctl + 3, flag, counters); // roundCnt[1] == ctl[4]
 	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntT, tb.offT, (int)(tb.stride * (size_t)A.nNeighbors), s);
-	hipLaunchKernelGGL(fuse_fill_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, roundCnt);
-	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, roundCnt, 0, order);
+	hipLaunchKernelGGL(fuse_fill_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3);
+	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3, 0, order);
 	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntP, tb.offP, (int)(2 * tb.stride), s);
 }
-void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* roundCnt, int order, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, roundCnt, 1, order);
+void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3, 1, order);
 }
-// the whole image pass in one persistent launch; `blocks` must not exceed the number of workgroups the device keeps
-// resident at once (the rounds are separated by a grid barrier)
-void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, uint32_t* list0, uint32_t* list1, uint32_t* roundCnt,
-                      uint32_t* barrier, uint32_t roundCap, float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
+// the whole image pass in one launch of dataflow workers (one wave per workgroup); any grid size is correct
+void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl,
+                      float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
                       int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, int blocks, hipStream_t s) {
 	FuseOut out{oxyz, onormal, obgr, onv, oflag};
 	FusePass fp;
-	fp.list[0] = list0; fp.list[1] = list1; fp.tb = tb;
-	fp.roundCnt = roundCnt; fp.barrier = barrier; fp.roundCap = roundCap; fp.tailCount = getenv("HCMVS_FUSE_TAIL") ? (uint32_t)atoi(getenv("HCMVS_FUSE_TAIL")) : 256u;
+	fp.tb = tb; fp.queue = queue; fp.ctl = ctl;
 	fp.nMinViewsFuse = nMinViewsFuse; fp.thDepth = thDepth; fp.normalError = normalError;
-	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_pass_kernel<16>, dim3(blocks), dim3(256), 0, s, A, maps, fp, out, counters);
-	else hipLaunchKernelGGL(fuse_pass_kernel<32>, dim3(blocks), dim3(256), 0, s, A, maps, fp, out, counters);
+	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_pass_kernel<16>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
+	else hipLaunchKernelGGL(fuse_pass_kernel<32>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
 }
 size_t fuse_scan_temp_bytes(int n) {
 	size_t bytes = 0;

@@ -77,6 +77,7 @@ struct hcmvs_ctx {
 	DevMap* dMaps = nullptr; size_t capMaps = 0;
 	unsigned long long* counters = nullptr;
 	void* fuseScratch = nullptr; size_t capFuseScratch = 0;
+	uint32_t* fuseLinks = nullptr; size_t capFuseLinks = 0; // per-pixel link lists of the fuse pass (grown to the exact size)
 	bool errPending = false; // an estimate was enqueued since the error word was last read
 	int wavesPerRow = 0; // 0 = automatic: 2 waves per row for small batches (latency), 1 when >= 3 images fill the chip
 };
@@ -209,7 +210,7 @@ void hcmvs_destroy(hcmvs_ctx* c) {
 	for (auto& kv : c->views) free_view(kv.second);
 	for (auto& sl : c->slots) for (void* p : {(void*)sl.dn, (void*)sl.conf, (void*)sl.tmpDepth, (void*)sl.progress, (void*)sl.srcSlab}) if (p) (void)hipFree(p);
 	for (void* p : {(void*)c->tmpU8, (void*)c->sDepth, (void*)c->sNormal, (void*)c->sConf, (void*)c->dViews, (void*)c->dItems, (void*)c->sync,
-	                (void*)c->evals, (void*)c->dMaps, (void*)c->counters, c->fuseScratch})
+	                (void*)c->evals, (void*)c->dMaps, (void*)c->counters, c->fuseScratch, (void*)c->fuseLinks})
 		if (p) (void)hipFree(p);
 	for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -783,8 +784,6 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	hipStream_t s = c->stream;
 	for (auto& m : host) if (m.depth) { launch_fill_u32(m.claim, 0xFFFFFFFFu, (size_t)m.w * m.h, s); }
 	// per-pass scratch (sized for the largest image) + device cloud
-	constexpr int kRoundCap = 1 << 18; // rounds of one image pass (one counter each)
-	constexpr size_t kLinkFactor = 3;  // room for the per-pixel link lists, in units of (pixels x neighbours)
 	int maxNb = 1;
 	size_t stride = maxArea; // pixels reserved per neighbour map in the per-target tables
 	for (int i = 0; i < n_order; ++i) {
@@ -797,24 +796,20 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	const size_t scanBytes = (std::max({fuse_scan_temp_bytes((int)maxArea), fuse_scan_temp_bytes((int)tblElems), fuse_scan_temp_bytes((int)(2 * stride))}) + 255) & ~(size_t)255;
 	size_t off = 0;
 	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-	const size_t oList0 = carve(maxArea * 4), oList1 = carve(maxArea * 4), oTgt = carve(maxArea * 4 * (size_t)maxNb),
+	const size_t oPending = carve(maxArea * 4), oQueue = carve(maxArea * 4), oTgt = carve(maxArea * 4 * (size_t)maxNb),
 	             oCntT = carve(tblElems * 4), oFillT = carve(tblElems * 4), oCntP = carve(stride * 8), oOffT = carve(tblElems * 4), oOffP = carve(stride * 8),
-	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oNbr = carve(kLinkFactor * maxArea * 4 * (size_t)maxNb),
-	             oDone = carve(maxArea * 4), oQueued = carve(maxArea * 4), oCnt = carve((size_t)(kRoundCap + 1) * 4), oBar = carve(64),
+	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(64),
 	             oFlag = carve(maxArea), oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
 	             oXyz = carve(maxArea * 12), oNrm = carve(maxArea * 12), oBgr = carve(maxArea * 3), oNv = carve(maxArea * 4),
 	             oCX = carve(capacity * 12), oCN = carve(normal ? capacity * 12 : 0), oCB = carve(bgr ? capacity * 3 : 0), oCV = carve(n_views ? capacity * 4 : 0);
 	rc = ensure_scratch(c, off);
 	if (rc) return rc;
 	char* b = (char*)c->fuseScratch;
-	uint32_t* lists[2] = {(uint32_t*)(b + oList0), (uint32_t*)(b + oList1)};
-	uint32_t* roundCnt = (uint32_t*)(b + oCnt); uint32_t* bar = (uint32_t*)(b + oBar);
+	uint32_t* pendingList = (uint32_t*)(b + oPending); uint32_t* queue = (uint32_t*)(b + oQueue);
+	uint32_t* ctl = (uint32_t*)(b + oCtl);
 	int32_t* targets = (int32_t*)(b + oTgt);
 	uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders),
-	         *doneRound = (uint32_t*)(b + oDone), *queued = (uint32_t*)(b + oQueued), *cntP = (uint32_t*)(b + oCntP), *offP = (uint32_t*)(b + oOffP),
-	         *nbrList = (uint32_t*)(b + oNbr);
-	const FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, cntP, offP, nbrList, doneRound, queued, stride);
-	const size_t linkCap = kLinkFactor * maxArea * (size_t)maxNb;
+	         *cntP = (uint32_t*)(b + oCntP), *offP = (uint32_t*)(b + oOffP);
 	uint8_t* flag = (uint8_t*)(b + oFlag);
 	uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos);
 	float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
@@ -822,37 +817,53 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	uint32_t* cV = n_views ? (uint32_t*)(b + oCV) : nullptr;
 	const float normalError = cosf(normal_diff_deg * normalweight * (3.14159274101257324f / 180.f)); // SceneDensify.cpp:3310
 	const float thDepth = depth_diff_threshold * depthweight;                                       // SceneDensify.cpp:3400
-	// as many workgroups as the device keeps resident at once (the grid barrier of the pass kernel relies on that)
+	// dataflow workers: one wave per workgroup, a few per CU; any number is correct (no co-residency assumption)
 	hipDeviceProp_t prop;
 	HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
 	const int nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
+	int blocks = nCU * 4;
+	if (getenv("HCMVS_FUSE_BLOCKS")) blocks = std::min(nCU * 16, std::max(1, atoi(getenv("HCMVS_FUSE_BLOCKS"))));
 	unsigned long long total = 0, depths = 0;
 	for (int oi = 0; oi < n_order; ++oi) { // best connected images first (SceneDensify.cpp:3302, order given by the caller)
 		const DevMap& A = host[order[oi]];
 		const int n = A.w * A.h;
 		HIPCHK(c, hipMemsetAsync(c->counters, 0, 64, s));
-		HIPCHK(c, hipMemsetAsync(roundCnt, 0, oFlag - oCnt, s));                              // round counters + barrier words
+		HIPCHK(c, hipMemsetAsync(ctl, 0, 64, s));
+		HIPCHK(c, hipMemsetAsync(queue, 0xFF, (size_t)n * 4, s));                             // FS_EMPTY
 		HIPCHK(c, hipMemsetAsync(cntT, 0, (oOffT - oCntT), s));                               // per-target counts, fill cursors, per-pixel link counts
-		launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, lists[1], roundCnt, flag, c->counters, c->fuseOrder, s);
+		FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, cntP, offP, c->fuseLinks, stride);
+		launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, c->counters, c->fuseOrder, s);
 		uint32_t lastOff = 0, lastCnt = 0; // total size of the link lists = last offset + last count
 		HIPCHK(c, hipMemcpyAsync(&lastOff, offP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, s));
 		HIPCHK(c, hipMemcpyAsync(&lastCnt, cntP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, s));
 		HIPCHK(c, hipStreamSynchronize(s));
-		if ((size_t)lastOff + lastCnt > linkCap)
-			return fail(c, HCMVS_ERR_CAPACITY, "fuse: image %u has %zu pixel links (room for %zu): too many of its pixels project onto the same neighbour pixels",
-			            A.id, (size_t)lastOff + lastCnt, linkCap);
-		launch_fuse_links_fill(A, tb, lists[1], roundCnt, c->fuseOrder, s);
-		launch_fuse_pass(A, c->dMaps, tb, lists[0], lists[1], roundCnt, bar, (uint32_t)kRoundCap,
-		                 pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, n_min_views_fuse, thDepth, normalError, c->counters,
-		                 getenv("HCMVS_FUSE_BLOCKS") ? std::min(nCU, std::max(1, atoi(getenv("HCMVS_FUSE_BLOCKS")))) : nCU, s);
+		// the link lists hold, per pending pixel, every other pending pixel that shares a target with it: their total is
+		// only known now (a neighbour seen at a much coarser scale collects many pixels per target), so the buffer grows
+		// to the exact size instead of failing (the reference's FuseDepthMaps has no such limit)
+		const size_t links = (size_t)lastOff + lastCnt;
+		if (links > c->capFuseLinks) {
+			if (c->fuseLinks) (void)hipFree(c->fuseLinks);
+			c->fuseLinks = nullptr; c->capFuseLinks = 0;
+			const size_t want = std::max(links + links / 4, (size_t)1 << 20);
+			HIPCHK(c, hipMalloc(&c->fuseLinks, want * 4));
+			c->capFuseLinks = want;
+			tb.nbrList = c->fuseLinks;
+		}
+		launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, s);
+		launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, n_min_views_fuse,
+		                 thDepth, normalError, c->counters, blocks, s);
 		unsigned long long cnt[4];
-		uint32_t barWords[3] = {0, 0, 0};
+		uint32_t ctlWords[5] = {0, 0, 0, 0, 0};
 		HIPCHK(c, hipMemcpyAsync(cnt, c->counters, 32, hipMemcpyDeviceToHost, s));
-		HIPCHK(c, hipMemcpyAsync(barWords, bar, 12, hipMemcpyDeviceToHost, s));
+		HIPCHK(c, hipMemcpyAsync(ctlWords, ctl, 20, hipMemcpyDeviceToHost, s));
 		HIPCHK(c, hipStreamSynchronize(s));
-		if (barWords[1] != 0) return fail(c, HCMVS_ERR_TIMEOUT, "fuse: grid barrier timed out in image %u", A.id);
-		if (barWords[2] + 2 >= (uint32_t)kRoundCap) return fail(c, HCMVS_ERR_HIP, "fuse: image %u needs more than %d rounds", A.id, kRoundCap);
-		if (getenv("HCMVS_FUSE_DEBUG")) fprintf(stderr, "fuse: image %u: %u rounds, %llu accepted\n", A.id, barWords[2], cnt[3]);
+		if (ctlWords[3] != 0 || ctlWords[2] != ctlWords[4]) {
+			// a worker gave up waiting (never expected): the claim and depth maps are half updated -- say so, the caller must
+			// not reuse them
+			return fail(c, HCMVS_ERR_TIMEOUT, "fuse: the pass of image %u stalled (%u of %u pixels decided); the registered depth maps are left partially fused",
+			            A.id, ctlWords[2], ctlWords[4]);
+		}
+		if (getenv("HCMVS_FUSE_DEBUG")) fprintf(stderr, "fuse: image %u: %u pending pixels, %u through the queue, %llu accepted\n", A.id, ctlWords[4], ctlWords[0], cnt[3]);
 		depths += cnt[0];
 		const unsigned long long accepted = cnt[3];
 		if (total + accepted > capacity) return fail(c, HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity);

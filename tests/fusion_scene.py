@@ -6,8 +6,18 @@ import numpy as np
 synth = importlib.import_module("hc-mvs_amd.synth")
 
 
-def make_maps(w=96, h=80, f=90.0, n_views=5, seed=3, noise=0.0, outliers=0.0, holes=0.0):
-    views = synth.make_views(w, h, f, n_views - 1, seed=seed, baseline=(0.04, 0.09))
+def make_maps(w=96, h=80, f=90.0, n_views=5, seed=3, noise=0.0, outliers=0.0, holes=0.0, far=None, far_factor=2.8):
+    """far: index of a view that is moved back to far_factor times the scene distance (same focal length): its pixels are
+    far_factor times coarser, so several pixels of the other views land on each of its pixels"""
+    px = 10.0 / f
+    scene = synth.Scene(seed, min_wavelength=3.5 * px, max_wavelength=150 * px)
+    views = synth.make_views(w, h, f, n_views - 1, seed=seed, baseline=(0.04, 0.09), scene=scene)
+    if far is not None:
+        v = views[far]
+        C = np.array([v["C"][0], v["C"][1], -(far_factor - 1.0) * scene.depth0])
+        R = synth.look_at(C, np.array([0.0, 0.0, scene.depth0]))
+        gray, depth, normal = scene.render(v["K"], R, C, w, h)
+        views[far] = dict(K=v["K"], R=R, C=C, gray=gray, depth=depth, normal=normal, width=w, height=h)
     rng = np.random.RandomState(seed + 77)
     maps = []
     for i, v in enumerate(views):

@@ -41,6 +41,22 @@ def test_fuse_bit_exact(ctx, kw):
         assert np.array_equal(ctx.get_depthmap(i)[0], d)
 
 
+def test_fuse_scale_mismatched_neighbour(ctx):
+    """a neighbour seen at 2.8x the footprint scale: ~8 pixels of every other image land on each of its pixels, so the
+    per-pixel link lists are far longer than for equal scales (the round-1 build returned HCMVS_ERR_CAPACITY here; the
+    reference's FuseDepthMaps, SceneDensify.cpp:3265-3495, has no such limit).  Bit-exact against the oracle, both ways."""
+    for far in (1, 0):
+        maps, order = make_maps(w=160, h=128, f=150.0, n_views=5, noise=0.002, outliers=0.02, far=far, far_factor=2.8)
+        upload(ctx, maps)
+        want = O.fuse_depthmaps(maps, order, 200000)
+        got = ctx.fuse(order, 200000)
+        assert got["n_points"] == want["n_points"] > 1000 and got["n_depths"] == want["n_depths"]
+        assert np.array_equal(got["xyz"], want["xyz"]) and np.array_equal(got["n_views"], want["n_views"])
+        assert np.array_equal(got["normal"], want["normal"]) and np.array_equal(got["bgr"], want["bgr"])
+        for i, d in enumerate(want["depths"]):
+            assert np.array_equal(ctx.get_depthmap(i)[0], d)
+
+
 def test_fuse_options_and_capacity(ctx):
     maps, order = make_maps(noise=0.002)
     upload(ctx, maps)
