@@ -47,7 +47,8 @@ _lib = None
 
 # every symbol include/hcmvs_hip.h declares
 SYMBOLS = ["hcmvs_default_params", "hcmvs_create", "hcmvs_destroy", "hcmvs_last_error", "hcmvs_set_stream",
-           "hcmvs_synchronize", "hcmvs_upload_view", "hcmvs_set_view_device", "hcmvs_release_view",
+           "hcmvs_synchronize", "hcmvs_upload_view", "hcmvs_set_view_device", "hcmvs_release_view", "hcmvs_rescale_view", "hcmvs_get_view_info",
+           "hcmvs_get_view_gray",
            "hcmvs_get_gradient_map", "hcmvs_estimate", "hcmvs_estimate_device", "hcmvs_estimate_batch_device", "hcmvs_get_stats",
            "hcmvs_splat_init", "hcmvs_triangulate_init", "hcmvs_triangulate_points", "hcmvs_set_depthmap", "hcmvs_set_depthmap_device", "hcmvs_get_depthmap",
            "hcmvs_set_neighbors", "hcmvs_filter", "hcmvs_set_fuse_order", "hcmvs_fuse"]
@@ -94,6 +95,9 @@ def lib():
         L.hcmvs_upload_view.argtypes = [vp, C.c_uint32, C.c_int32, C.c_int32, fp, u8p, dp, dp, dp]
         L.hcmvs_set_view_device.argtypes = [vp, C.c_uint32, C.c_int32, C.c_int32, vp, vp, dp, dp, dp]
         L.hcmvs_release_view.argtypes = [vp, C.c_uint32]
+        L.hcmvs_rescale_view.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_float]
+        L.hcmvs_get_view_info.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp]
+        L.hcmvs_get_view_gray.argtypes = [vp, C.c_uint32, fp]
         L.hcmvs_get_gradient_map.argtypes = [vp, C.c_uint32, u8p]
         L.hcmvs_estimate.argtypes = [vp, C.c_uint32, u32p, C.c_int32, C.POINTER(Params), C.c_float, C.c_float, fp, fp, fp]
         L.hcmvs_estimate_device.argtypes = [vp, C.c_uint32, u32p, C.c_int32, C.POINTER(Params), C.c_float, C.c_float,
@@ -186,6 +190,16 @@ class Context:
                                               C.c_void_p(d_bgr_ptr) if d_bgr_ptr else None, Kp, Rp, Cp))
         self.shapes[vid] = (h, w)
 
+    def rescale_view(self, src_id, dst_id, scale):
+        """DepthData::ViewData::ScaleImage: view dst_id = view src_id resampled by scale; returns (gray, K) of the new view"""
+        self._chk(lib().hcmvs_rescale_view(self._h, src_id, dst_id, C.c_float(scale)))
+        w = C.c_int32(); h = C.c_int32(); K = (C.c_double * 9)()
+        self._chk(lib().hcmvs_get_view_info(self._h, dst_id, C.byref(w), C.byref(h), K))
+        self.shapes[dst_id] = (h.value, w.value)
+        g = np.empty((h.value, w.value), np.float32)
+        self._chk(lib().hcmvs_get_view_gray(self._h, dst_id, _f(g)))
+        return g, np.array(list(K), np.float64).reshape(3, 3)
+
     def release_view(self, vid):
         self._chk(lib().hcmvs_release_view(self._h, vid))
         self.shapes.pop(vid, None)
@@ -255,6 +269,11 @@ class Context:
         d = np.ascontiguousarray(depth, np.float32); c = np.ascontiguousarray(conf, np.float32)
         n = None if normal is None else np.ascontiguousarray(normal, np.float32)
         self._chk(lib().hcmvs_set_depthmap(self._h, vid, _f(d), None if n is None else _f(n), _f(c), d_min, d_max))
+
+    def set_depthmap_device(self, vid, d_depth_ptr, d_normal_ptr, d_conf_ptr, d_min, d_max):
+        """maps that already live in device memory (caller-owned; fusion mutates the depth map, SceneDensify.cpp:3447-3449)"""
+        self._chk(lib().hcmvs_set_depthmap_device(self._h, vid, C.c_void_p(d_depth_ptr), C.c_void_p(d_normal_ptr) if d_normal_ptr else None,
+                                                  C.c_void_p(d_conf_ptr), d_min, d_max))
 
     def get_depthmap(self, vid):
         h, w = self.shapes[vid]

@@ -134,6 +134,7 @@ static inline float fd2r(float d) { return d * (3.14159274101257324f / 180.f); }
 #ifdef HCMVS_STAMPS
 namespace hcmvs { void debug_read_stamps(unsigned long long* out, int reset); }
 #endif
+namespace hcmvs { void launch_resize_gray(const float* src, int sw, int sh, float* dst, int dw, int dh, float scaleParam, hipStream_t s); } // img_kernels.hip
 
 extern "C" {
 
@@ -279,6 +280,49 @@ int hcmvs_set_view_device(hcmvs_ctx* c, uint32_t id, int32_t w, int32_t h, const
                           const double K[9], const double R[9], const double C[3]) {
 	return set_view(c, id, w, h, gray, bgr, K, R, C, false);
 }
+int hcmvs_rescale_view(hcmvs_ctx* c, uint32_t src_id, uint32_t dst_id, float scale) {
+	if (!c) return HCMVS_ERR_INVALID;
+	auto it = c->views.find(src_id);
+	if (it == c->views.end() || dst_id >= 65536 || dst_id == src_id) return fail(c, HCMVS_ERR_INVALID, "rescale_view: bad view ids %u -> %u", src_id, dst_id);
+	if (!(scale > 0.f) || fabsf(scale - 1.f) < 0.15f) return fail(c, HCMVS_ERR_INVALID, "rescale_view: scale %g is within 15 %% of 1 (DepthMap.h:234: not resampled)", scale);
+	const View src = it->second;
+	// cv::resize with dsize empty: Size(saturate_cast<int>(w * fx), saturate_cast<int>(h * fy)), saturate_cast<int>(double) = cvRound
+	const int nw = (int)lrint((double)src.w * (double)scale), nh = (int)lrint((double)src.h * (double)scale);
+	if (nw < 2 * kHalfWindow + 2 || nh < 2 * kHalfWindow + 2 || nw > 32768 || nh > 32768) return fail(c, HCMVS_ERR_INVALID, "rescale_view: %dx%d x %g gives an unusable size", src.w, src.h, scale);
+	HIPCHK(c, hipSetDevice(c->device));
+	auto old = c->views.find(dst_id);
+	if (old != c->views.end()) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_view(old->second); c->views.erase(old); }
+	View v;
+	v.w = nw; v.h = nh; v.owned = true;
+	HIPCHK(c, hipMalloc(&v.gray, (size_t)nw * nh * sizeof(float)));
+	hcmvs::launch_resize_gray(src.gray, src.w, src.h, v.gray, nw, nh, scale, c->stream);
+	HIPCHK(c, hipGetLastError());
+	// Image::GetCamera(platforms, size): K normalised by max(w, h) of the image, scaled to max(w', h') (Camera.h:167-180)
+	const double f = (double)std::max(nw, nh) / (double)std::max(src.w, src.h);
+	memcpy(v.K, src.K, sizeof v.K); memcpy(v.R, src.R, sizeof v.R); memcpy(v.C, src.C, sizeof v.C);
+	v.K[0] *= f; v.K[4] *= f; v.K[2] *= f; v.K[5] *= f;
+	c->views[dst_id] = v;
+	return HCMVS_OK;
+}
+int hcmvs_get_view_info(hcmvs_ctx* c, uint32_t id, int32_t* w, int32_t* h, double K[9]) {
+	if (!c) return HCMVS_ERR_INVALID;
+	auto it = c->views.find(id);
+	if (it == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "get_view_info: unknown view %u", id);
+	if (w) *w = it->second.w;
+	if (h) *h = it->second.h;
+	if (K) memcpy(K, it->second.K, sizeof(double) * 9);
+	return HCMVS_OK;
+}
+int hcmvs_get_view_gray(hcmvs_ctx* c, uint32_t id, float* out) {
+	if (!c || !out) return HCMVS_ERR_INVALID;
+	auto it = c->views.find(id);
+	if (it == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "get_view_gray: unknown view %u", id);
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipMemcpyAsync(out, it->second.gray, (size_t)it->second.w * it->second.h * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return HCMVS_OK;
+}
+
 int hcmvs_release_view(hcmvs_ctx* c, uint32_t id) {
 	if (!c) return HCMVS_ERR_INVALID;
 	auto it = c->views.find(id);

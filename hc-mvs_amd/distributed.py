@@ -50,6 +50,12 @@ def allgather_maps(local_slabs, group=None, out=None):
     if out is None:
         out = torch.empty((world * local_slabs.shape[0],) + tuple(local_slabs.shape[1:]), dtype=local_slabs.dtype,
                           device=local_slabs.device)
+    if local_slabs.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal on one GPU box (several ranks on device 0): gloo gathers host tensors; staged through pinned-size copies
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local_slabs.cpu().contiguous(), group=group)
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, local_slabs.contiguous(), group=group)
     return out
 
@@ -67,3 +73,66 @@ def gather_scene_maps(order, my_maps, h, w, group=None, device=None):
         pack_maps(*my_maps[img], out=slabs[j])
     allm = allgather_maps(slabs, group)
     return {img: unpack_maps(allm[slab_index(k, world, n_local)], h, w) for k, img in enumerate(order)}
+
+
+def densify_scene(ctx, views, srcs, neighbors, order, init, params, group=None, device=None, batch=32, capacity=None,
+                  fuse_kw=None):
+    """The multi-rank scene path (BASELINE.json configs[3]) over the C-ABI binding:
+
+        shard_order -> per-rank hcmvs_estimate_batch_device -> all-gather of the packed maps on the device ->
+        hcmvs_set_depthmap_device + hcmvs_fuse on every rank (replicated fusion, identical clouds).
+
+    ctx:       binding.Context of this rank's device (one process per GPU)
+    views:     {image id: dict(gray, K, R, C[, bgr])} of EVERY image (all the same size): images are read-only inputs each
+               rank needs for the source views of its own reference images and for the colours of the fused points
+    srcs:      {image id: [source view ids]}            (DepthMapsData::InitViews, SceneDensify.cpp:336-397)
+    neighbors: {image id: [neighbour ids]}              (DepthData::neighbors, decreasing importance)
+    order:     fusion order, best connected first       (SceneDensify.cpp:3302)
+    init:      {image id: (depth0 (H,W), normal0 (H,W,3), d_min, d_max)} numpy, at least for this rank's images
+    params:    binding.Params of the estimate (one outer iteration; call again for the next)
+    Returns the fused cloud dict of binding.Context.fuse plus `maps`: {id: (depth, normal, conf) device tensors}."""
+    import numpy as np
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    ids = list(order)
+    h, w = views[ids[0]]["gray"].shape
+    hw = h * w
+    for i in ids:
+        assert views[i]["gray"].shape == (h, w), "densify_scene: all images must have one size (equal slabs for one all-gather)"
+    for i, v in views.items():
+        ctx.upload_view(i, v["gray"], v["K"], v["R"], v["C"], bgr=v.get("bgr"))
+    mine = shard_order(ids, world)[rank]
+    n_local = (len(ids) + world - 1) // world
+    slabs = torch.zeros(n_local, FLOATS_PER_PIXEL * hw, dtype=torch.float32, device=dev)
+    rng = torch.zeros(n_local, 2, dtype=torch.float32, device=dev)      # (d_min, d_max) travel with the maps
+    items_by_class = {}
+    for j, img in enumerate(mine):
+        d0, n0, dmin, dmax = init[img]
+        slabs[j, :hw] = torch.from_numpy(np.ascontiguousarray(d0, np.float32)).reshape(-1).to(dev)
+        slabs[j, hw:4 * hw] = torch.from_numpy(np.ascontiguousarray(n0, np.float32)).reshape(-1).to(dev)
+        rng[j, 0], rng[j, 1] = float(dmin), float(dmax)
+        base = slabs[j].data_ptr()
+        v = len(srcs[img])
+        cls = 1 if v <= 1 else 2 if v <= 2 else 4 if v <= 4 else 8 if v <= 8 else 16   # one kernel lane layout per class
+        items_by_class.setdefault(cls, []).append(dict(ref_id=img, src_ids=list(srcs[img]), d_min=float(dmin), d_max=float(dmax),
+                                                       d_depth=base, d_normal=base + 4 * hw, d_conf=base + 16 * hw, seed_offset=img))
+    torch.cuda.synchronize(dev)
+    for cls, items in sorted(items_by_class.items()):     # NO collective on the estimation path
+        for b0 in range(0, len(items), batch):
+            ctx.estimate_batch_device(items[b0:b0 + batch], params)
+    ctx.synchronize()
+    allm = allgather_maps(slabs, group)                    # the one exchange: 20 B/px, rank-major equal slabs
+    allr = allgather_maps(rng, group)
+    maps = {}
+    for k, img in enumerate(ids):
+        row = slab_index(k, world, n_local)
+        base = allm[row].data_ptr()
+        ctx.set_depthmap_device(img, base, base + 4 * hw, base + 16 * hw, float(allr[row, 0]), float(allr[row, 1]))
+        ctx.set_neighbors(img, [n for n in neighbors[img] if n in views][:31])
+        maps[img] = unpack_maps(allm[row], h, w)
+    cap = capacity if capacity is not None else hw * len(ids) // 2
+    cloud = ctx.fuse(ids, cap, **(fuse_kw or {}))          # replicated on every rank: identical clouds
+    cloud["maps"] = maps
+    cloud["_keep"] = (allm, allr, slabs)                   # the registered device maps must outlive the context's use of them
+    return cloud

@@ -60,7 +60,9 @@ struct ImageData {
 	std::vector<uint32_t> points;               // sparse points seen (>= 2 views), Scene.cpp:568-569
 	struct Nb { uint32_t id; uint32_t points; float scale, angle, area, score; };
 	std::vector<Nb> neighbors;                  // Scene.cpp:640-650, sorted by score
-	std::vector<uint32_t> srcs;                 // SceneDensify.cpp:362-367
+	std::vector<uint32_t> srcs;                 // SceneDensify.cpp:362-367 (the ids the estimate is called with: resampled copies get ids of their own)
+	std::vector<float> srcScale;                // per source view: 1 or the scale it is resampled by (ViewData::ScaleImage)
+	std::vector<uint32_t> srcImages;            // the scene images behind srcs
 	float dMin = 0, dMax = 0;
 	float *dDepth = nullptr, *dNormal = nullptr, *dConf = nullptr; // device maps
 };
@@ -276,8 +278,8 @@ bool select_views(std::vector<ImageData>& images, const std::vector<Vertex>& ver
 	const float fMinScore = A.neighbors[0].score * (0.3f * 0.1f);
 	for (const auto& nb : A.neighbors) {
 		if ((numberViews && (int)A.srcs.size() + 1 > numberViews) || nb.score < fMinScore) break;
-		if (std::fabs(nb.scale - 1.f) >= 0.15f) continue; // would need the rescaled-neighbour path (DepthMap.h:233-238)
 		A.srcs.push_back(nb.id);
+		A.srcScale.push_back(std::fabs(nb.scale - 1.f) >= 0.15f ? nb.scale : 1.f); // >= 15 %: the view is resampled (DepthMap.h:233-238)
 	}
 	return !A.srcs.empty();
 }
@@ -290,8 +292,9 @@ bool save_dmap(const std::string& path, const ImageData& im, const std::vector<f
 	f.write((const char*)&h, 28);
 	const uint16_t nl = (uint16_t)im.name.size();
 	f.write((const char*)&nl, 2); f.write(im.name.data(), nl);
-	const uint32_t nids = 1 + (uint32_t)im.srcs.size();
-	f.write((const char*)&nids, 4); f.write((const char*)&im.id, 4); f.write((const char*)im.srcs.data(), (std::streamsize)im.srcs.size() * 4);
+	const std::vector<uint32_t>& ids = im.srcImages.empty() ? im.srcs : im.srcImages; // scene image ids, not the ids of resampled copies
+	const uint32_t nids = 1 + (uint32_t)ids.size();
+	f.write((const char*)&nids, 4); f.write((const char*)&im.id, 4); f.write((const char*)ids.data(), (std::streamsize)ids.size() * 4);
 	f.write((const char*)im.cam.K, 72); f.write((const char*)im.cam.R, 72); f.write((const char*)im.cam.C, 24);
 	f.write((const char*)d.data(), (std::streamsize)d.size() * 4); f.write((const char*)n.data(), (std::streamsize)n.size() * 4);
 	f.write((const char*)c.data(), (std::streamsize)c.size() * 4);
@@ -501,6 +504,30 @@ int main(int argc, char** argv) {
 				printf(" %3u(%.2fscl)", s, scl);
 			}
 			printf(" (%zu shared points)\n", im.points.size());
+		}
+	}
+	// neighbours whose footprint scale differs by >= 15 % are resampled on the device and registered as views of their own
+	// (DepthData::ViewData::ScaleImage + Image::GetCamera, SceneDensify.cpp:372-374); one copy per (image, new size)
+	{
+		std::map<std::pair<uint32_t, std::pair<int, int>>, uint32_t> scaled;
+		uint32_t nextId = 0x8000;
+		for (uint32_t id : todo) {
+			ImageData& im = images[id];
+			im.srcImages = im.srcs;
+			for (size_t k = 0; k < im.srcs.size(); ++k) {
+				if (im.srcScale[k] == 1.f) continue;
+				const ImageData& sv = images[im.srcs[k]];
+				const std::pair<int, int> size((int)std::lrint((double)sv.w * im.srcScale[k]), (int)std::lrint((double)sv.h * im.srcScale[k]));
+				const auto key = std::make_pair(sv.id, size);
+				auto it = scaled.find(key);
+				if (it == scaled.end()) {
+					if (nextId >= 65536) { fprintf(stderr, "error: too many resampled neighbour views\n"); return EXIT_FAILURE; }
+					CHK(hcmvs_rescale_view(ctx, sv.id, nextId, im.srcScale[k]));
+					if (o.verbosity > 2) printf("Image %3u resampled by %.2f to %dx%d as view %u\n", sv.id, im.srcScale[k], size.first, size.second, nextId);
+					it = scaled.emplace(key, nextId++).first;
+				}
+				im.srcs[k] = it->second;
+			}
 		}
 	}
 	hcmvs_params prm;

@@ -102,6 +102,17 @@ int hcmvs_upload_view(hcmvs_ctx* ctx, uint32_t id, int32_t width, int32_t height
 /* same, but gray/bgr already live in device memory and stay owned by the caller */
 int hcmvs_set_view_device(hcmvs_ctx* ctx, uint32_t id, int32_t width, int32_t height, const float* d_gray,
                           const uint8_t* d_bgr_or_null, const double K[9], const double R[9], const double C[3]);
+/* DepthData::ViewData::ScaleImage (DepthMap.h:233-238) + Image::GetCamera for the new size (SceneDensify.cpp:372-374,
+ * Image.cpp:194-209): register view dst_id as view src_id resampled by `scale` on the device -- cv::resize(image, Size(),
+ * scale, scale, scale > 1 ? INTER_CUBIC : INTER_AREA) on the f32 gray image, new size cvRound(w * scale) x cvRound(h * scale),
+ * K rescaled by max(w', h') / max(w, h) like the reference's normalised K.  The reference resamples a source view when its
+ * average footprint scale differs from the reference image's by 15 % or more; |scale - 1| < 0.15 is refused as it is there.
+ * The new view has no colour image (source views are only matched against). */
+int hcmvs_rescale_view(hcmvs_ctx* ctx, uint32_t src_id, uint32_t dst_id, float scale);
+/* size and camera of a registered view (any pointer may be NULL) */
+int hcmvs_get_view_info(hcmvs_ctx* ctx, uint32_t id, int32_t* width, int32_t* height, double K[9]);
+/* copy the f32 gray image of a registered view to a host buffer of w*h floats */
+int hcmvs_get_view_gray(hcmvs_ctx* ctx, uint32_t id, float* out);
 int hcmvs_release_view(hcmvs_ctx* ctx, uint32_t id);
 /* copy the u8 gradient map of a view (SceneDensify.cpp:581-595 InitGraMap) to a host buffer of w*h bytes */
 int hcmvs_get_gradient_map(hcmvs_ctx* ctx, uint32_t id, uint8_t* out);

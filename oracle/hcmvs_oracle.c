@@ -228,6 +228,96 @@ void hcor_median3(const float* in, int w, int h, float* out) {
 		}
 }
 
+/* cv::resize(src, dst, Size(), scale, scale, scale > 1 ? INTER_CUBIC : INTER_AREA) on an f32 image, as
+ * DepthData::ViewData::ScaleImage calls it (DM.h:233-238).  OpenCV 4.2 imgproc/src/resize.cpp restated:
+ *   dsize = (cvRound(w*scale), cvRound(h*scale)); scale_x = scale_y = 1/scale (double);
+ *   INTER_AREA, integer factor -> ResizeAreaFast: block sum * (1/area);
+ *   INTER_AREA otherwise -> computeResizeAreaTab (per axis: leading partial cell if sx1 - fsx1 > 1e-3, whole cells with
+ *     alpha = 1/cellWidth, trailing partial cell if fsx2 - sx2 > 1e-3) and ResizeArea_Invoker: per source row the x table
+ *     accumulates into buf from 0, rows combine as sum = beta*buf for the first and sum += beta*buf for the rest;
+ *   INTER_CUBIC -> fx = (dx+0.5)*scale_x - 0.5, Keys kernel A = -0.75 (interpolateCubic), taps clamped to the image,
+ *     horizontal sums first, then the vertical one, left to right. */
+void hcor_resize_size(int w, int h, float scale, int* dw, int* dh) {
+	*dw = (int)lrint((double)w * (double)scale);
+	*dh = (int)lrint((double)h * (double)scale);
+}
+typedef struct { int idx[8]; float alpha[8]; int n; } area_tab; /* one destination cell; factor < 6 -> at most 8 entries */
+static void area_cell(int d, double scale, int ssize, int* idx, float* alpha, int* n, int cap) {
+	const double fsx1 = d * scale, fsx2 = fsx1 + scale;
+	const double cellWidth = fmin(scale, ssize - fsx1);
+	int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2), k = 0;
+	if (sx2 > ssize - 1) sx2 = ssize - 1;
+	if (sx1 > sx2) sx1 = sx2;
+	if (sx1 - fsx1 > 1e-3 && k < cap) { idx[k] = sx1 - 1; alpha[k++] = (float)((sx1 - fsx1) / cellWidth); }
+	for (int sx = sx1; sx < sx2 && k < cap; ++sx) { idx[k] = sx; alpha[k++] = (float)(1.0 / cellWidth); }
+	if (fsx2 - sx2 > 1e-3 && k < cap) { idx[k] = sx2; alpha[k++] = (float)(fmin(fmin(fsx2 - sx2, 1.), cellWidth) / cellWidth); }
+	*n = k;
+}
+static void cubic_w(float x, float* c) {
+	const float A = -0.75f;
+	c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+	c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+	c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+	c[3] = 1.f - c[0] - c[1] - c[2];
+}
+void hcor_resize_gray(const float* src, int sw, int sh, float scale, float* dst, int dw, int dh) {
+	const double sc = 1.0 / (double)scale;
+	if (scale > 1.f) {
+		for (int y = 0; y < dh; ++y) {
+			float fy = (float)((y + 0.5) * sc - 0.5);
+			const int sy = (int)floorf(fy);
+			fy -= sy;
+			float cy[4]; cubic_w(fy, cy);
+			for (int x = 0; x < dw; ++x) {
+				float fx = (float)((x + 0.5) * sc - 0.5);
+				const int sx = (int)floorf(fx);
+				fx -= sx;
+				float cx[4]; cubic_w(fx, cx);
+				float rows[4];
+				for (int j = 0; j < 4; ++j) {
+					int yy = sy - 1 + j; if (yy < 0) yy = 0; if (yy > sh - 1) yy = sh - 1;
+					float r = 0;
+					for (int i = 0; i < 4; ++i) {
+						int xx = sx - 1 + i; if (xx < 0) xx = 0; if (xx > sw - 1) xx = sw - 1;
+						const float t = src[(size_t)yy * sw + xx] * cx[i];
+						r = i ? r + t : t;
+					}
+					rows[j] = r;
+				}
+				dst[(size_t)y * dw + x] = ((rows[0] * cy[0] + rows[1] * cy[1]) + rows[2] * cy[2]) + rows[3] * cy[3];
+			}
+		}
+		return;
+	}
+	const int isc = (int)sc;
+	if ((double)isc == sc && isc >= 1 && dw * isc <= sw && dh * isc <= sh) {
+		const float inv = 1.f / (float)(isc * isc);
+		for (int y = 0; y < dh; ++y)
+			for (int x = 0; x < dw; ++x) {
+				float sum = 0;
+				for (int j = 0; j < isc; ++j)
+					for (int i = 0; i < isc; ++i) sum += src[(size_t)(y * isc + j) * sw + x * isc + i];
+				dst[(size_t)y * dw + x] = sum * inv;
+			}
+		return;
+	}
+	for (int y = 0; y < dh; ++y) {
+		int yi[16], ny; float yb[16];
+		area_cell(y, sc, sh, yi, yb, &ny, 16);
+		for (int x = 0; x < dw; ++x) {
+			int xi[16], nx; float xa[16];
+			area_cell(x, sc, sw, xi, xa, &nx, 16);
+			float sum = 0;
+			for (int j = 0; j < ny; ++j) {
+				float buf = 0;
+				for (int i = 0; i < nx; ++i) buf += src[(size_t)yi[j] * sw + xi[i]] * xa[i];
+				if (j == 0) sum = yb[j] * buf; else sum += yb[j] * buf;
+			}
+			dst[(size_t)y * dw + x] = sum;
+		}
+	}
+}
+
 void hcor_splat_init(const hcor_view* ref, const float* pts, int n, float* depth, float* normal,
                      float* d_min, float* d_max) {
 	/* SD.cpp:783-808 */

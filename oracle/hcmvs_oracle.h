@@ -73,6 +73,11 @@ typedef struct {
 
 void hcor_default_params(hcor_params* p);
 
+/* DepthData::ViewData::ScaleImage (DM.h:233-238): cv::resize(..., Size(), scale, scale, scale>1 ? INTER_CUBIC : INTER_AREA)
+ * on an f32 image, restated from OpenCV 4.2's published algorithm (OpenCV is absent: parity unpinned) */
+void hcor_resize_size(int w, int h, float scale, int* dw, int* dh);
+void hcor_resize_gray(const float* src, int sw, int sh, float scale, float* dst, int dw, int dh);
+
 /* ---- small pieces, exposed for known-answer tests ------------------------------------------- */
 
 /* DM.cpp:354-381 MapMatrix2ZigzagIdx (no mask). coords_xy: 2*w*h uint16 (x,y pairs). returns count */

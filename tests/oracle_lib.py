@@ -69,6 +69,8 @@ def lib():
         L.hcor_gray_f32_to_u8.argtypes = [fp, C.c_int, C.c_int, u8p]
         L.hcor_gradient_map.argtypes = [u8p, C.c_int, C.c_int, u8p]
         L.hcor_median3.argtypes = [fp, C.c_int, C.c_int, fp]
+        L.hcor_resize_size.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.hcor_resize_gray.argtypes = [fp, C.c_int, C.c_int, C.c_float, fp, C.c_int, C.c_int]
         L.hcor_splat_init.argtypes = [C.POINTER(View), fp, C.c_int, fp, fp, fp, fp]
         L.hcor_fill_patch.argtypes = [C.POINTER(View), u8p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, fp, fp, fp, fp]
         L.hcor_fill_patch.restype = C.c_int
@@ -152,6 +154,18 @@ def gradient_map(gray_f32):
     L.hcor_gray_f32_to_u8(fptr(np.ascontiguousarray(gray_f32)), w, h, u8ptr(g8))
     L.hcor_gradient_map(u8ptr(g8), w, h, u8ptr(gra))
     return gra
+
+
+def resize_gray(gray, scale):
+    """ViewData::ScaleImage on an f32 image: returns the resampled image"""
+    L = lib()
+    g = np.ascontiguousarray(gray, np.float32)
+    h, w = g.shape
+    dw = C.c_int(); dh = C.c_int()
+    L.hcor_resize_size(w, h, C.c_float(scale), C.byref(dw), C.byref(dh))
+    out = np.empty((dh.value, dw.value), np.float32)
+    L.hcor_resize_gray(fptr(g), w, h, C.c_float(scale), fptr(out), dw.value, dh.value)
+    return out
 
 
 def estimate(views, params, d_min, d_max, depth, normal, gra=None, passes="all", iter_index=0):

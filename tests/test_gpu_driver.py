@@ -159,3 +159,53 @@ def test_densify_driver_init_modes(tmp_path):
         acc[name] = _accuracy(tmp, views)
     assert acc["tri"] > 0.6 and acc["splat"] > 0.3
     assert acc["tri"] >= acc["splat"] - 0.02      # a full rough surface is at least as good a start as isolated splats
+
+
+@pytest.mark.gpu
+def test_densify_driver_rescales_mismatched_neighbours(tmp_path):
+    """one camera stands 1.7x farther from the scene than the others, so its footprint scale differs by
+    more than 15 %: the reference keeps such a neighbour and resamples it (DepthData::ViewData::ScaleImage, DepthMap.h:233-238,
+    SceneDensify.cpp:372-374) -- INTER_CUBIC up for the near references, INTER_AREA down for the far one.  The driver's choice
+    of views and scales is checked against the oracle's restatement of SelectNeighborViews/InitViews."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import select_views as SV
+    import scene_files as SF
+    tmp = str(tmp_path)
+    w, h, f = 320, 240, 380.0
+    px = 10.0 / f
+    scene = synth.Scene(7, min_wavelength=3.5 * px, max_wavelength=150 * px)
+    base = synth.make_views(w, h, f, 4, seed=7, baseline=(0.05, 0.1), scene=scene)
+    far = 2
+    C = np.array([base[far]["C"][0], base[far]["C"][1], -0.7 * scene.depth0])
+    R = synth.look_at(C, np.array([0.0, 0.0, scene.depth0]))
+    g, d, n = scene.render(base[far]["K"], R, C, w, h)
+    base[far] = dict(K=base[far]["K"], R=R, C=C, gray=g, depth=d, normal=n, width=w, height=h)
+    verts = SF.sparse_vertices(base, 250, seed=3)
+    path = SF.write_scene(tmp, base, verts)
+    r = subprocess.run([EXE, "-i", path, "--resolution-level", "0", "--number-views", "4", "--n-EstimationIters", "3", "--n-EstimationIters-external", "1",
+                        "--n-photometric_flow", "0", "--fusion-mode", "1", "-v", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "resampled by" in r.stdout
+    cams = [dict(K=v["K"], R=v["R"], C=v["C"]) for v in base]
+    vlist = [(x["X"], [j for j, _ in x["views"]]) for x in verts]
+    pairs = {}
+    for m in re.finditer(r"Reference image\s+(\d+) paired with (\d+) views:((?:\s+\d+\([\d.]+scl\))*)", r.stdout):
+        pairs[int(m.group(1))] = [(int(a), float(b)) for a, b in re.findall(r"(\d+)\(([\d.]+)scl\)", m.group(3))]
+    n_scaled = 0
+    for i in range(len(base)):
+        sel = SV.select(cams, [(w, h)] * len(base), vlist, i, number_views=4)
+        assert sel is not None and [s[0] for s in sel["srcs"]] == [p[0] for p in pairs[i]]
+        for (sid, sscale), (pid, pscale) in zip(sel["srcs"], pairs[i]):
+            nb = [q for q in sel["neighbors"] if q["id"] == sid][0]
+            assert abs(nb["scale"] - pscale) < 0.006
+            n_scaled += sscale != 1.0
+    assert n_scaled >= 4          # the far view as a neighbour of the others, and the others as neighbours of the far view
+    # the far image's depth map (its sources were all resampled down) and a near one (one source resampled up) are accurate
+    for i in (far, 0):
+        dm = mvsio.read_dmap(os.path.join(tmp, "depth%04d.dmap" % i))
+        assert len(dm["ids"]) >= 3 and all(j < len(base) for j in dm["ids"])     # scene image ids, not the ids of the copies
+        m = dm["depth"] > 0
+        gt = base[i]["depth"]
+        assert m.mean() > 0.5 and (np.abs(dm["depth"] - gt)[m] / gt[m] < 0.01).mean() > 0.8
