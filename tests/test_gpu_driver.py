@@ -208,4 +208,7 @@ def test_densify_driver_rescales_mismatched_neighbours(tmp_path):
         assert len(dm["ids"]) >= 3 and all(j < len(base) for j in dm["ids"])     # scene image ids, not the ids of the copies
         m = dm["depth"] > 0
         gt = base[i]["depth"]
-        assert m.mean() > 0.5 and (np.abs(dm["depth"] - gt)[m] / gt[m] < 0.01).mean() > 0.8
+        # the far camera sees 1.7x the field of the others: only the part the near cameras cover can be estimated
+        # (and at 1.7x the distance with the same small baselines 1 % of depth is a 3x tighter bar in disparity)
+        rel = np.abs(dm["depth"] - gt)[m] / gt[m]
+        assert m.mean() > (0.3 if i == far else 0.5) and (rel < 0.01).mean() > (0.6 if i == far else 0.8)
