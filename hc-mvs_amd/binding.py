@@ -37,6 +37,12 @@ class BatchItem(C.Structure):
                 ("d_normal", C.c_void_p), ("d_conf", C.c_void_p)]
 
 
+class Cloud(C.Structure):
+    _fields_ = [("capacity", C.c_uint64), ("xyz", C.POINTER(C.c_float)), ("normal", C.POINTER(C.c_float)), ("bgr", C.POINTER(C.c_uint8)),
+                ("n_views", C.POINTER(C.c_uint32)), ("views_capacity", C.c_uint64), ("view_ids", C.POINTER(C.c_uint32)),
+                ("view_weights", C.POINTER(C.c_float)), ("n_points", C.c_uint64), ("n_depths", C.c_uint64), ("n_view_entries", C.c_uint64)]
+
+
 class HcmvsError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("hcmvs error %d: %s" % (code, msg))
@@ -51,7 +57,8 @@ SYMBOLS = ["hcmvs_default_params", "hcmvs_create", "hcmvs_destroy", "hcmvs_last_
            "hcmvs_get_view_gray",
            "hcmvs_get_gradient_map", "hcmvs_estimate", "hcmvs_estimate_device", "hcmvs_estimate_batch_device", "hcmvs_get_stats",
            "hcmvs_splat_init", "hcmvs_triangulate_init", "hcmvs_triangulate_points", "hcmvs_set_depthmap", "hcmvs_set_depthmap_device", "hcmvs_get_depthmap",
-           "hcmvs_set_neighbors", "hcmvs_filter", "hcmvs_set_fuse_order", "hcmvs_fuse"]
+           "hcmvs_set_neighbors", "hcmvs_filter", "hcmvs_set_fuse_order", "hcmvs_fuse", "hcmvs_fuse_cloud", "hcmvs_estimate_point_colors",
+           "hcmvs_estimate_point_normals"]
 
 
 def triangulate_points(w, h, K, R, Cc, points_xyz, avg_depth=0.0, add_corners=True):
@@ -118,6 +125,9 @@ def lib():
                                    u64p, u64p]
         L.hcmvs_fuse.argtypes = [vp, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint64,
                                  fp, fp, u8p, u32p, u64p, u64p]
+        L.hcmvs_fuse_cloud.argtypes = [vp, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Cloud)]
+        L.hcmvs_estimate_point_colors.argtypes = [vp, C.c_uint64, fp, u32p, u32p, u8p]
+        L.hcmvs_estimate_point_normals.argtypes = [vp, C.c_uint64, fp, u32p, u32p, C.c_int32, fp]
         _lib = L
     return _lib
 
@@ -315,3 +325,33 @@ class Context:
         k = npts.value
         return dict(xyz=xyz[:k], normal=None if nrm is None else nrm[:k], bgr=None if bgr is None else bgr[:k],
                     n_views=nv[:k], n_points=k, n_depths=nd.value)
+
+    def fuse_cloud(self, order, capacity, views_capacity, n_min_views_fuse=2, depth_diff_threshold=0.01, normal_diff_deg=25.0, depthweight=1.0,
+                   normalweight=1.0):
+        """hcmvs_fuse_cloud: the complete PointCloud (points, view lists + weights as CSR, colours, normals)"""
+        xyz = np.empty((capacity, 3), np.float32); nrm = np.empty((capacity, 3), np.float32); bgr = np.empty((capacity, 3), np.uint8)
+        nv = np.empty(capacity, np.uint32); vids = np.empty(max(views_capacity, 1), np.uint32); vwts = np.empty(max(views_capacity, 1), np.float32)
+        cl = Cloud()
+        cl.capacity = capacity; cl.xyz = _f(xyz); cl.normal = _f(nrm); cl.bgr = bgr.ctypes.data_as(C.POINTER(C.c_uint8))
+        cl.n_views = nv.ctypes.data_as(C.POINTER(C.c_uint32)); cl.views_capacity = views_capacity
+        cl.view_ids = vids.ctypes.data_as(C.POINTER(C.c_uint32)); cl.view_weights = _f(vwts)
+        ids = (C.c_uint32 * len(order))(*order)
+        self._chk(lib().hcmvs_fuse_cloud(self._h, ids, len(order), n_min_views_fuse, depth_diff_threshold, normal_diff_deg, depthweight, normalweight,
+                                         C.byref(cl)))
+        k, ne = cl.n_points, cl.n_view_entries
+        return dict(xyz=xyz[:k], normal=nrm[:k], bgr=bgr[:k], n_views=nv[:k], n_points=k, n_depths=cl.n_depths, view_ids=vids[:ne],
+                    view_weights=vwts[:ne])
+
+    def estimate_point_colors(self, xyz, n_views, view_ids):
+        x = np.ascontiguousarray(xyz, np.float32); nv = np.ascontiguousarray(n_views, np.uint32); vi = np.ascontiguousarray(view_ids, np.uint32)
+        out = np.empty((len(x), 3), np.uint8)
+        self._chk(lib().hcmvs_estimate_point_colors(self._h, len(x), _f(x), nv.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                    vi.ctypes.data_as(C.POINTER(C.c_uint32)), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def estimate_point_normals(self, xyz, n_views, view_ids, n_neighbors=16):
+        x = np.ascontiguousarray(xyz, np.float32); nv = np.ascontiguousarray(n_views, np.uint32); vi = np.ascontiguousarray(view_ids, np.uint32)
+        out = np.empty((len(x), 3), np.float32)
+        self._chk(lib().hcmvs_estimate_point_normals(self._h, len(x), _f(x), nv.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                     vi.ctypes.data_as(C.POINTER(C.c_uint32)), n_neighbors, _f(out)))
+        return out

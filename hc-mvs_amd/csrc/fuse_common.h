@@ -50,12 +50,14 @@ void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb
                        uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, hipStream_t s);
 void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, hipStream_t s);
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl,
-                      float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
+                      float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
                       int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, int blocks, hipStream_t s);
+void launch_point_colors(unsigned long long n, const float* xyz, const unsigned long long* voff, const uint32_t* views, const DevMap* maps, uint8_t* bgr, hipStream_t s);
 size_t fuse_scan_temp_bytes(int n);
 void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,
                          float* onormal, uint8_t* obgr, uint32_t* onv, unsigned long long base, unsigned long long capacity, float* xyz,
-                         float* normal, uint8_t* bgr, uint32_t* nviews, hipStream_t s);
+                         float* normal, uint8_t* bgr, uint32_t* nviews, uint32_t* oviews, float* oweights, int vstride, uint32_t* voff,
+                         unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights, hipStream_t s);
 
 } // namespace hcmvs
 #endif

@@ -283,6 +283,7 @@ __global__ void fuse_links_kernel(int nNb, FuseTables tb, const uint32_t* pendin
 
 struct FuseOut { // per pixel of the current image, compacted in raster order afterwards
 	float* xyz; float* normal; uint8_t* bgr; uint32_t* nviews; uint8_t* flag;
+	uint32_t* views; float* weights; int vstride; // optional: the point's view list (image ids ascending) and weights, vstride per pixel
 };
 struct FusePass {
 	FuseTables tb;
@@ -349,9 +350,10 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 			float point[3];
 			pixel_point(A, idx, depth, point);
 			// the reference's body, SceneDensify.cpp:3364-3450
-			uint32_t vimg[MAXV]; int vpix[MAXV]; int nv = 0;
+			uint32_t vimg[MAXV]; int vpix[MAXV]; float vwt[MAXV]; int nv = 0;
+			vwt[nv] = conf2weight(A.conf[idx], depth); // PointCloud::WeightArr (float), SceneDensify.cpp:3378
 			vimg[nv] = A.id; vpix[nv] = idx; ++nv;
-			double confidence = (double)conf2weight(A.conf[idx], depth);
+			double confidence = (double)vwt[0];
 			float normal[3] = {0.f, 0.f, -1.f};
 			if (A.normal) {
 				const float* nm = A.normal + 3 * (size_t)idx;
@@ -405,8 +407,8 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 						if (normal[0] * normalB[0] + normal[1] * normalB[1] + normal[2] * normalB[2] > fp.normalError) {
 							const float confB = conf2weight(cfB[j], depthB);
 							int pos = nv;
-							while (pos > 0 && vimg[pos - 1] > Bid) { vimg[pos] = vimg[pos - 1]; vpix[pos] = vpix[pos - 1]; --pos; }
-							vimg[pos] = Bid; vpix[pos] = ib; ++nv;
+							while (pos > 0 && vimg[pos - 1] > Bid) { vimg[pos] = vimg[pos - 1]; vpix[pos] = vpix[pos - 1]; vwt[pos] = vwt[pos - 1]; --pos; }
+							vimg[pos] = Bid; vpix[pos] = ib; vwt[pos] = confB; ++nv;
 							st_u32(&B.claim[ib], 0u);
 							double XB[3];
 							i2w(B, (double)xs[j], (double)ys[j], (double)depthB, XB);
@@ -436,6 +438,8 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 					out.normal[3 * (size_t)idx] = n0 / len; out.normal[3 * (size_t)idx + 1] = n1 / len; out.normal[3 * (size_t)idx + 2] = n2 / len;
 				}
 				out.nviews[idx] = (uint32_t)nv;
+				if (out.views)
+					for (int v = 0; v < nv; ++v) { out.views[(size_t)idx * out.vstride + v] = vimg[v]; out.weights[(size_t)idx * out.vstride + v] = vwt[v]; }
 				out.flag[idx] = 1;
 				++accepted;
 				for (int v = 0; v < ninv; ++v) st_f32(&maps[invImg[v]].depth[invPix[v]], 0.f);
@@ -467,11 +471,18 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 
 // ordered compaction of the accepted pixels of one pass into the cloud
 __global__ void fuse_gather_kernel(int n, const uint8_t* flag, const uint32_t* pos, FuseOut out, unsigned long long base,
-                                   unsigned long long capacity, float* xyz, float* normal, uint8_t* bgr, uint32_t* nviews) {
+                                   unsigned long long capacity, float* xyz, float* normal, uint8_t* bgr, uint32_t* nviews,
+                                   const uint32_t* voff, unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights) {
 	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
 		if (!flag[idx]) continue;
 		const unsigned long long o = base + pos[idx];
 		if (o >= capacity) continue;
+		if (cviews) {
+			const unsigned long long vo = viewBase + voff[idx];
+			const uint32_t nv = out.nviews[idx];
+			if (vo + nv <= viewCapacity)
+				for (uint32_t v = 0; v < nv; ++v) { cviews[vo + v] = out.views[(size_t)idx * out.vstride + v]; cweights[vo + v] = out.weights[(size_t)idx * out.vstride + v]; }
+		}
 		for (int k = 0; k < 3; ++k) xyz[3 * o + k] = out.xyz[3 * (size_t)idx + k];
 		if (normal) for (int k = 0; k < 3; ++k) normal[3 * o + k] = out.normal[3 * (size_t)idx + k];
 		if (bgr) for (int k = 0; k < 3; ++k) bgr[3 * o + k] = out.bgr[3 * (size_t)idx + k];
@@ -487,6 +498,50 @@ __global__ void fill_u64_kernel(unsigned long long* p, unsigned long long v, siz
 }
 __global__ void flag_to_u32_kernel(const uint8_t* f, uint32_t* o, int n) {
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] = f[i];
+}
+__global__ void flag_nviews_kernel(const uint8_t* f, const uint32_t* nv, uint32_t* o, int n) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] = f[i] ? nv[i] : 0u;
+}
+
+// MVS::EstimatePointColors (DepthMap.cpp:2125-2161): per point the colour of the closest of its views (smallest
+// Camera::PointDepth), sampled bilinearly the way TImage<Pixel8U>::sample does it -- every product and sum is truncated
+// back to 8 bits (Types.inl:2250-2258 over TPixel<uint8_t>::operator*, Types.h:1931) -- or white outside the image
+__global__ void point_colors_kernel(unsigned long long n, const float* xyz, const unsigned long long* voff, const uint32_t* views, const DevMap* maps, uint8_t* bgr) {
+	for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+		const float X[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+		double best = 3.402823466e+38; // FLT_MAX
+		int bestImg = -1;
+		for (unsigned long long v = voff[i]; v < voff[i + 1]; ++v) {
+			const DevMap& m = maps[views[v]];
+			if (!m.bgr) continue;
+			const double d = m.P[8] * (double)X[0] + m.P[9] * (double)X[1] + m.P[10] * (double)X[2] + m.P[11]; // Camera::PointDepth
+			if (best > d) { best = d; bestImg = (int)views[v]; }
+		}
+		uint8_t c[3] = {255, 255, 255};
+		if (bestImg >= 0) {
+			const DevMap& m = maps[bestImg];
+			const double* p = m.P;
+			const float qx = (float)(p[0] * X[0] + p[1] * X[1] + p[2] * X[2] + p[3]), qy = (float)(p[4] * X[0] + p[5] * X[1] + p[6] * X[2] + p[7]),
+			            qz = (float)(p[8] * X[0] + p[9] * X[1] + p[10] * X[2] + p[11]);
+			const float iz = 1.f / qz;
+			const float px = qx * iz, py = qy * iz;
+			if (px >= 1.f && py >= 1.f && px <= (float)(m.w - 2) && py <= (float)(m.h - 2)) { // isInsideWithBorder<float,1>
+				const int lx = (int)px, ly = (int)py;
+				const float x = px - (float)lx, x1 = 1.f - x, y = py - (float)ly, y1 = 1.f - y;
+				const uint8_t* r0 = m.bgr + 3 * ((size_t)ly * m.w + lx);
+				const uint8_t* r1 = r0 + 3 * (size_t)m.w;
+				for (int k = 0; k < 3; ++k) {
+					const uint8_t top = (uint8_t)(((uint8_t)((uint8_t)(x1 * (float)r0[k]) + (uint8_t)(x * (float)r0[3 + k]))) * y1);
+					const uint8_t bot = (uint8_t)(((uint8_t)((uint8_t)(x1 * (float)r1[k]) + (uint8_t)(x * (float)r1[3 + k]))) * y);
+					c[k] = (uint8_t)(top + bot);
+				}
+			}
+		}
+		bgr[3 * i] = c[0]; bgr[3 * i + 1] = c[1]; bgr[3 * i + 2] = c[2];
+	}
+}
+void launch_point_colors(unsigned long long n, const float* xyz, const unsigned long long* voff, const uint32_t* views, const DevMap* maps, uint8_t* bgr, hipStream_t s) {
+	hipLaunchKernelGGL(point_colors_kernel, dim3(2048), dim3(256), 0, s, n, xyz, voff, views, maps, bgr);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -526,9 +581,9 @@ void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_
 }
 // the whole image pass in one launch of dataflow workers (one wave per workgroup); any grid size is correct
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl,
-                      float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag,
+                      float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
                       int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, int blocks, hipStream_t s) {
-	FuseOut out{oxyz, onormal, obgr, onv, oflag};
+	FuseOut out{oxyz, onormal, obgr, onv, oflag, oviews, oweights, vstride};
 	FusePass fp;
 	fp.tb = tb; fp.queue = queue; fp.ctl = ctl;
 	fp.nMinViewsFuse = nMinViewsFuse; fp.thDepth = thDepth; fp.normalError = normalError;
@@ -542,11 +597,17 @@ size_t fuse_scan_temp_bytes(int n) {
 }
 void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,
                          float* onormal, uint8_t* obgr, uint32_t* onv, unsigned long long base, unsigned long long capacity, float* xyz,
-                         float* normal, uint8_t* bgr, uint32_t* nviews, hipStream_t s) {
+                         float* normal, uint8_t* bgr, uint32_t* nviews, uint32_t* oviews, float* oweights, int vstride, uint32_t* voff,
+                         unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights, hipStream_t s) {
 	hipLaunchKernelGGL(flag_to_u32_kernel, kGrid, kBlock, 0, s, flag, flag32, n);
 	(void)hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, flag32, pos, n, s);
-	FuseOut out{oxyz, onormal, obgr, onv, const_cast<uint8_t*>(flag)};
-	hipLaunchKernelGGL(fuse_gather_kernel, kGrid, kBlock, 0, s, n, flag, pos, out, base, capacity, xyz, normal, bgr, nviews);
+	if (cviews) { // offsets of the accepted pixels' view lists inside this image's part of the CSR arrays
+		hipLaunchKernelGGL(flag_nviews_kernel, kGrid, kBlock, 0, s, flag, onv, flag32, n);
+		(void)hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, flag32, voff, n, s);
+	}
+	FuseOut out{oxyz, onormal, obgr, onv, const_cast<uint8_t*>(flag), oviews, oweights, vstride};
+	hipLaunchKernelGGL(fuse_gather_kernel, kGrid, kBlock, 0, s, n, flag, pos, out, base, capacity, xyz, normal, bgr, nviews, voff, viewBase, viewCapacity,
+	                   cviews, cweights);
 }
 
 } // namespace hcmvs

@@ -10,6 +10,7 @@
 #include "pm_common.h"
 #include "fuse_common.h"
 #include "tri_init.h"
+#include "cloud_post.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -808,9 +809,15 @@ int hcmvs_set_fuse_order(hcmvs_ctx* c, int32_t mode) {
 	return HCMVS_OK;
 }
 
-int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
-               float normal_diff_deg, float depthweight, float normalweight, uint64_t capacity, float* xyz, float* normal,
-               uint8_t* bgr, uint32_t* n_views, uint64_t* n_points, uint64_t* n_depths) {
+int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
+                     float normal_diff_deg, float depthweight, float normalweight, hcmvs_cloud* cloud) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!cloud) return fail(c, HCMVS_ERR_INVALID, "fuse: null cloud");
+	const uint64_t capacity = cloud->capacity, viewCapacity = cloud->view_ids ? cloud->views_capacity : 0;
+	float* xyz = cloud->xyz; float* normal = cloud->normal; uint8_t* bgr = cloud->bgr; uint32_t* n_views = cloud->n_views;
+	uint64_t* n_points = &cloud->n_points; uint64_t* n_depths = &cloud->n_depths;
+	cloud->n_points = cloud->n_depths = cloud->n_view_entries = 0;
+	if (cloud->view_ids && !cloud->view_weights) return fail(c, HCMVS_ERR_INVALID, "fuse: view_ids without view_weights");
 	if (!c) return HCMVS_ERR_INVALID;
 	if (!order || n_order < 1 || !xyz || !n_points) return fail(c, HCMVS_ERR_INVALID, "fuse: bad arguments");
 	HIPCHK(c, hipSetDevice(c->device));
@@ -845,7 +852,10 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(64),
 	             oFlag = carve(maxArea), oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
 	             oXyz = carve(maxArea * 12), oNrm = carve(maxArea * 12), oBgr = carve(maxArea * 3), oNv = carve(maxArea * 4),
-	             oCX = carve(capacity * 12), oCN = carve(normal ? capacity * 12 : 0), oCB = carve(bgr ? capacity * 3 : 0), oCV = carve(n_views ? capacity * 4 : 0);
+	             oPV = carve(viewCapacity ? maxArea * 4 * (size_t)(maxNb + 1) : 0), oPW = carve(viewCapacity ? maxArea * 4 * (size_t)(maxNb + 1) : 0),
+	             oVoff = carve(viewCapacity ? maxArea * 4 : 0),
+	             oCX = carve(capacity * 12), oCN = carve(normal ? capacity * 12 : 0), oCB = carve(bgr ? capacity * 3 : 0), oCV = carve(n_views || viewCapacity ? capacity * 4 : 0),
+	             oCVI = carve(viewCapacity * 4), oCVW = carve(viewCapacity * 4);
 	rc = ensure_scratch(c, off);
 	if (rc) return rc;
 	char* b = (char*)c->fuseScratch;
@@ -858,7 +868,12 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos);
 	float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
 	float* cX = (float*)(b + oCX); float* cN = normal ? (float*)(b + oCN) : nullptr; uint8_t* cB = bgr ? (uint8_t*)(b + oCB) : nullptr;
-	uint32_t* cV = n_views ? (uint32_t*)(b + oCV) : nullptr;
+	uint32_t* cV = n_views || viewCapacity ? (uint32_t*)(b + oCV) : nullptr;
+	uint32_t* pviews = viewCapacity ? (uint32_t*)(b + oPV) : nullptr; float* pweights = viewCapacity ? (float*)(b + oPW) : nullptr;
+	uint32_t* voff = viewCapacity ? (uint32_t*)(b + oVoff) : nullptr;
+	uint32_t* cVI = viewCapacity ? (uint32_t*)(b + oCVI) : nullptr; float* cVW = viewCapacity ? (float*)(b + oCVW) : nullptr;
+	const int vstride = maxNb + 1;
+	unsigned long long viewTotal = 0;
 	const float normalError = cosf(normal_diff_deg * normalweight * (3.14159274101257324f / 180.f)); // SceneDensify.cpp:3310
 	const float thDepth = depth_diff_threshold * depthweight;                                       // SceneDensify.cpp:3400
 	// dataflow workers: one wave per workgroup, a few per CU; any number is correct (no co-residency assumption)
@@ -894,8 +909,8 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 			tb.nbrList = c->fuseLinks;
 		}
 		launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, s);
-		launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, n_min_views_fuse,
-		                 thDepth, normalError, c->counters, blocks, s);
+		launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
+		                 n_min_views_fuse, thDepth, normalError, c->counters, blocks, s);
 		unsigned long long cnt[4];
 		uint32_t ctlWords[5] = {0, 0, 0, 0, 0};
 		HIPCHK(c, hipMemcpyAsync(cnt, c->counters, 32, hipMemcpyDeviceToHost, s));
@@ -911,7 +926,18 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 		depths += cnt[0];
 		const unsigned long long accepted = cnt[3];
 		if (total + accepted > capacity) return fail(c, HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity);
-		if (accepted) launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, total, capacity, cX, cN, cB, cV, s);
+		if (accepted) {
+			launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, total, capacity, cX, cN, cB, cV, pviews, pweights, vstride,
+			                    voff, viewTotal, viewCapacity, cVI, cVW, s);
+			if (viewCapacity) { // this image's share of the view lists = last offset + last count
+				uint32_t lo = 0, ln = 0;
+				HIPCHK(c, hipMemcpyAsync(&lo, voff + (n - 1), 4, hipMemcpyDeviceToHost, s));
+				HIPCHK(c, hipMemcpyAsync(&ln, flag32 + (n - 1), 4, hipMemcpyDeviceToHost, s));
+				HIPCHK(c, hipStreamSynchronize(s));
+				viewTotal += (unsigned long long)lo + ln;
+				if (viewTotal > viewCapacity) return fail(c, HCMVS_ERR_CAPACITY, "fuse: view-list capacity %llu exceeded", (unsigned long long)viewCapacity);
+			}
+		}
 		total += accepted;
 	}
 	HIPCHK(c, hipGetLastError());
@@ -919,9 +945,73 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	if (normal) HIPCHK(c, hipMemcpyAsync(normal, cN, total * 12, hipMemcpyDeviceToHost, s));
 	if (bgr) HIPCHK(c, hipMemcpyAsync(bgr, cB, total * 3, hipMemcpyDeviceToHost, s));
 	if (n_views) HIPCHK(c, hipMemcpyAsync(n_views, cV, total * 4, hipMemcpyDeviceToHost, s));
+	if (viewCapacity) {
+		HIPCHK(c, hipMemcpyAsync(cloud->view_ids, cVI, viewTotal * 4, hipMemcpyDeviceToHost, s));
+		HIPCHK(c, hipMemcpyAsync(cloud->view_weights, cVW, viewTotal * 4, hipMemcpyDeviceToHost, s));
+	}
 	HIPCHK(c, hipStreamSynchronize(s));
 	*n_points = total;
 	if (n_depths) *n_depths = depths;
+	cloud->n_view_entries = viewTotal;
+	return HCMVS_OK;
+}
+
+int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
+               float normal_diff_deg, float depthweight, float normalweight, uint64_t capacity, float* xyz, float* normal,
+               uint8_t* bgr, uint32_t* n_views, uint64_t* n_points, uint64_t* n_depths) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!n_points) return fail(c, HCMVS_ERR_INVALID, "fuse: bad arguments");
+	hcmvs_cloud cl;
+	memset(&cl, 0, sizeof cl);
+	cl.capacity = capacity; cl.xyz = xyz; cl.normal = normal; cl.bgr = bgr; cl.n_views = n_views;
+	const int rc = hcmvs_fuse_cloud(c, order, n_order, n_min_views_fuse, depth_diff_threshold, normal_diff_deg, depthweight, normalweight, &cl);
+	*n_points = cl.n_points;
+	if (n_depths) *n_depths = cl.n_depths;
+	return rc;
+}
+
+int hcmvs_estimate_point_colors(hcmvs_ctx* c, uint64_t n, const float* xyz, const uint32_t* n_views, const uint32_t* view_ids, uint8_t* bgr) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!xyz || !n_views || !view_ids || !bgr) return fail(c, HCMVS_ERR_INVALID, "estimate_point_colors: null argument");
+	if (n == 0) return HCMVS_OK;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	std::vector<DevMap> host;
+	int rc = build_map_table(c, host);
+	if (rc) return rc;
+	std::vector<unsigned long long> off(n + 1, 0);
+	for (uint64_t i = 0; i < n; ++i) off[i + 1] = off[i] + n_views[i];
+	for (unsigned long long k = 0; k < off[n]; ++k)
+		if (view_ids[k] >= host.size() || !c->views.count(view_ids[k])) return fail(c, HCMVS_ERR_INVALID, "estimate_point_colors: unknown view %u", view_ids[k]);
+	float* dX = nullptr; unsigned long long* dOff = nullptr; uint32_t* dV = nullptr; uint8_t* dC = nullptr;
+	auto freeAll = [&]() { for (void* p : {(void*)dX, (void*)dOff, (void*)dV, (void*)dC}) if (p) (void)hipFree(p); };
+	if (hipMalloc(&dX, n * 12) != hipSuccess || hipMalloc(&dOff, (n + 1) * 8) != hipSuccess || hipMalloc(&dV, std::max<unsigned long long>(off[n], 1) * 4) != hipSuccess ||
+	    hipMalloc(&dC, n * 3) != hipSuccess) { freeAll(); return fail(c, HCMVS_ERR_HIP, "estimate_point_colors: out of device memory"); }
+	hipStream_t s = c->stream;
+	(void)hipMemcpyAsync(dX, xyz, n * 12, hipMemcpyHostToDevice, s);
+	(void)hipMemcpyAsync(dOff, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s);
+	(void)hipMemcpyAsync(dV, view_ids, off[n] * 4, hipMemcpyHostToDevice, s);
+	launch_point_colors(n, dX, dOff, dV, c->dMaps, dC, s);
+	const hipError_t e1 = hipMemcpyAsync(bgr, dC, n * 3, hipMemcpyDeviceToHost, s);
+	const hipError_t e2 = hipStreamSynchronize(s);
+	freeAll();
+	if (e1 != hipSuccess || e2 != hipSuccess || hipGetLastError() != hipSuccess) return fail(c, HCMVS_ERR_HIP, "estimate_point_colors: device failure");
+	return HCMVS_OK;
+}
+
+int hcmvs_estimate_point_normals(hcmvs_ctx* c, uint64_t n, const float* xyz, const uint32_t* n_views, const uint32_t* view_ids, int32_t k, float* normal) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!xyz || !n_views || !view_ids || !normal || k < 3) return fail(c, HCMVS_ERR_INVALID, "estimate_point_normals: bad arguments");
+	std::vector<double> firstC(3 * n);
+	unsigned long long off = 0;
+	for (uint64_t i = 0; i < n; ++i) {
+		if (n_views[i] < 1) return fail(c, HCMVS_ERR_INVALID, "estimate_point_normals: point %llu has no view", (unsigned long long)i);
+		auto it = c->views.find(view_ids[off]);
+		if (it == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "estimate_point_normals: unknown view %u", view_ids[off]);
+		for (int q = 0; q < 3; ++q) firstC[3 * i + q] = it->second.C[q];
+		off += n_views[i];
+	}
+	hcmvs::pca_normals(n, xyz, firstC.data(), k, normal);
 	return HCMVS_OK;
 }
 

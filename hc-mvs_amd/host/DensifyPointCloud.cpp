@@ -125,7 +125,8 @@ struct Writer {
 	void str(const std::string& s) { put<uint64_t>(s.size()); f.write(s.data(), (std::streamsize)s.size()); }
 };
 bool save_mvs(const std::string& path, const std::vector<MvsPlatform>& platforms, const std::vector<MvsImage>& images,
-              const std::vector<float>& xyz, const std::vector<float>& normals, const std::vector<uint8_t>& bgr) {
+              const std::vector<float>& xyz, const std::vector<float>& normals, const std::vector<uint8_t>& bgr,
+              const std::vector<uint32_t>& nviews, const std::vector<uint32_t>& viewIds, const std::vector<float>& viewWeights) {
 	Writer w;
 	w.f.open(path, std::ios::binary);
 	if (!w.f) return false;
@@ -146,7 +147,14 @@ bool save_mvs(const std::string& path, const std::vector<MvsPlatform>& platforms
 	for (const auto& im : images) { w.str(im.name); w.str(""); w.put(im.platformID); w.put(im.cameraID); w.put(im.poseID); w.put(im.ID); }
 	const uint64_t n = xyz.size() / 3;
 	w.put<uint64_t>(n);
-	for (uint64_t i = 0; i < n; ++i) { w.f.write((const char*)&xyz[3 * i], 12); w.put<uint64_t>(0); }
+	uint64_t vo = 0;
+	for (uint64_t i = 0; i < n; ++i) { // Interface::Vertex = X + views {imageID, confidence} (Interface.h:502-524; Scene.cpp:330-345 stores the weights as confidence)
+		w.f.write((const char*)&xyz[3 * i], 12);
+		const uint64_t nv = i < nviews.size() ? nviews[i] : 0;
+		w.put<uint64_t>(nv);
+		for (uint64_t v = 0; v < nv; ++v) { w.put<uint32_t>(viewIds[vo + v]); w.put<float>(viewWeights[vo + v]); }
+		vo += nv;
+	}
 	w.put<uint64_t>(normals.size() / 3); w.f.write((const char*)normals.data(), (std::streamsize)normals.size() * 4);
 	w.put<uint64_t>(bgr.size() / 3); w.f.write((const char*)bgr.data(), (std::streamsize)bgr.size());
 	for (int i = 0; i < 3; ++i) w.put<uint64_t>(0);
@@ -305,12 +313,15 @@ bool save_ply(const std::string& path, const std::vector<float>& xyz, const std:
 	std::ofstream f(path, std::ios::binary); // PointCloud.cpp:189-240
 	if (!f) return false;
 	const size_t n = xyz.size() / 3;
-	f << "ply\nformat binary_little_endian 1.0\nelement vertex " << n << "\nproperty float x\nproperty float y\nproperty float z\n"
-	  << "property float nx\nproperty float ny\nproperty float nz\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n";
+	const bool hasN = nrm.size() == xyz.size() && n > 0, hasC = bgr.size() == xyz.size() && n > 0; // PointCloud.cpp:105-128: only what exists
+	f << "ply\nformat binary_little_endian 1.0\nelement vertex " << n << "\nproperty float x\nproperty float y\nproperty float z\n";
+	if (hasN) f << "property float nx\nproperty float ny\nproperty float nz\n";
+	if (hasC) f << "property uchar red\nproperty uchar green\nproperty uchar blue\n";
+	f << "end_header\n";
 	for (size_t i = 0; i < n; ++i) {
-		f.write((const char*)&xyz[3 * i], 12); f.write((const char*)&nrm[3 * i], 12);
-		const uint8_t rgb[3] = {bgr[3 * i + 2], bgr[3 * i + 1], bgr[3 * i]};
-		f.write((const char*)rgb, 3);
+		f.write((const char*)&xyz[3 * i], 12);
+		if (hasN) f.write((const char*)&nrm[3 * i], 12);
+		if (hasC) { const uint8_t rgb[3] = {bgr[3 * i + 2], bgr[3 * i + 1], bgr[3 * i]}; f.write((const char*)rgb, 3); }
 	}
 	return (bool)f;
 }
@@ -653,19 +664,35 @@ int main(int argc, char** argv) {
 	// fuse: best connected images first (SceneDensify.cpp:3285-3302)
 	std::vector<uint32_t> order(todo);
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return images[a].neighbors.size() > images[b].neighbors.size(); });
+	// the complete PointCloud: points, view lists + weights (PointCloud::pointViews / pointWeights), colours, normals
+	uint64_t viewCapacity = 0;
+	for (uint32_t id : todo) viewCapacity += (uint64_t)images[id].w * images[id].h; // a point merges at most one depth per image
 	std::vector<float> xyz(capacity * 3), nrm(capacity * 3); std::vector<uint8_t> bgr(capacity * 3); std::vector<uint32_t> nviews(capacity);
+	std::vector<uint32_t> viewIds(viewCapacity); std::vector<float> viewWeights(viewCapacity);
 	uint64_t nPoints = 0, nDepths = 0;
 	CHK(hcmvs_set_fuse_order(ctx, o.fuseOrder));
-	CHK(hcmvs_fuse(ctx, order.data(), (int32_t)order.size(), std::min<int>(o.numberViewsFuse, (int)images.size()), 0.01f, 25.f, o.depthweight,
-	               o.normalweight, capacity, xyz.data(), nrm.data(), bgr.data(), nviews.data(), &nPoints, &nDepths));
-	xyz.resize(nPoints * 3); nrm.resize(nPoints * 3); bgr.resize(nPoints * 3);
+	hcmvs_cloud cl;
+	memset(&cl, 0, sizeof cl);
+	cl.capacity = capacity; cl.xyz = xyz.data(); cl.normal = nrm.data(); cl.bgr = bgr.data(); cl.n_views = nviews.data();
+	cl.views_capacity = viewCapacity; cl.view_ids = viewIds.data(); cl.view_weights = viewWeights.data();
+	CHK(hcmvs_fuse_cloud(ctx, order.data(), (int32_t)order.size(), std::min<int>(o.numberViewsFuse, (int)images.size()), 0.01f, 25.f, o.depthweight,
+	                     o.normalweight, &cl));
+	nPoints = cl.n_points; nDepths = cl.n_depths;
+	xyz.resize(nPoints * 3); nrm.resize(nPoints * 3); bgr.resize(nPoints * 3); nviews.resize(nPoints);
+	viewIds.resize(cl.n_view_entries); viewWeights.resize(cl.n_view_entries);
+	// --estimate-colors / --estimate-normals: 2 = estimated during fusion (above), 1 = re-estimated on the final cloud
+	// (SceneDensify.cpp:3544, 3567-3572), 0 = none
+	if (o.estimateColors == 1) CHK(hcmvs_estimate_point_colors(ctx, nPoints, xyz.data(), nviews.data(), viewIds.data(), bgr.data()));
+	if (o.estimateNormals == 1) CHK(hcmvs_estimate_point_normals(ctx, nPoints, xyz.data(), nviews.data(), viewIds.data(), 16, nrm.data()));
+	if (o.estimateColors == 0) bgr.clear();
+	if (o.estimateNormals == 0) nrm.clear();
 	const double tFused = now_s();
 	if (o.verbosity > 1)
 		printf("Depth-maps fused and filtered: %zu depth-maps, %llu depths, %llu points (%d%%) in %.2f s (%.2f Mpoints/s)\n", order.size(),
 		       (unsigned long long)nDepths, (unsigned long long)nPoints, nDepths ? (int)std::lround(100.0 * nPoints / nDepths) : 0, tFused - tSaved,
 		       nPoints / (tFused - tSaved) / 1e6);
 	const std::string base = o.output.substr(0, o.output.rfind('.'));
-	if (!save_mvs(o.output, platforms, mimages, xyz, nrm, bgr) || !save_ply(base + ".ply", xyz, nrm, bgr)) {
+	if (!save_mvs(o.output, platforms, mimages, xyz, nrm, bgr, nviews, viewIds, viewWeights) || !save_ply(base + ".ply", xyz, nrm, bgr)) {
 		fprintf(stderr, "error: can not write the output files\n");
 		return EXIT_FAILURE;
 	}

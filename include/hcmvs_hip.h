@@ -201,6 +201,36 @@ int hcmvs_fuse(hcmvs_ctx* ctx, const uint32_t* order, int32_t n_order, int32_t n
                uint64_t capacity, float* xyz, float* normal_or_null, uint8_t* bgr_or_null, uint32_t* n_views_or_null,
                uint64_t* n_points, uint64_t* n_depths);
 
+/* The fused cloud with everything PointCloud holds (PointCloud.h: points, pointViews, pointWeights, colors, normals).
+ * Host buffers owned by the caller; any optional pointer may be NULL.  The view lists are stored back to back (CSR): point p's
+ * n_views[p] entries follow those of point p-1, image ids ascending like PointCloud::ViewArr (SceneDensify.cpp:3376-3379,
+ * 3408-3411); a point merges at most one depth per image, so views_capacity = the number of valid depths is always enough. */
+typedef struct {
+	uint64_t capacity;        /* in: room for this many points */
+	float* xyz;               /* capacity * 3 */
+	float* normal;            /* capacity * 3 or NULL */
+	uint8_t* bgr;             /* capacity * 3 (B,G,R) or NULL */
+	uint32_t* n_views;        /* capacity or NULL */
+	uint64_t views_capacity;  /* in: room for this many view entries (0 with NULL lists) */
+	uint32_t* view_ids;       /* views_capacity or NULL */
+	float* view_weights;      /* views_capacity or NULL: Conf2Weight of the merged estimates (SceneDensify.cpp:154-156) */
+	uint64_t n_points, n_depths, n_view_entries; /* out */
+} hcmvs_cloud;
+/* hcmvs_fuse with the complete cloud */
+int hcmvs_fuse_cloud(hcmvs_ctx* ctx, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
+                     float normal_diff_deg, float depthweight, float normalweight, hcmvs_cloud* cloud);
+
+/* MVS::EstimatePointColors (DepthMap.cpp:2125-2161; --estimate-colors 1): per point the colour of the closest of its views,
+ * sampled bilinearly from that view's colour image (white when it projects outside).  Views must have been registered with a
+ * colour image.  Host arrays: xyz n*3, n_views n, view_ids (CSR as in hcmvs_cloud), out bgr n*3. */
+int hcmvs_estimate_point_colors(hcmvs_ctx* ctx, uint64_t n_points, const float* xyz, const uint32_t* n_views, const uint32_t* view_ids,
+                                uint8_t* bgr);
+/* MVS::EstimatePointNormals (DepthMap.cpp:2221-2269; --estimate-normals 1): normal of the plane fitted by PCA to the
+ * n_neighbors nearest points of every point (the reference calls CGAL::pca_estimate_normals with 16), oriented towards the first
+ * view of the point.  Host-side helper (no device work); CGAL is absent, so the PCA is restated (parity unpinned). */
+int hcmvs_estimate_point_normals(hcmvs_ctx* ctx, uint64_t n_points, const float* xyz, const uint32_t* n_views, const uint32_t* view_ids,
+                                 int32_t n_neighbors, float* normal);
+
 #ifdef __cplusplus
 }
 #endif

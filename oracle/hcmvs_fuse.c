@@ -11,6 +11,7 @@
  */
 #include "hcmvs_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -183,7 +184,7 @@ int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, 
 	}
 	const float normalError = cosf(fNormalDiffDeg * normalweight * ((float)3.1415926535897932384626433832795 / 180.f));
 	const float thDepth = fDepthDiffThreshold * depthweight;
-	cloud->n_points = 0; cloud->n_depths = 0;
+	cloud->n_points = 0; cloud->n_depths = 0; cloud->n_view_entries = 0;
 	int rc = 0;
 	for (int oi = 0; oi < n_order && !rc; ++oi) {
 		const uint32_t A = order[oi];
@@ -202,9 +203,10 @@ int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, 
 				double Xw[3];
 				i2w(dA, (double)j, (double)i, (double)depth, Xw);
 				const float point[3] = {(float)Xw[0], (float)Xw[1], (float)Xw[2]};
-				uint32_t views[FUSE_MAX_VIEWS]; size_t vpix[FUSE_MAX_VIEWS]; int nv = 0;
+				uint32_t views[FUSE_MAX_VIEWS]; size_t vpix[FUSE_MAX_VIEWS]; float vwt[FUSE_MAX_VIEWS]; int nv = 0;
+				vwt[nv] = conf2weight(dA->conf[idx], depth); /* weights.emplace_back(Conf2Weight(...)), SD.cpp:3378 */
 				views[nv] = A; vpix[nv] = idx; ++nv;
-				double confidence = (double)conf2weight(dA->conf[idx], depth);
+				double confidence = (double)vwt[0];
 				float normal[3] = {0, 0, -1};
 				if (dA->normal) {
 					const float* nm = dA->normal + 3 * idx;
@@ -240,8 +242,8 @@ int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, 
 							const float confB = conf2weight(dB->conf[ib], *depthB);
 							/* views.InsertSort(idxImageB): keep the list sorted by image id */
 							int pos = nv;
-							while (pos > 0 && views[pos - 1] > B) { views[pos] = views[pos - 1]; vpix[pos] = vpix[pos - 1]; --pos; }
-							views[pos] = B; vpix[pos] = ib; ++nv;
+							while (pos > 0 && views[pos - 1] > B) { views[pos] = views[pos - 1]; vpix[pos] = vpix[pos - 1]; vwt[pos] = vwt[pos - 1]; --pos; }
+							views[pos] = B; vpix[pos] = ib; vwt[pos] = confB; ++nv; /* weights.InsertAt(idx, confidenceB), SD.cpp:3410 */
 							claim[B][ib] = idPoint;
 							double XB[3];
 							i2w(dB, (double)xB, (double)yB, (double)*depthB, XB);
@@ -271,6 +273,12 @@ int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, 
 						on[0] = n0 / len; on[1] = n1 / len; on[2] = n2 / len;
 					}
 					if (cloud->n_views) cloud->n_views[cloud->n_points] = (uint32_t)nv;
+					if (cloud->view_ids && cloud->n_view_entries + (uint64_t)nv <= cloud->views_capacity)
+						for (int v = 0; v < nv; ++v) {
+							cloud->view_ids[cloud->n_view_entries + v] = views[v];
+							if (cloud->view_weights) cloud->view_weights[cloud->n_view_entries + v] = vwt[v];
+						}
+					cloud->n_view_entries += (uint64_t)nv;
 					++cloud->n_points;
 					for (int v = 0; v < ninv; ++v) *invalid[v] = 0; /* SD.cpp:3447-3449 */
 				}
@@ -279,4 +287,48 @@ int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, 
 	for (int m = 0; m < n_maps; ++m) free(claim[m]);
 	free(claim); free(P);
 	return rc;
+}
+
+/* MVS::EstimatePointColors, DM.cpp:2125-2161 */
+void hcor_estimate_point_colors(const hcor_depthmap* maps, int n_maps, uint64_t n_points, const float* xyz, const uint32_t* n_views,
+                                const uint32_t* view_ids, uint8_t* bgr) {
+	uint64_t off = 0;
+	for (uint64_t i = 0; i < n_points; ++i) {
+		const float* X = xyz + 3 * i;
+		double best = FLT_MAX;
+		int img = -1;
+		double Pb[12];
+		for (uint32_t v = 0; v < n_views[i]; ++v) {
+			const uint32_t id = view_ids[off + v];
+			if ((int)id >= n_maps || !maps[id].bgr) continue;
+			const hcor_depthmap* m = &maps[id];
+			double t[3], P[12];
+			for (int r = 0; r < 3; ++r) t[r] = -(m->R[r * 3] * m->C[0] + m->R[r * 3 + 1] * m->C[1] + m->R[r * 3 + 2] * m->C[2]);
+			for (int r = 0; r < 3; ++r) {
+				for (int c = 0; c < 3; ++c) P[r * 4 + c] = m->K[r * 3] * m->R[c] + m->K[r * 3 + 1] * m->R[3 + c] + m->K[r * 3 + 2] * m->R[6 + c];
+				P[r * 4 + 3] = m->K[r * 3] * t[0] + m->K[r * 3 + 1] * t[1] + m->K[r * 3 + 2] * t[2];
+			}
+			const double d = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11]; /* Camera::PointDepth */
+			if (best > d) { best = d; img = (int)id; memcpy(Pb, P, sizeof Pb); }
+		}
+		off += n_views[i];
+		uint8_t* c = bgr + 3 * i;
+		c[0] = c[1] = c[2] = 255; /* Pixel8U::WHITE */
+		if (img < 0) continue;
+		const hcor_depthmap* m = &maps[img];
+		const float qx = (float)(Pb[0] * X[0] + Pb[1] * X[1] + Pb[2] * X[2] + Pb[3]), qy = (float)(Pb[4] * X[0] + Pb[5] * X[1] + Pb[6] * X[2] + Pb[7]),
+		            qz = (float)(Pb[8] * X[0] + Pb[9] * X[1] + Pb[10] * X[2] + Pb[11]);
+		const float invZ = 1.f / qz;
+		const float px = qx * invZ, py = qy * invZ;
+		if (!(px >= 1.f && py >= 1.f && px <= (float)(m->width - 2) && py <= (float)(m->height - 2))) continue;
+		const int lx = (int)px, ly = (int)py;
+		const float x = px - lx, x1 = 1.f - x, y = py - ly, y1 = 1.f - y;
+		const uint8_t* r0 = m->bgr + 3 * ((size_t)ly * m->width + lx);
+		const uint8_t* r1 = r0 + 3 * (size_t)m->width;
+		for (int k = 0; k < 3; ++k) { /* (p00*x1 + p01*x)*y1 + (p10*x1 + p11*x)*y over TPixel<uint8_t> */
+			const uint8_t a = (uint8_t)((uint8_t)(x1 * r0[k]) + (uint8_t)(x * r0[3 + k]));
+			const uint8_t b = (uint8_t)((uint8_t)(x1 * r1[k]) + (uint8_t)(x * r1[3 + k]));
+			c[k] = (uint8_t)((uint8_t)(a * y1) + (uint8_t)(b * y));
+		}
+	}
 }

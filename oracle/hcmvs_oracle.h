@@ -176,7 +176,16 @@ typedef struct {
 	uint8_t* bgr;     /* capacity*3 or NULL (stored B,G,R like Interface.h:369) */
 	uint32_t* n_views;/* capacity: number of views merged into each point */
 	uint64_t n_depths;/* valid depths visited (SD.cpp:3359) */
+	/* optional: PointCloud::pointViews / pointWeights stored back to back (point p's n_views[p] entries follow those of p-1) */
+	uint64_t views_capacity, n_view_entries;
+	uint32_t* view_ids;
+	float* view_weights;
 } hcor_cloud;
+
+/* MVS::EstimatePointColors (DM.cpp:2125-2161): colour of the closest view of each point, bilinear over 8-bit pixels with every
+ * product and sum truncated to 8 bits (Types.inl:2250-2258, Types.h:1931), white outside.  views: CSR like hcor_cloud */
+void hcor_estimate_point_colors(const hcor_depthmap* maps, int n_maps, uint64_t n_points, const float* xyz, const uint32_t* n_views,
+                                const uint32_t* view_ids, uint8_t* bgr);
 
 /* SD.cpp:3265-3495 FuseDepthMaps.  order: image ids sorted by #neighbours descending (SD.cpp:3302;
  * ties broken by ascending id here -- std::sort leaves them unspecified).  returns 0 ok, 1 = capacity */

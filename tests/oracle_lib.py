@@ -37,7 +37,8 @@ class DepthMap(C.Structure):
 class Cloud(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("capacity", C.c_uint64), ("xyz", C.POINTER(C.c_float)),
                 ("normal", C.POINTER(C.c_float)), ("bgr", C.POINTER(C.c_uint8)), ("n_views", C.POINTER(C.c_uint32)),
-                ("n_depths", C.c_uint64)]
+                ("n_depths", C.c_uint64), ("views_capacity", C.c_uint64), ("n_view_entries", C.c_uint64),
+                ("view_ids", C.POINTER(C.c_uint32)), ("view_weights", C.POINTER(C.c_float))]
 
 
 _lib = None
@@ -99,6 +100,8 @@ def lib():
         L.hcor_fuse_depthmaps.argtypes = [C.POINTER(DepthMap), C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int,
                                           C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Cloud)]
         L.hcor_fuse_depthmaps.restype = C.c_int
+        L.hcor_estimate_point_colors.argtypes = [C.POINTER(DepthMap), C.c_int, C.c_uint64, fp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p]
+        L.hcor_estimate_point_colors.restype = None
     return _lib
 
 
@@ -225,9 +228,23 @@ def fuse_depthmaps(maps, order, capacity, n_min_views_fuse=2, thr=0.01, normal_d
     bgr = np.zeros((capacity, 3), np.uint8); nv = np.zeros(capacity, np.uint32)
     cl = Cloud(); cl.capacity = capacity; cl.xyz = fptr(xyz); cl.normal = fptr(nrm); cl.bgr = u8ptr(bgr)
     cl.n_views = nv.ctypes.data_as(C.POINTER(C.c_uint32))
+    vcap = int(sum(int((np.asarray(m["depth"]) != 0).sum()) for m in maps))
+    vids = np.zeros(max(vcap, 1), np.uint32); vwts = np.zeros(max(vcap, 1), np.float32)
+    cl.views_capacity = vcap; cl.view_ids = vids.ctypes.data_as(C.POINTER(C.c_uint32)); cl.view_weights = fptr(vwts)
     ids = (C.c_uint32 * len(order))(*order)
     rc = lib().hcor_fuse_depthmaps(arr, len(maps), ids, len(order), n_min_views_fuse, thr, normal_deg, depthweight,
                                    normalweight, C.byref(cl))
     assert rc == 0
     k = cl.n_points
-    return dict(xyz=xyz[:k], normal=nrm[:k], bgr=bgr[:k], n_views=nv[:k], n_points=k, n_depths=cl.n_depths, depths=depths)
+    ne = cl.n_view_entries
+    return dict(xyz=xyz[:k], normal=nrm[:k], bgr=bgr[:k], n_views=nv[:k], n_points=k, n_depths=cl.n_depths, depths=depths,
+                view_ids=vids[:ne], view_weights=vwts[:ne])
+
+
+def estimate_point_colors(maps, xyz, n_views, view_ids):
+    arr, _ = make_depthmaps(maps)
+    x = np.ascontiguousarray(xyz, np.float32); nv = np.ascontiguousarray(n_views, np.uint32); vi = np.ascontiguousarray(view_ids, np.uint32)
+    out = np.zeros((len(x), 3), np.uint8)
+    lib().hcor_estimate_point_colors(arr, len(maps), len(x), fptr(x), nv.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                     vi.ctypes.data_as(C.POINTER(C.c_uint32)), u8ptr(out))
+    return out

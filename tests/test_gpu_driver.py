@@ -212,3 +212,39 @@ def test_densify_driver_rescales_mismatched_neighbours(tmp_path):
         # (and at 1.7x the distance with the same small baselines 1 % of depth is a 3x tighter bar in disparity)
         rel = np.abs(dm["depth"] - gt)[m] / gt[m]
         assert m.mean() > (0.3 if i == far else 0.5) and (rel < 0.01).mean() > (0.6 if i == far else 0.8)
+
+
+@pytest.mark.gpu
+def test_densify_driver_cloud_attributes_and_strict_cli(tmp_path):
+    """--estimate-colors / --estimate-normals 0|1|2 (DensifyPointCloud.cpp:150-151, SceneDensify.cpp:3544, 3567-3572), the view
+    lists of the fused points in the output scene (Interface.h:502-524), and the option parser: unknown options are errors,
+    negative numbers are values"""
+    tmp = str(tmp_path)
+    scene, views = make_scene(tmp, w=256, h=192, n_views=4)
+    common = ["-i", scene, "--resolution-level", "0", "--number-views", "3", "--n-EstimationIters", "2", "--n-EstimationIters-external", "1",
+              "--n-photometric_flow", "0", "--fuse-order", "0"]
+    out2 = os.path.join(tmp, "d2.mvs"); out1 = os.path.join(tmp, "d1.mvs"); out0 = os.path.join(tmp, "d0.mvs")
+    for out, c, n in ((out2, "2", "2"), (out1, "1", "1"), (out0, "0", "0")):
+        r = subprocess.run([EXE] + common + ["-o", out, "--estimate-colors", c, "--estimate-normals", n], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+    p2, p1, p0 = (mvsio.read_ply(o[:-4] + ".ply") for o in (out2, out1, out0))
+    assert len(p2) == len(p1) == len(p0) > 5000
+    assert np.array_equal(p2["x"], p1["x"]) and np.array_equal(p2["x"], p0["x"])             # the same points
+    assert "nx" in p2.dtype.names and "red" in p2.dtype.names and "nx" in p1.dtype.names
+    assert "nx" not in p0.dtype.names and "red" not in p0.dtype.names                         # PLY holds only what exists (PointCloud.cpp:105-128)
+    n2 = np.stack([p2["nx"], p2["ny"], p2["nz"]], -1); n1 = np.stack([p1["nx"], p1["ny"], p1["nz"]], -1)
+    assert ((n2 * n1).sum(1) > 0.7).mean() > 0.7                                              # PCA normals ~ fused normals
+    assert np.abs(p2["red"].astype(int) - p1["red"].astype(int)).mean() < 10                  # closest-view colours ~ fused colours
+    dense = mvsio.read_mvs(out2)
+    vs = dense["vertices"]
+    assert len(vs) == len(p2) and all(len(v["views"]) >= 2 for v in vs[:200])                 # number-views-fuse 2
+    assert all(v["views"][k][0] < v["views"][k + 1][0] for v in vs[:200] for k in range(len(v["views"]) - 1))
+    # strict option parsing
+    r = subprocess.run([EXE] + common + ["--no-such-option", "1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "unrecognised option" in r.stderr
+    r = subprocess.run([EXE] + common + ["--fusion-mode", "-1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "SGM" in r.stderr                                            # -1 is a value, not a flag
+    r = subprocess.run([EXE] + common + ["--number-views-fuse"], capture_output=True, text=True)
+    assert r.returncode != 0 and "missing" in r.stderr
+    r = subprocess.run([EXE] + common + ["-o", out0, "--number-views-fuse", "1", "--fusion-mode=0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr                                             # every depth may become a point: no capacity error

@@ -109,3 +109,48 @@ def test_fuse_hashed_order_within_tolerance(ctx, kw):
     assert (d < 2e-3 * scale).mean() > 0.97
     with pytest.raises(binding.HcmvsError):
         ctx.set_fuse_order(2)
+
+
+def test_fuse_cloud_views_weights_colors_normals(ctx):
+    """the complete PointCloud (SURVEY.md 8f row F2): view lists + weights of every fused point (PointCloud::pointViews /
+    pointWeights, SceneDensify.cpp:3376-3411) bit-exact against the oracle; MVS::EstimatePointColors (DepthMap.cpp:2125-2161)
+    bit-exact; MVS::EstimatePointNormals (DepthMap.cpp:2221-2269, CGAL PCA over 16 neighbours -- restated, parity unpinned)
+    against a brute-force numpy PCA"""
+    maps, order = make_maps(w=144, h=112, f=130.0, n_views=6, noise=0.002, outliers=0.03, holes=0.05)
+    upload(ctx, maps)
+    want = O.fuse_depthmaps(maps, order, 200000)
+    vcap = int(sum((m["depth"] != 0).sum() for m in maps))
+    got = ctx.fuse_cloud(order, 200000, vcap)
+    assert got["n_points"] == want["n_points"] > 1000
+    assert np.array_equal(got["xyz"], want["xyz"]) and np.array_equal(got["n_views"], want["n_views"])
+    assert np.array_equal(got["view_ids"], want["view_ids"]) and np.array_equal(got["view_weights"], want["view_weights"])
+    assert len(got["view_ids"]) == int(got["n_views"].sum())
+    off = np.concatenate([[0], np.cumsum(got["n_views"].astype(np.int64))]).astype(np.int64)
+    for p in (0, 17, got["n_points"] - 1):                      # ascending image ids inside a point's list
+        v = got["view_ids"][off[p]:off[p + 1]]
+        assert (np.diff(v.astype(np.int64)) > 0).all()
+    # colours from the closest view
+    gc = ctx.estimate_point_colors(got["xyz"], got["n_views"], got["view_ids"])
+    wc = O.estimate_point_colors(maps, want["xyz"], want["n_views"], want["view_ids"])
+    assert np.array_equal(gc, wc)
+    assert (gc != 255).any() and np.abs(gc.astype(int) - got["bgr"].astype(int)).mean() < 12   # close to the fusion-time colours
+    # normals by PCA over the 16 nearest points, flipped towards the first view
+    gn = ctx.estimate_point_normals(got["xyz"], got["n_views"], got["view_ids"], 16)
+    from scipy.spatial import cKDTree
+    X = got["xyz"].astype(np.float64)
+    _, nn = cKDTree(X).query(X, k=16)
+    sub = np.arange(0, len(X), 7)
+    Pn = X[nn[sub]]
+    Pc = Pn - Pn.mean(1, keepdims=True)
+    w, v = np.linalg.eigh(np.einsum("nki,nkj->nij", Pc, Pc))
+    ref = v[:, :, 0]
+    first = got["view_ids"][off[:-1]][sub]
+    Cs = np.stack([maps[i]["C"] for i in first])
+    flip = ((Cs - X[sub]) * ref).sum(1) < 0
+    ref[flip] *= -1
+    cosang = np.abs((gn[sub] * ref).sum(1))
+    well = (w[:, 1] > 50 * np.maximum(w[:, 0], 1e-30))          # a clear plane: the smallest eigenvalue is well separated
+    assert well.mean() > 0.5 and (cosang[well] > 1 - 1e-6).mean() > 0.99
+    assert ((gn[sub] * ref).sum(1)[well] > 0).mean() > 0.999    # same orientation
+    assert np.abs(np.linalg.norm(gn, axis=1) - 1).max() < 1e-5
+    assert ((gn * got["normal"]).sum(1) > 0.8).mean() > 0.7     # and they agree with the normals fusion averaged
