@@ -34,7 +34,7 @@ class Stats(C.Structure):
 class BatchItem(C.Structure):
     _fields_ = [("ref_id", C.c_uint32), ("src_ids", C.POINTER(C.c_uint32)), ("n_src", C.c_int32),
                 ("seed_offset", C.c_uint32), ("d_min", C.c_float), ("d_max", C.c_float), ("d_depth", C.c_void_p),
-                ("d_normal", C.c_void_p), ("d_conf", C.c_void_p)]
+                ("d_normal", C.c_void_p), ("d_conf", C.c_void_p), ("d_hint_depth", C.c_void_p), ("d_hint_normal", C.c_void_p)]
 
 
 class Cloud(C.Structure):
@@ -266,6 +266,7 @@ class Context:
             arr[i].ref_id = it["ref_id"]; arr[i].src_ids = ids; arr[i].n_src = len(it["src_ids"])
             arr[i].seed_offset = it.get("seed_offset", 0); arr[i].d_min = it["d_min"]; arr[i].d_max = it["d_max"]
             arr[i].d_depth = it["d_depth"]; arr[i].d_normal = it["d_normal"]; arr[i].d_conf = it["d_conf"]
+            arr[i].d_hint_depth = it.get("d_hint_depth"); arr[i].d_hint_normal = it.get("d_hint_normal")
         self._chk(lib().hcmvs_estimate_batch_device(self._h, arr, len(items), C.byref(params)))
 
     def stats(self):

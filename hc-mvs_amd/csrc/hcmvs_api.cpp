@@ -480,6 +480,10 @@ static int build_item(hcmvs_ctx* c, int slot, const hcmvs_batch_item& it, const 
 	k.pfScale = 1.f - p->photometric_flow;
 	k.seed = p->seed + it.seed_offset;
 	k.dn = c->slots[slot].dn; k.conf = c->slots[slot].conf; k.progress = c->slots[slot].progress;
+	k.hintDepth = nullptr; k.hintNormal = nullptr; k.hintIter = -1;
+	if (it.d_hint_depth && it.d_hint_normal && p->it_external == p->n_external_iters - 1) { // restore/libs/MVS/DepthMap.cpp:1527
+		k.hintDepth = it.d_hint_depth; k.hintNormal = it.d_hint_normal; k.hintIter = p->n_estimation_iters - 1;
+	}
 	return HCMVS_OK;
 }
 

@@ -49,6 +49,11 @@ struct EstConst {
 	float4* dn;
 	float* conf;
 	int32_t* progress; // [rows * kProgressStride] pixels finished per logical row of this image (sweeps)
+	// restore-variant extra hypothesis (restore/libs/MVS/DepthMap.cpp:1527-1549): in sweep number hintIter every pixel also tries
+	// the estimate of the up-sampled coarser level, with a 0.1 bonus; null / -1 when not in use
+	const float* hintDepth;
+	const float* hintNormal;
+	int32_t hintIter;
 };
 
 struct SweepSync {

@@ -1267,6 +1267,22 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		STAMP(11)
 		if (phase == PH_DONE) break;
 	}
+	if (c.hintDepth && iter == c.hintIter) {
+		// restore variant, last sweep of the last outer iteration (restore/libs/MVS/DepthMap.cpp:1527-1549): the estimate of the
+		// up-sampled coarser level is one more hypothesis; it wins even when up to 0.1 worse.  Every wave evaluates it itself.
+		const float hdep = as_global(c.hintDepth)[idx];
+		if (hdep > 0.f) {
+			float h0 = as_global(c.hintNormal)[3 * idx], h1 = as_global(c.hintNormal)[3 * idx + 1], h2 = as_global(c.hintNormal)[3 * idx + 2];
+			const float hd = interpolate_pixel(c, G, x, y, hdep, h0, h1, h2);
+			correct_normal(G, h0, h1, h2);
+			const float hpd = -hd * dot3(h0, h1, h2, G.v0, G.v1, 1.f); // InitPlane
+			const float F = smooth_pass(c, st.pk->cl, closeMask, eligMask, lane, hd, h0, h1, h2, h0, h1, h2, hpd, 63);
+			const float sc = score_chunk<S, BIG>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, 1ull, 0, 0, __builtin_huge_valf(), issued);
+			const float nconf = rlf(sc, 0);
+			++evals;
+			if (conf > nconf - 0.1f) { conf = nconf; depth = hd; n0 = h0; n1 = h1; n2 = h2; }
+		}
+	}
 	if (pp.r > 0 && pp.poll > pp.known) pp.known = pp.poll; // consume the poll issued after the propagation phase
 	if (lane == 0) {
 		float* hrec = sh.hist[q & (kHist - 1)];

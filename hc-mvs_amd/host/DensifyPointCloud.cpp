@@ -44,6 +44,8 @@ struct Options { // DensifyPointCloud.cpp:139-198 (defaults from there)
 	                              // reference's), 0 reference raster order (bit-exact cloud, ~10x slower on dense scenes)
 	int estimateColors = 2, estimateNormals = 2;   // 2: during fusion, 1: after it (DepthMap.cpp:2125-2269), 0: none
 	int maxResolution = 3200, minResolution = 640;  // DensifyPointCloud.cpp:144-145
+	int restoreHypothesis = 0;    // 1: the `restore` binary's extra last-sweep hypothesis from the previous level's maps
+	                              // (restore/libs/MVS/DepthMap.cpp:1527-1549); needs the previous level's maps in the working folder
 	int device = 0, batch = 8;
 	uint32_t seed = 1234;
 };
@@ -65,6 +67,7 @@ struct ImageData {
 	std::vector<uint32_t> srcImages;            // the scene images behind srcs
 	float dMin = 0, dMax = 0;
 	float *dDepth = nullptr, *dNormal = nullptr, *dConf = nullptr; // device maps
+	float *dHintDepth = nullptr, *dHintNormal = nullptr;            // previous level's maps, resized (restore variant)
 };
 struct Vertex { float X[3]; std::vector<std::pair<uint32_t, float>> views; };
 
@@ -186,18 +189,70 @@ bool load_pnm(const std::string& path, int& w, int& h, std::vector<uint8_t>& bgr
 	}
 	return true;
 }
-// halve with a 2x2 box filter (cv::resize INTER_AREA for an integer factor), rounding like saturate_cast
-void halve(int& w, int& h, std::vector<uint8_t>& bgr) {
-	const int nw = w / 2, nh = h / 2;
+// cv::resize(image, image, Size(nw, nh), 0, 0, INTER_AREA) on an 8-bit BGR image, as Image::ResizeImage calls it
+// (Image.cpp:140-160), restated from OpenCV's published algorithm (imgproc/src/resize.cpp): an exact factor of 2 averages
+// 2x2 blocks with (sum + 2) >> 2; another integer factor multiplies the block sum by 1/area and rounds; any other factor goes
+// through computeResizeAreaTab / ResizeArea_Invoker in float and rounds (saturate_cast<uchar> = round half to even)
+void resize_area_bgr(int& w, int& h, std::vector<uint8_t>& bgr, int nw, int nh) {
 	std::vector<uint8_t> out((size_t)nw * nh * 3);
-	for (int y = 0; y < nh; ++y)
-		for (int x = 0; x < nw; ++x)
-			for (int c = 0; c < 3; ++c) {
-				const int s = bgr[3 * ((size_t)(2 * y) * w + 2 * x) + c] + bgr[3 * ((size_t)(2 * y) * w + 2 * x + 1) + c] +
-				              bgr[3 * ((size_t)(2 * y + 1) * w + 2 * x) + c] + bgr[3 * ((size_t)(2 * y + 1) * w + 2 * x + 1) + c];
-				out[3 * ((size_t)y * nw + x) + c] = (uint8_t)((s + 2) >> 2);
-			}
+	const double sx = (double)w / nw, sy = (double)h / nh;
+	const int ix = (int)sx, iy = (int)sy;
+	auto rnd = [](float v) { const long r = lrintf(v); return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r)); };
+	if ((double)ix == sx && (double)iy == sy) {
+		const float inv = 1.f / (float)(ix * iy);
+		for (int y = 0; y < nh; ++y)
+			for (int x = 0; x < nw; ++x)
+				for (int c = 0; c < 3; ++c) {
+					int s = 0;
+					for (int j = 0; j < iy; ++j)
+						for (int i = 0; i < ix; ++i) s += bgr[3 * ((size_t)(y * iy + j) * w + (x * ix + i)) + c];
+					out[3 * ((size_t)y * nw + x) + c] = (ix == 2 && iy == 2) ? (uint8_t)((s + 2) >> 2) : rnd((float)s * inv);
+				}
+	} else {
+		struct Tab { std::vector<int> idx; std::vector<float> a; };
+		auto cell = [](int d, double scale, int ssize, Tab& t) {
+			t.idx.clear(); t.a.clear();
+			const double f1 = d * scale, f2 = f1 + scale, cw = std::min(scale, ssize - f1);
+			int s1 = (int)std::ceil(f1), s2 = (int)std::floor(f2);
+			s2 = std::min(s2, ssize - 1); s1 = std::min(s1, s2);
+			if (s1 - f1 > 1e-3) { t.idx.push_back(s1 - 1); t.a.push_back((float)((s1 - f1) / cw)); }
+			for (int q = s1; q < s2; ++q) { t.idx.push_back(q); t.a.push_back((float)(1.0 / cw)); }
+			if (f2 - s2 > 1e-3) { t.idx.push_back(s2); t.a.push_back((float)(std::min(std::min(f2 - s2, 1.), cw) / cw)); }
+		};
+		std::vector<Tab> xt((size_t)nw);
+		for (int x = 0; x < nw; ++x) cell(x, sx, w, xt[x]);
+#pragma omp parallel for schedule(static)
+		for (int y = 0; y < nh; ++y) {
+			Tab yt;
+			cell(y, sy, h, yt);
+			for (int x = 0; x < nw; ++x)
+				for (int c = 0; c < 3; ++c) {
+					float sum = 0.f;
+					for (size_t j = 0; j < yt.idx.size(); ++j) {
+						float buf = 0.f;
+						for (size_t i = 0; i < xt[x].idx.size(); ++i) buf += (float)bgr[3 * ((size_t)yt.idx[j] * w + xt[x].idx[i]) + c] * xt[x].a[i];
+						sum = j == 0 ? yt.a[j] * buf : sum + yt.a[j] * buf;
+					}
+					out[3 * ((size_t)y * nw + x) + c] = rnd(sum);
+				}
+		}
+	}
 	w = nw; h = nh; bgr.swap(out);
+}
+// TImage::computeMaxResolution (Types.inl:2442-2460) + Image::ResizeImage (Image.cpp:140-160): the working size of an image
+void working_size(int w, int h, unsigned level, unsigned minSize, unsigned maxSize, int& nw, int& nh) {
+	const unsigned imageSize = (unsigned)std::max(w, h);
+	unsigned size;
+	if (level == 0) size = std::min(imageSize, maxSize);
+	else {
+		size = imageSize >> level;
+		if (size < minSize) { level = 0; while ((imageSize >> (level + 1)) >= minSize) ++level; size = imageSize >> level; }
+		size = std::min(size, maxSize);
+	}
+	nw = w; nh = h;
+	if (size == 0 || imageSize <= size) return;
+	if (w > h) { nh = (int)((unsigned)h * size / (unsigned)w); nw = (int)size; }
+	else { nw = (int)((unsigned)w * size / (unsigned)h); nh = (int)size; }
 }
 
 // ---- camera helpers (Camera.h) -------------------------------------------------------------------------------------
@@ -434,7 +489,7 @@ int main(int argc, char** argv) {
 	geti("--n-propagatehalfwin", o.propagateHalfWin); geti("--n-propagatestep", o.propagateStep);
 	getf("--n-photometric_flow", o.photometricFlow); getf("--depthweight", o.depthweight); getf("--normalweight", o.normalweight);
 	geti("--n-initTriangulate", o.initTriangulate); geti("--min-views-trust-point", o.minViewsTrustPoint);
-	geti("--fuse-order", o.fuseOrder);
+	geti("--fuse-order", o.fuseOrder); geti("--restore-hypothesis", o.restoreHypothesis);
 	geti("--device", o.device); geti("--batch", o.batch);
 	if (kv.count("--seed")) o.seed = (uint32_t)strtoul(kv["--seed"].c_str(), nullptr, 10);
 	geti("--estimate-colors", o.estimateColors); geti("--estimate-normals", o.estimateNormals);
@@ -471,7 +526,11 @@ int main(int argc, char** argv) {
 		const MvsPose& q = p.poses[mimages[i].poseID];
 		std::string path = im.name[0] == '/' ? im.name : dirname_of(o.input) + "/" + im.name;
 		if (!load_pnm(path, im.w, im.h, im.bgr)) { fprintf(stderr, "error: failed loading image '%s' (binary PPM/PGM expected)\n", path.c_str()); return EXIT_FAILURE; }
-		for (int l = 0; l < o.resolutionLevel && std::min(im.w, im.h) / 2 >= 64; ++l) halve(im.w, im.h, im.bgr);
+		{ // SceneDensify.cpp:3612-3615: one INTER_AREA resize to the resolution level's size, within [min-resolution, max-resolution]
+			int nw, nh;
+			working_size(im.w, im.h, (unsigned)std::max(0, o.resolutionLevel), (unsigned)std::max(1, o.minResolution), (unsigned)std::max(1, o.maxResolution), nw, nh);
+			if (nw != im.w || nh != im.h) resize_area_bgr(im.w, im.h, im.bgr, nw, nh);
+		}
 		// Interface.h:451-459 pose composition; K rescaled to the working resolution (Scene.cpp:83-91, Camera.h:167-180)
 		mat3mul(c.R, q.R, im.cam.R);
 		for (int k = 0; k < 3; ++k) im.cam.C[k] = q.R[0 * 3 + k] * c.C[0] + q.R[1 * 3 + k] * c.C[1] + q.R[2 * 3 + k] * c.C[2] + q.C[k];
@@ -554,7 +613,7 @@ int main(int argc, char** argv) {
 	// loop over the images (SceneDensify.cpp:3651-3667); the uploads follow in order
 	for (size_t c0 = 0; c0 < todo.size(); c0 += 16) {
 		const size_t c1 = std::min(todo.size(), c0 + 16);
-		std::vector<std::vector<float>> dAll(c1 - c0), nAll(c1 - c0);
+		std::vector<std::vector<float>> dAll(c1 - c0), nAll(c1 - c0), hdAll(c1 - c0), hnAll(c1 - c0);
 		std::vector<int> failed(c1 - c0, 0);
 #pragma omp parallel for schedule(dynamic, 1)
 		for (long k = (long)c0; k < (long)c1; ++k) {
@@ -593,6 +652,22 @@ int main(int argc, char** argv) {
 				if (!(hi > 0.f)) { failed[k - c0] = 3; continue; }
 				im.dMin = lo * 0.9f; im.dMax = hi * 1.1f;
 			}
+			if (o.restoreHypothesis) { // restore/libs/MVS/SceneDensify.cpp:508-532: the previous level's maps, resized, feed the extra hypothesis
+				char nm[64];
+				snprintf(nm, sizeof nm, "/depth%04u.dmap", id);
+				int pw = 0, ph = 0;
+				std::vector<float> pd, pn;
+				if (!load_dmap(o.workdir + nm, pw, ph, pd, pn)) { failed[k - c0] = 2; continue; }
+				resize_cubic(pd, pw, ph, 1, hdAll[k - c0], im.w, im.h);
+				resize_cubic(pn, pw, ph, 3, hnAll[k - c0], im.w, im.h);
+				for (size_t q_ = 0; q_ < n; ++q_) {
+					float& hd = hdAll[k - c0][q_];
+					float* q = &hnAll[k - c0][3 * q_];
+					const float len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+					if (!(hd > 0.f) || !(len > 0.f)) { hd = 0.f; continue; } // no estimate at the coarser level: no extra hypothesis here
+					q[0] /= len; q[1] /= len; q[2] /= len;
+				}
+			}
 		}
 		for (size_t k = c0; k < c1; ++k) {
 			ImageData& im = images[todo[k]];
@@ -604,6 +679,11 @@ int main(int argc, char** argv) {
 			HIPOK(hipMemcpy(im.dDepth, dAll[k - c0].data(), n * 4, hipMemcpyHostToDevice));
 			HIPOK(hipMemcpy(im.dNormal, nAll[k - c0].data(), n * 12, hipMemcpyHostToDevice));
 			HIPOK(hipMemset(im.dConf, 0, n * 4));
+			if (o.restoreHypothesis) {
+				HIPOK(hipMalloc(&im.dHintDepth, n * 4)); HIPOK(hipMalloc(&im.dHintNormal, n * 12));
+				HIPOK(hipMemcpy(im.dHintDepth, hdAll[k - c0].data(), n * 4, hipMemcpyHostToDevice));
+				HIPOK(hipMemcpy(im.dHintNormal, hnAll[k - c0].data(), n * 12, hipMemcpyHostToDevice));
+			}
 		}
 	}
 	const double tInit = now_s();
@@ -621,6 +701,7 @@ int main(int argc, char** argv) {
 					hcmvs_batch_item itx;
 					itx.ref_id = im.id; itx.src_ids = im.srcs.data(); itx.n_src = (int32_t)im.srcs.size(); itx.seed_offset = im.id;
 					itx.d_min = im.dMin; itx.d_max = im.dMax; itx.d_depth = im.dDepth; itx.d_normal = im.dNormal; itx.d_conf = im.dConf;
+					itx.d_hint_depth = im.dHintDepth; itx.d_hint_normal = im.dHintNormal;
 					items.push_back(itx);
 				}
 				CHK(hcmvs_estimate_batch_device(ctx, items.data(), (int32_t)items.size(), &prm));
@@ -696,7 +777,7 @@ int main(int argc, char** argv) {
 		fprintf(stderr, "error: can not write the output files\n");
 		return EXIT_FAILURE;
 	}
-	for (auto& im : images) for (float* p : {im.dDepth, im.dNormal, im.dConf}) if (p) (void)hipFree(p);
+	for (auto& im : images) for (float* p : {im.dDepth, im.dNormal, im.dConf, im.dHintDepth, im.dHintNormal}) if (p) (void)hipFree(p);
 	hcmvs_destroy(ctx);
 	return EXIT_SUCCESS;
 }

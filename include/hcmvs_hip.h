@@ -140,6 +140,10 @@ typedef struct {
 	uint32_t seed_offset;  /* added to params->seed for this item */
 	float d_min, d_max;
 	float *d_depth, *d_normal, *d_conf; /* DEVICE in/out maps of this item */
+	/* optional (NULL = none): DEVICE maps (w*h depth, w*h*3 normal) of the up-sampled coarser level.  With them, the last
+	 * sweep of the last outer iteration also tries that estimate at every pixel, accepting it when it is at most 0.1 worse
+	 * than the current score -- the extra hypothesis of the fork's `restore` variant (restore/libs/MVS/DepthMap.cpp:1527-1549) */
+	const float *d_hint_depth, *d_hint_normal;
 } hcmvs_batch_item;
 int hcmvs_estimate_batch_device(hcmvs_ctx* ctx, const hcmvs_batch_item* items, int32_t n_items, const hcmvs_params* params);
 /* synchronises, then reports counters/timings of the last estimate (summed over the items of a batch) */

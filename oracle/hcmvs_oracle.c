@@ -1054,6 +1054,16 @@ static void process_pixel(est_ctx* c, int x, int y, int iter, float* depthMap, f
 			}
 		}
 	}
+	/* restore/libs/MVS/DepthMap.cpp:1527-1549: last sweep of the last outer iteration */
+	if (c->p.hint_depth && c->p.hint_normal && c->p.it_external == c->p.n_external_iters - 1 && iter == c->p.n_estimation_iters - 1 &&
+	    c->p.hint_depth[idx] > 0) {
+		float nn[3] = {c->p.hint_normal[3 * idx], c->p.hint_normal[3 * idx + 1], c->p.hint_normal[3 * idx + 2]};
+		const float nd = interpolate_pixel(c, &ps, x, y, c->p.hint_depth[idx], nn);
+		correct_normal(c->mt, ps.viewDir, nn);
+		init_plane(&ps, nd, nn);
+		const float nconf = score_pixel(c, &ps, nd, nn);
+		if (conf > nconf - 0.1f) { conf = nconf; depth = nd; normal[0] = nn[0]; normal[1] = nn[1]; normal[2] = nn[2]; }
+	}
 	confMap[idx] = conf; depthMap[idx] = depth;
 	normalMap[3 * idx] = normal[0]; normalMap[3 * idx + 1] = normal[1]; normalMap[3 * idx + 2] = normal[2];
 }

@@ -69,6 +69,10 @@ typedef struct {
 	int n_threads;              /* zig-zag band height = max(64, 8*n_threads) (SD.cpp:835); ROWS order
 	                               uses n_threads OpenMP threads and gives the same result for any count */
 	int median_blur;            /* 1 = cv::medianBlur(depth,3) at the start of the call (SD.cpp:859) */
+	/* restore variant (restore/libs/MVS/DepthMap.cpp:1527-1549): maps of the up-sampled coarser level (W*H depth, W*H*3 normal)
+	 * tried as one more hypothesis, with a 0.1 bonus, in the last sweep of the last outer iteration; NULL = frame_main behaviour */
+	const float* hint_depth;
+	const float* hint_normal;
 } hcor_params;
 
 void hcor_default_params(hcor_params* p);

@@ -24,7 +24,8 @@ class Params(C.Structure):
                 ("random_angle1_deg", C.c_float), ("random_angle2_deg", C.c_float),
                 ("random_smooth_depth", C.c_float), ("random_smooth_normal_deg", C.c_float),
                 ("random_smooth_bonus", C.c_float), ("photometric_flow", C.c_float), ("seed", C.c_uint32),
-                ("arith_mode", C.c_int), ("order", C.c_int), ("n_threads", C.c_int), ("median_blur", C.c_int)]
+                ("arith_mode", C.c_int), ("order", C.c_int), ("n_threads", C.c_int), ("median_blur", C.c_int),
+                ("hint_depth", C.POINTER(C.c_float)), ("hint_normal", C.POINTER(C.c_float))]
 
 
 class DepthMap(C.Structure):

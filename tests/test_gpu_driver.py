@@ -92,13 +92,25 @@ def test_densify_driver_end_to_end(tmp_path):
 def test_densify_driver_resolution_level_and_errors(tmp_path):
     tmp = str(tmp_path)
     scene, views = make_scene(tmp, w=384, h=256, n_views=4)
-    r = subprocess.run([EXE, "-i", scene, "--resolution-level=1", "--fusion-mode", "1", "--n-EstimationIters-external", "1"],
+    r = subprocess.run([EXE, "-i", scene, "--resolution-level=1", "--min-resolution", "100", "--fusion-mode", "1", "--n-EstimationIters-external", "1"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     dm = mvsio.read_dmap(os.path.join(tmp, "depth0000.dmap"))
     assert dm["depth"].shape == (128, 192)
     assert abs(dm["K"][0, 0] - views[0]["K"][0, 0] / 2) < 1e-9
     assert not os.path.exists(os.path.join(tmp, "scene_dense.mvs"))  # fusion-mode 1: depth maps only
+    # --min-resolution (default 640, DensifyPointCloud.cpp:145) stops the level from shrinking an image below it, --max-resolution caps it
+    # (TImage::computeMaxResolution, Types.inl:2442-2460; Image::ResizeImage, Image.cpp:140-160: one INTER_AREA resize, h * size / w)
+    r = subprocess.run([EXE, "-i", scene, "--resolution-level", "1", "--fusion-mode", "1", "--n-EstimationIters-external", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and mvsio.read_dmap(os.path.join(tmp, "depth0000.dmap"))["depth"].shape == (256, 384)
+    r = subprocess.run([EXE, "-i", scene, "--resolution-level", "0", "--max-resolution", "300", "--fusion-mode", "1", "--n-EstimationIters-external", "1"],
+                       capture_output=True, text=True, timeout=600)
+    dm = mvsio.read_dmap(os.path.join(tmp, "depth0000.dmap"))
+    assert r.returncode == 0 and dm["depth"].shape == (200, 300) and abs(dm["K"][0, 0] - views[0]["K"][0, 0] * 300 / 384) < 1e-9
+    m = dm["depth"] > 0
+    gt = views[0]["depth"][::1, ::1]
+    assert m.mean() > 0.4                                             # a non-integer area resize still gives a usable image
     r = subprocess.run([EXE, "-i", os.path.join(tmp, "missing.mvs")], capture_output=True, text=True)
     assert r.returncode != 0 and "can not load" in r.stderr
     r = subprocess.run([EXE], capture_output=True, text=True)
@@ -124,7 +136,7 @@ def test_densify_driver_coarse_to_fine_handoff(tmp_path):
     tmp = str(tmp_path)
     scene, views = make_scene(tmp, w=384, h=256, n_views=5)
     common = ["--number-views", "4", "--fusion-mode", "1", "--n-EstimationIters-external", "1", "-v", "3"]
-    r = subprocess.run([EXE, "-i", scene, "--resolution-level", "1", "--n-EstimationIters", "4"] + common, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([EXE, "-i", scene, "--resolution-level", "1", "--min-resolution", "100", "--n-EstimationIters", "4"] + common, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert mvsio.read_dmap(os.path.join(tmp, "depth0000.dmap"))["depth"].shape == (128, 192)
     r = subprocess.run([EXE, "-i", scene, "--resolution-level", "0", "--n-initTriangulate", "0", "--n-EstimationIters", "1"] + common,
@@ -138,6 +150,20 @@ def test_densify_driver_coarse_to_fine_handoff(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     tri = _accuracy(tmp, views)
     assert handoff is not None and handoff > 0.7 and handoff >= tri - 0.02
+    # the `restore` binary's extra last-sweep hypothesis from the previous level (restore/libs/MVS/DepthMap.cpp:1527-1549,
+    # restore/libs/MVS/SceneDensify.cpp:508-532): triangulated init + the coarser level's maps as one more hypothesis
+    for f in os.listdir(tmp):
+        if f.endswith(".dmap"):
+            os.remove(os.path.join(tmp, f))
+    r = subprocess.run([EXE, "-i", scene, "--resolution-level", "1", "--min-resolution", "100", "--n-EstimationIters", "4"] + common, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0
+    r = subprocess.run([EXE, "-i", scene, "--resolution-level", "0", "--n-initTriangulate", "1", "--restore-hypothesis", "1", "--n-EstimationIters", "1"] + common,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    restore = _accuracy(tmp, views)
+    # the extra hypothesis wins even when it scores up to 0.1 worse (that is the variant's rule), so a coarser-level estimate
+    # can displace a finer one: the result is a different, still accurate map
+    assert restore > 0.7 and abs(restore - tri) > 1e-4
     # missing previous level -> clean error
     for f in os.listdir(tmp):
         if f.endswith(".dmap"):
