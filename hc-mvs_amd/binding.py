@@ -58,7 +58,7 @@ SYMBOLS = ["hcmvs_default_params", "hcmvs_create", "hcmvs_destroy", "hcmvs_last_
            "hcmvs_get_gradient_map", "hcmvs_estimate", "hcmvs_estimate_device", "hcmvs_estimate_batch_device", "hcmvs_get_stats",
            "hcmvs_splat_init", "hcmvs_triangulate_init", "hcmvs_triangulate_points", "hcmvs_set_depthmap", "hcmvs_set_depthmap_device", "hcmvs_get_depthmap",
            "hcmvs_set_neighbors", "hcmvs_filter", "hcmvs_set_fuse_order", "hcmvs_fuse", "hcmvs_fuse_cloud", "hcmvs_estimate_point_colors",
-           "hcmvs_estimate_point_normals"]
+           "hcmvs_estimate_point_normals", "hcmvs_postfilter"]
 
 
 def triangulate_points(w, h, K, R, Cc, points_xyz, avg_depth=0.0, add_corners=True):
@@ -126,6 +126,7 @@ def lib():
         L.hcmvs_fuse.argtypes = [vp, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint64,
                                  fp, fp, u8p, u32p, u64p, u64p]
         L.hcmvs_fuse_cloud.argtypes = [vp, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Cloud)]
+        L.hcmvs_postfilter.argtypes = [vp, C.c_uint32, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, u64p]
         L.hcmvs_estimate_point_colors.argtypes = [vp, C.c_uint64, fp, u32p, u32p, u8p]
         L.hcmvs_estimate_point_normals.argtypes = [vp, C.c_uint64, fp, u32p, u32p, C.c_int32, fp]
         _lib = L
@@ -286,11 +287,12 @@ class Context:
         self._chk(lib().hcmvs_set_depthmap_device(self._h, vid, C.c_void_p(d_depth_ptr), C.c_void_p(d_normal_ptr) if d_normal_ptr else None,
                                                   C.c_void_p(d_conf_ptr), d_min, d_max))
 
-    def get_depthmap(self, vid):
+    def get_depthmap(self, vid, with_normal=False):
         h, w = self.shapes[vid]
         d = np.empty((h, w), np.float32); c = np.empty((h, w), np.float32)
-        self._chk(lib().hcmvs_get_depthmap(self._h, vid, _f(d), None, _f(c)))
-        return d, c
+        n = np.empty((h, w, 3), np.float32) if with_normal else None
+        self._chk(lib().hcmvs_get_depthmap(self._h, vid, _f(d), None if n is None else _f(n), _f(c)))
+        return (d, n, c) if with_normal else (d, c)
 
     def set_neighbors(self, vid, ids):
         arr = (C.c_uint32 * max(len(ids), 1))(*ids)
@@ -356,3 +358,12 @@ class Context:
         self._chk(lib().hcmvs_estimate_point_normals(self._h, len(x), _f(x), nv.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                      vi.ctypes.data_as(C.POINTER(C.c_uint32)), n_neighbors, _f(out)))
         return out
+
+    def postfilter(self, vid, order, n_min_views_fuse=2, depth_diff_threshold=0.01, normal_diff_deg=25.0, depthweight=1.0, normalweight=1.0,
+                   gap_size=7):
+        """RemoveSmallSegments (fork version) + GapInterpolation on the registered device maps of view vid; returns pixels filled"""
+        ids = (C.c_uint32 * len(order))(*order)
+        nf = C.c_uint64()
+        self._chk(lib().hcmvs_postfilter(self._h, vid, ids, len(order), n_min_views_fuse, depth_diff_threshold, normal_diff_deg, depthweight,
+                                         normalweight, gap_size, C.byref(nf)))
+        return nf.value

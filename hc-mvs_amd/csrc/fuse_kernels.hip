@@ -26,6 +26,7 @@
  * Double precision follows the reference (Point3 = double); no contraction (-ffp-contract=off).
  */
 #include "fuse_common.h"
+#include "pm_math.h"
 
 #include <cstdlib>
 
@@ -33,6 +34,7 @@
 
 namespace hcmvs {
 
+static const dim3 kGrid(2048), kBlock(256);
 #define NO_ID 0xFFFFFFFFu
 
 __device__ __forceinline__ void i2w(const DevMap& m, double x, double y, double z, double* X) { // Camera.h:306-320
@@ -540,6 +542,85 @@ __global__ void point_colors_kernel(unsigned long long n, const float* xyz, cons
 		bgr[3 * i] = c[0]; bgr[3 * i + 1] = c[1]; bgr[3 * i + 2] = c[2];
 	}
 }
+// ------------------------------------------------------------------------------------------------------
+// the fork's depth-map post-filters, applied after outer iterations 1 and 2 (SceneDensify.cpp:3939-3958):
+// RemoveSmallSegments as the fork rewrote it (SceneDensify.cpp:2048-2275) = a complete fusion pass, after which depthMap_fuse /
+// normalMap_fuse are the image's maps restricted to the pixels that ended up in a fused point (postfilter_mask_kernel, from
+// the claim map the fuse pass leaves); GapInterpolation (SceneDensify.cpp:2280-3001): gaps along rows, then along columns
+// (gap_lines_kernel, one thread per line -- a line is filled left to right with a running counter, so it is sequential, while
+// the lines of a pass are independent), then the merge (SceneDensify.cpp:2989-3000).  The third, per-pixel pass of the
+// reference (SceneDensify.cpp:2717-2983) reads uninitialised variables and is not reproduced.
+
+__global__ void postfilter_mask_kernel(int n, const float* depth, const float* normal, const uint32_t* claim, float* dF, float* nF) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const bool on = claim[i] != NO_ID;
+		dF[i] = on ? depth[i] : 0.f;
+		for (int k = 0; k < 3; ++k) nF[3 * i + k] = on ? normal[3 * i + k] : 0.f;
+	}
+}
+__global__ void gap_lines_kernel(float* dF, float* nF, float* conf, const uint8_t* gra, int nLines, int len, size_t lineStride, size_t stride, int gap,
+                                 float thr, unsigned long long* filledOut) {
+	const int line = blockIdx.x * blockDim.x + threadIdx.x;
+	if (line >= nLines) return;
+	const size_t base = (size_t)line * lineStride;
+	unsigned count = 0;
+	unsigned long long filled = 0;
+	for (int u = 0; u < len; ++u) {
+		const size_t iu = base + (size_t)u * stride;
+		const float depth = dF[iu];
+		if (depth <= 0.f) { ++count; continue; }
+		if (count == 0) continue;
+		if ((unsigned)u > count) {
+			const size_t i0 = base + (size_t)(u - (int)count - 1) * stride;
+			const float depthFirst = dF[i0];
+			bool fill;
+			if (count <= (unsigned)gap) fill = is_depth_similar(depthFirst, depth, thr);
+			else {
+				const float t0 = (float)gra[i0], t1 = (float)gra[iu];
+				const float ratio = (t1 - t0) / t0;
+				fill = ratio <= 0.1f || is_depth_similar(depthFirst, depth, thr);
+			}
+			if (fill) {
+				const float cnt1 = (float)(count + 1);
+				const float diff = (depth - depthFirst) / cnt1;
+				float d = depthFirst;
+				const float c = conf[i0] < conf[iu] ? conf[i0] : conf[iu];
+				float p0 = pm_atan2f(nF[3 * i0 + 1], nF[3 * i0]), p1 = pm_acosf(nF[3 * i0 + 2]);               // Normal2Dir, Util.inl:614-618
+				const float q0 = pm_atan2f(nF[3 * iu + 1], nF[3 * iu]), q1 = pm_acosf(nF[3 * iu + 2]);
+				const float dd0 = (q0 - p0) / cnt1, dd1 = (q1 - p1) / cnt1;
+				for (int uc = u - (int)count; uc < u; ++uc) {
+					const size_t ic = base + (size_t)uc * stride;
+					d += diff;
+					dF[ic] = d;
+					p0 += dd0; p1 += dd1;
+					float s0, c0, s1, c1;
+					pm_sincosf(p0, &s0, &c0); pm_sincosf(p1, &s1, &c1);                                       // Dir2Normal, Util.inl:620-625
+					nF[3 * ic] = c0 * s1; nF[3 * ic + 1] = s0 * s1; nF[3 * ic + 2] = c1;
+					conf[ic] = c;
+					++filled;
+				}
+			}
+		}
+		count = 0;
+	}
+	if (filled) atomicAdd(filledOut, filled);
+}
+__global__ void postfilter_merge_kernel(int n, float* depth, float* normal, const float* dF, const float* nF) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		if (dF[i] > 0.f) depth[i] = dF[i];
+		const float a = nF[3 * i], b = nF[3 * i + 1], c = nF[3 * i + 2];
+		if (a != 0.f || b != 0.f || c != 0.f) { normal[3 * i] = a; normal[3 * i + 1] = b; normal[3 * i + 2] = c; }
+	}
+}
+void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const uint32_t* claim, const uint8_t* gra, float* dF, float* nF,
+                       int gap, float thr, unsigned long long* filled, hipStream_t s) {
+	const int n = w * h;
+	hipLaunchKernelGGL(postfilter_mask_kernel, kGrid, kBlock, 0, s, n, depth, normal, claim, dF, nF);
+	hipLaunchKernelGGL(gap_lines_kernel, dim3((h + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, h, w, (size_t)w, (size_t)1, gap, thr, filled);   // rows
+	hipLaunchKernelGGL(gap_lines_kernel, dim3((w + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, w, h, (size_t)1, (size_t)w, gap, thr, filled);   // columns
+	hipLaunchKernelGGL(postfilter_merge_kernel, kGrid, kBlock, 0, s, n, depth, normal, dF, nF);
+}
+
 void launch_point_colors(unsigned long long n, const float* xyz, const unsigned long long* voff, const uint32_t* views, const DevMap* maps, uint8_t* bgr, hipStream_t s) {
 	hipLaunchKernelGGL(point_colors_kernel, dim3(2048), dim3(256), 0, s, n, xyz, voff, views, maps, bgr);
 }
@@ -547,7 +628,6 @@ void launch_point_colors(unsigned long long n, const float* xyz, const unsigned 
 // ------------------------------------------------------------------------------------------------------
 // launch wrappers
 
-static const dim3 kGrid(2048), kBlock(256);
 
 void launch_fill_u32(uint32_t* p, uint32_t v, size_t n, hipStream_t s) { hipLaunchKernelGGL(fill_u32_kernel, kGrid, kBlock, 0, s, p, v, n); }
 void launch_fill_u64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s) { hipLaunchKernelGGL(fill_u64_kernel, kGrid, kBlock, 0, s, p, v, n); }

@@ -823,7 +823,8 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	cloud->n_points = cloud->n_depths = cloud->n_view_entries = 0;
 	if (cloud->view_ids && !cloud->view_weights) return fail(c, HCMVS_ERR_INVALID, "fuse: view_ids without view_weights");
 	if (!c) return HCMVS_ERR_INVALID;
-	if (!order || n_order < 1 || !xyz || !n_points) return fail(c, HCMVS_ERR_INVALID, "fuse: bad arguments");
+	if (!order || n_order < 1 || !n_points) return fail(c, HCMVS_ERR_INVALID, "fuse: bad arguments");
+	const bool wantCloud = xyz != nullptr; // without xyz only the fusion's side effects (claims, invalidated depths) and counts are produced
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	std::vector<DevMap> host;
@@ -858,7 +859,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	             oXyz = carve(maxArea * 12), oNrm = carve(maxArea * 12), oBgr = carve(maxArea * 3), oNv = carve(maxArea * 4),
 	             oPV = carve(viewCapacity ? maxArea * 4 * (size_t)(maxNb + 1) : 0), oPW = carve(viewCapacity ? maxArea * 4 * (size_t)(maxNb + 1) : 0),
 	             oVoff = carve(viewCapacity ? maxArea * 4 : 0),
-	             oCX = carve(capacity * 12), oCN = carve(normal ? capacity * 12 : 0), oCB = carve(bgr ? capacity * 3 : 0), oCV = carve(n_views || viewCapacity ? capacity * 4 : 0),
+	             oCX = carve(wantCloud ? capacity * 12 : 0), oCN = carve(normal ? capacity * 12 : 0), oCB = carve(bgr ? capacity * 3 : 0), oCV = carve(n_views || viewCapacity ? capacity * 4 : 0),
 	             oCVI = carve(viewCapacity * 4), oCVW = carve(viewCapacity * 4);
 	rc = ensure_scratch(c, off);
 	if (rc) return rc;
@@ -929,8 +930,8 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 		if (getenv("HCMVS_FUSE_DEBUG")) fprintf(stderr, "fuse: image %u: %u pending pixels, %u through the queue, %llu accepted\n", A.id, ctlWords[4], ctlWords[0], cnt[3]);
 		depths += cnt[0];
 		const unsigned long long accepted = cnt[3];
-		if (total + accepted > capacity) return fail(c, HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity);
-		if (accepted) {
+		if (wantCloud && total + accepted > capacity) return fail(c, HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity);
+		if (accepted && wantCloud) {
 			launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, total, capacity, cX, cN, cB, cV, pviews, pweights, vstride,
 			                    voff, viewTotal, viewCapacity, cVI, cVW, s);
 			if (viewCapacity) { // this image's share of the view lists = last offset + last count
@@ -945,7 +946,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 		total += accepted;
 	}
 	HIPCHK(c, hipGetLastError());
-	HIPCHK(c, hipMemcpyAsync(xyz, cX, total * 12, hipMemcpyDeviceToHost, s));
+	if (wantCloud) HIPCHK(c, hipMemcpyAsync(xyz, cX, total * 12, hipMemcpyDeviceToHost, s));
 	if (normal) HIPCHK(c, hipMemcpyAsync(normal, cN, total * 12, hipMemcpyDeviceToHost, s));
 	if (bgr) HIPCHK(c, hipMemcpyAsync(bgr, cB, total * 3, hipMemcpyDeviceToHost, s));
 	if (n_views) HIPCHK(c, hipMemcpyAsync(n_views, cV, total * 4, hipMemcpyDeviceToHost, s));
@@ -972,6 +973,36 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	*n_points = cl.n_points;
 	if (n_depths) *n_depths = cl.n_depths;
 	return rc;
+}
+
+int hcmvs_postfilter(hcmvs_ctx* c, uint32_t id, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
+                     float normal_diff_deg, float depthweight, float normalweight, int32_t gap_size, uint64_t* n_filled) {
+	if (!c) return HCMVS_ERR_INVALID;
+	auto it = c->views.find(id);
+	if (it == c->views.end() || !it->second.mDepth || !it->second.mNormal) return fail(c, HCMVS_ERR_INVALID, "postfilter: view %u has no registered depth + normal maps", id);
+	if (gap_size < 0) return fail(c, HCMVS_ERR_INVALID, "postfilter: bad gap size");
+	HIPCHK(c, hipSetDevice(c->device));
+	// RemoveSmallSegments (fork version): the whole fusion, for its claim maps and invalidations only
+	hcmvs_cloud cl;
+	memset(&cl, 0, sizeof cl);
+	int rc = hcmvs_fuse_cloud(c, order, n_order, n_min_views_fuse, depth_diff_threshold, normal_diff_deg, depthweight, normalweight, &cl);
+	if (rc) return rc;
+	View& v = c->views.find(id)->second;
+	rc = ensure_gradient(c, v);
+	if (rc) return rc;
+	const size_t n = (size_t)v.w * v.h;
+	float* dF = nullptr; float* nF = nullptr;
+	if (hipMalloc(&dF, n * 4) != hipSuccess || hipMalloc(&nF, n * 12) != hipSuccess) { if (dF) (void)hipFree(dF); return fail(c, HCMVS_ERR_HIP, "postfilter: out of device memory"); }
+	hipStream_t s = c->stream;
+	(void)hipMemsetAsync(c->counters, 0, 64, s);
+	launch_postfilter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, v.claim, v.gra, dF, nF, gap_size, depth_diff_threshold * 2.5f, c->counters, s);
+	unsigned long long filled = 0;
+	const hipError_t e1 = hipMemcpyAsync(&filled, c->counters, 8, hipMemcpyDeviceToHost, s);
+	const hipError_t e2 = hipStreamSynchronize(s);
+	(void)hipFree(dF); (void)hipFree(nF);
+	if (e1 != hipSuccess || e2 != hipSuccess || hipGetLastError() != hipSuccess) return fail(c, HCMVS_ERR_HIP, "postfilter: device failure");
+	if (n_filled) *n_filled = filled;
+	return HCMVS_OK;
 }
 
 int hcmvs_estimate_point_colors(hcmvs_ctx* c, uint64_t n, const float* xyz, const uint32_t* n_views, const uint32_t* view_ids, uint8_t* bgr) {

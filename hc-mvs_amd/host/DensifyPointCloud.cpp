@@ -44,6 +44,7 @@ struct Options { // DensifyPointCloud.cpp:139-198 (defaults from there)
 	                              // reference's), 0 reference raster order (bit-exact cloud, ~10x slower on dense scenes)
 	int estimateColors = 2, estimateNormals = 2;   // 2: during fusion, 1: after it (DepthMap.cpp:2125-2269), 0: none
 	int maxResolution = 3200, minResolution = 640;  // DensifyPointCloud.cpp:144-145
+	int postFilter = 1;           // the fork's RemoveSmallSegments + GapInterpolation after outer iterations 1 and 2 (SceneDensify.cpp:3939-3958)
 	int restoreHypothesis = 0;    // 1: the `restore` binary's extra last-sweep hypothesis from the previous level's maps
 	                              // (restore/libs/MVS/DepthMap.cpp:1527-1549); needs the previous level's maps in the working folder
 	int device = 0, batch = 8;
@@ -489,7 +490,7 @@ int main(int argc, char** argv) {
 	geti("--n-propagatehalfwin", o.propagateHalfWin); geti("--n-propagatestep", o.propagateStep);
 	getf("--n-photometric_flow", o.photometricFlow); getf("--depthweight", o.depthweight); getf("--normalweight", o.normalweight);
 	geti("--n-initTriangulate", o.initTriangulate); geti("--min-views-trust-point", o.minViewsTrustPoint);
-	geti("--fuse-order", o.fuseOrder); geti("--restore-hypothesis", o.restoreHypothesis);
+	geti("--fuse-order", o.fuseOrder); geti("--restore-hypothesis", o.restoreHypothesis); geti("--n-postfilter", o.postFilter);
 	geti("--device", o.device); geti("--batch", o.batch);
 	if (kv.count("--seed")) o.seed = (uint32_t)strtoul(kv["--seed"].c_str(), nullptr, 10);
 	geti("--estimate-colors", o.estimateColors); geti("--estimate-normals", o.estimateNormals);
@@ -712,6 +713,31 @@ int main(int argc, char** argv) {
 						printf("Depth-map for image %3u estimated using %2d images: %dx%d (outer iteration %d, batch %.0f ms)\n", itx.ref_id,
 						       itx.n_src, images[itx.ref_id].w, images[itx.ref_id].h, it, st.ms_total);
 			}
+		// SceneDensify.cpp:3939-3958: after outer iterations 1 and 2 every image goes through RemoveSmallSegments (in the fork: a
+		// whole fusion pass over the current maps of all images) and GapInterpolation, one image after the other
+		if (o.postFilter && (it == 1 || it == 2)) {
+			const double tp = now_s();
+			std::vector<uint32_t> ord(todo);
+			std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return images[a].neighbors.size() > images[b].neighbors.size(); });
+			for (uint32_t id : todo) {
+				ImageData& im = images[id];
+				CHK(hcmvs_set_depthmap_device(ctx, id, im.dDepth, im.dNormal, im.dConf, im.dMin, im.dMax));
+				std::vector<uint32_t> nb;
+				for (const auto& x : im.neighbors) if (std::find(todo.begin(), todo.end(), x.id) != todo.end()) nb.push_back(x.id);
+				if (nb.size() > 31) nb.resize(31);
+				CHK(hcmvs_set_neighbors(ctx, id, nb.data(), (int32_t)nb.size()));
+			}
+			CHK(hcmvs_set_fuse_order(ctx, o.fuseOrder));
+			uint64_t filledAll = 0;
+			for (uint32_t id : todo) {
+				uint64_t filled = 0;
+				CHK(hcmvs_postfilter(ctx, id, ord.data(), (int32_t)ord.size(), std::min<int>(o.numberViewsFuse, (int)images.size()), 0.01f, 25.f, o.depthweight,
+				                     o.normalweight, 7, &filled));
+				filledAll += filled;
+			}
+			if (o.verbosity > 1) printf("Depth-maps filtered after outer iteration %d: fuse-consistency mask + gap interpolation, %llu pixels filled (%.2f s)\n", it,
+			                            (unsigned long long)filledAll, now_s() - tp);
+		}
 	}
 	double pixels = 0;
 	for (uint32_t id : todo) pixels += (double)images[id].w * images[id].h;

@@ -205,6 +205,21 @@ int hcmvs_fuse(hcmvs_ctx* ctx, const uint32_t* order, int32_t n_order, int32_t n
                uint64_t capacity, float* xyz, float* normal_or_null, uint8_t* bgr_or_null, uint32_t* n_views_or_null,
                uint64_t* n_points, uint64_t* n_depths);
 
+/* The fork's depth-map post-filters, which the reference applies to every image after outer iterations 1 and 2
+ * (SceneDensify.cpp:3939-3958), on the registered DEVICE maps of view `id` (hcmvs_set_depthmap_device; depth, normal and conf
+ * are updated in place):
+ *   RemoveSmallSegments as the fork rewrote it (SceneDensify.cpp:2048-2275): a complete FuseDepthMaps pass over the maps of
+ *   `order` -- it zeroes the estimates that fused points occlude, in every image, exactly like hcmvs_fuse -- which leaves
+ *   depthMap_fuse / normalMap_fuse = the image's maps restricted to the pixels that ended up in a fused point;
+ *   GapInterpolation (SceneDensify.cpp:2280-3001): gaps of at most gap_size (nIpolGapSize = 7) pixels along rows, then
+ *   columns, whose ends agree within 2.5 x depth_diff_threshold -- or longer ones whose ends agree or whose gradient-map values
+ *   differ by at most 10 % -- are filled by linear interpolation of depth and normal direction; finally the maps take the
+ *   fused-and-filled values where those are valid.
+ * The reference's third, per-pixel pass (SceneDensify.cpp:2717-2983) reads uninitialised variables and is not reproduced.
+ * n_filled: pixels the two interpolation passes wrote. */
+int hcmvs_postfilter(hcmvs_ctx* ctx, uint32_t id, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
+                     float normal_diff_deg, float depthweight, float normalweight, int32_t gap_size, uint64_t* n_filled);
+
 /* The fused cloud with everything PointCloud holds (PointCloud.h: points, pointViews, pointWeights, colors, normals).
  * Host buffers owned by the caller; any optional pointer may be NULL.  The view lists are stored back to back (CSR): point p's
  * n_views[p] entries follow those of point p-1, image ids ascending like PointCloud::ViewArr (SceneDensify.cpp:3376-3379,

@@ -197,7 +197,7 @@ int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, 
 				if (depth == 0) continue;
 				++cloud->n_depths;
 				if (claim[A][idx] != NO_ID) continue;
-				if (cloud->n_points >= cloud->capacity) { rc = 1; break; }
+				if (cloud->xyz && cloud->n_points >= cloud->capacity) { rc = 1; break; }
 				const uint32_t idPoint = (uint32_t)cloud->n_points;
 				claim[A][idx] = idPoint;
 				double Xw[3];
@@ -260,8 +260,10 @@ int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, 
 					for (int v = 0; v < nv; ++v) claim[views[v]][vpix[v]] = NO_ID; /* SD.cpp:3426-3437 */
 				} else {
 					const double nrm = 1.0 / confidence;
-					float* out = cloud->xyz + 3 * cloud->n_points;
-					for (int k = 0; k < 3; ++k) out[k] = (float)(X[k] * nrm);
+					if (cloud->xyz) {
+						float* out = cloud->xyz + 3 * cloud->n_points;
+						for (int k = 0; k < 3; ++k) out[k] = (float)(X[k] * nrm);
+					}
 					if (cloud->bgr) for (int k = 0; k < 3; ++k) {
 						const int r = (int)floorf(Cc[k] * (float)nrm + .5f);
 						cloud->bgr[3 * cloud->n_points + k] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
@@ -283,6 +285,10 @@ int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, 
 					for (int v = 0; v < ninv; ++v) *invalid[v] = 0; /* SD.cpp:3447-3449 */
 				}
 			}
+	}
+	if (cloud->claim_mask && (int)cloud->claim_image < n_maps && claim[cloud->claim_image]) {
+		const size_t area = (size_t)maps[cloud->claim_image].width * maps[cloud->claim_image].height;
+		for (size_t i = 0; i < area; ++i) cloud->claim_mask[i] = claim[cloud->claim_image][i] != NO_ID;
 	}
 	for (int m = 0; m < n_maps; ++m) free(claim[m]);
 	free(claim); free(P);
@@ -331,4 +337,96 @@ void hcor_estimate_point_colors(const hcor_depthmap* maps, int n_maps, uint64_t 
 			c[k] = (uint8_t)((uint8_t)(a * y1) + (uint8_t)(b * y));
 		}
 	}
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* SD.cpp:3939-3958: RemoveSmallSegments (fork version) + GapInterpolation                           */
+#include "portable_math.h"
+typedef struct { float (*atan2f_)(float, float); float (*acosf_)(float); float (*sinf_)(float); float (*cosf_)(float); } pf_math;
+static float pf_pm_atan2(float y, float x) { return pm_atan2f(y, x); }
+static float pf_pm_acos(float x) { return pm_acosf(x); }
+static float pf_pm_sin(float x) { return pm_sinf(x); }
+static float pf_pm_cos(float x) { return pm_cosf(x); }
+
+/* one line (row or column) of GapInterpolation: element i of the line lives at index base + i*stride */
+static uint64_t gap_line(float* dF, float* nF, float* conf, const uint8_t* gra, size_t base, size_t stride, int len, int gap, float thr,
+                         const pf_math* M) {
+	uint64_t filled = 0;
+	unsigned count = 0;
+	for (int u = 0; u < len; ++u) {
+		const size_t iu = base + (size_t)u * stride;
+		const float depth = dF[iu];
+		if (depth <= 0) { ++count; continue; }
+		if (count == 0) continue;
+		if ((unsigned)u > count) {
+			const int u_first = u - (int)count - 1;
+			const size_t i0 = base + (size_t)u_first * stride;
+			const float depthFirst = dF[i0];
+			int fill = 0;
+			if (count <= (unsigned)gap) {
+				fill = is_depth_similar(depthFirst, depth, thr);                       /* SD.cpp:2320 */
+			} else {
+				const float texture0 = (float)gra[i0], texture1 = (float)gra[iu];      /* SD.cpp:2383-2388 */
+				const float texture_ratio = (texture1 - texture0) / texture0;
+				fill = texture_ratio <= 0.1 || is_depth_similar(depthFirst, depth, thr);
+			}
+			if (fill) {
+				const float diff = (depth - depthFirst) / (float)(count + 1);
+				float d = depthFirst;
+				const float c = conf[i0] < conf[iu] ? conf[i0] : conf[iu];              /* MINF */
+				float dir1[2] = {M->atan2f_(nF[3 * i0 + 1], nF[3 * i0]), M->acosf_(nF[3 * i0 + 2])};      /* Normal2Dir */
+				const float dir2[2] = {M->atan2f_(nF[3 * iu + 1], nF[3 * iu]), M->acosf_(nF[3 * iu + 2])};
+				const float dd[2] = {(dir2[0] - dir1[0]) / (float)(count + 1), (dir2[1] - dir1[1]) / (float)(count + 1)};
+				for (int uc = u - (int)count; uc < u; ++uc) {
+					const size_t ic = base + (size_t)uc * stride;
+					d += diff;
+					dF[ic] = d;
+					dir1[0] += dd[0]; dir1[1] += dd[1];
+					const float siny = M->sinf_(dir1[1]);                                /* Dir2Normal */
+					nF[3 * ic] = M->cosf_(dir1[0]) * siny; nF[3 * ic + 1] = M->sinf_(dir1[0]) * siny; nF[3 * ic + 2] = M->cosf_(dir1[1]);
+					conf[ic] = c;
+					++filled;
+				}
+			}
+		}
+		count = 0;
+	}
+	return filled;
+}
+
+int hcor_postfilter(hcor_depthmap* maps, int n_maps, uint32_t id, const uint8_t* gra, const uint32_t* order, int n_order, int nMinViewsFuse,
+                    float fDepthDiffThreshold, float fNormalDiffDeg, float depthweight, float normalweight, int gap, int mode, uint64_t* n_filled) {
+	if ((int)id >= n_maps || !maps[id].depth || !maps[id].normal) return 1;
+	hcor_depthmap* A = &maps[id];
+	const int W = A->width, H = A->height;
+	const size_t area = (size_t)W * H;
+	const pf_math libm = {atan2f, acosf, sinf, cosf}, pm = {pf_pm_atan2, pf_pm_acos, pf_pm_sin, pf_pm_cos};
+	const pf_math* M = mode == HCOR_ARITH_DEVICE ? &pm : &libm;
+	/* RemoveSmallSegments, fork version: the whole fusion, then the mask of this image (SD.cpp:2048-2275) */
+	hcor_cloud cl;
+	memset(&cl, 0, sizeof cl);
+	cl.claim_image = id;
+	cl.claim_mask = (uint8_t*)calloc(area, 1);
+	hcor_fuse_depthmaps(maps, n_maps, order, n_order, nMinViewsFuse, fDepthDiffThreshold, fNormalDiffDeg, depthweight, normalweight, &cl);
+	float* dF = (float*)malloc(area * sizeof(float));
+	float* nF = (float*)malloc(area * 3 * sizeof(float));
+	for (size_t i = 0; i < area; ++i) {
+		const int on = cl.claim_mask[i];
+		dF[i] = on ? A->depth[i] : 0.f;
+		for (int k = 0; k < 3; ++k) nF[3 * i + k] = on ? A->normal[3 * i + k] : 0.f;
+	}
+	free(cl.claim_mask);
+	/* GapInterpolation (SD.cpp:2280-3001): rows, then columns */
+	const float thr = fDepthDiffThreshold * 2.5f;
+	uint64_t filled = 0;
+	for (int v = 0; v < H; ++v) filled += gap_line(dF, nF, (float*)A->conf, gra, (size_t)v * W, 1, W, gap, thr, M);
+	for (int u = 0; u < W; ++u) filled += gap_line(dF, nF, (float*)A->conf, gra, (size_t)u, (size_t)W, H, gap, thr, M);
+	/* SD.cpp:2989-3000 */
+	for (size_t i = 0; i < area; ++i) {
+		if (dF[i] > 0) A->depth[i] = dF[i];
+		if (nF[3 * i] != 0 || nF[3 * i + 1] != 0 || nF[3 * i + 2] != 0) { float* n = (float*)A->normal + 3 * i; n[0] = nF[3 * i]; n[1] = nF[3 * i + 1]; n[2] = nF[3 * i + 2]; }
+	}
+	free(dF); free(nF);
+	if (n_filled) *n_filled = filled;
+	return 0;
 }

@@ -184,6 +184,9 @@ typedef struct {
 	uint64_t views_capacity, n_view_entries;
 	uint32_t* view_ids;
 	float* view_weights;
+	/* optional: which pixels of image claim_image ended up in a fused point (arrDepthIdx != NO_ID), W*H bytes */
+	uint32_t claim_image;
+	uint8_t* claim_mask;
 } hcor_cloud;
 
 /* MVS::EstimatePointColors (DM.cpp:2125-2161): colour of the closest view of each point, bilinear over 8-bit pixels with every
@@ -196,6 +199,24 @@ void hcor_estimate_point_colors(const hcor_depthmap* maps, int n_maps, uint64_t 
 int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, int n_order,
                         int n_min_views_fuse, float depth_diff_threshold, float normal_diff_deg,
                         float depthweight, float normalweight, hcor_cloud* cloud);
+
+/* The fork's depth-map post-filters, applied to every image after outer iterations 1 and 2 (SD.cpp:3939-3958):
+ *   RemoveSmallSegments as the fork rewrote it (SD.cpp:2048-2275): a complete FuseDepthMaps pass over the current maps of all
+ *     images (it zeroes the estimates fused points occlude, in every image, like the final fusion), after which
+ *     depthMap_fuse / normalMap_fuse = this image's maps restricted to the pixels that ended up in a fused point;
+ *   GapInterpolation (SD.cpp:2280-3001): gaps of depthMap_fuse along rows, then along columns, are filled by linear
+ *     interpolation of depth and of the normal's (atan2, acos) direction when they are at most nIpolGapSize = 7 pixels long and
+ *     their ends agree within 2.5 x fDepthDiffThreshold, or longer and either that or the gradient-map values at the ends differ
+ *     by at most 10 %; the confidence of a filled pixel is the smaller of the two ends'.  Finally depthMap / normalMap take the
+ *     fused-and-filled values wherever those are valid (SD.cpp:2989-3000).
+ * Restated: the row pass SD.cpp:2293-2447 and the column pass SD.cpp:2560-2713 (their live branches; `u == size.x` and
+ * `(u-count) == 0` can not be true inside the loops).  NOT restated: the third, per-pixel pass (SD.cpp:2717-2983): it reads
+ * variables that are never initialised (dir1, dirDiffsum, x1_demin ... at SD.cpp:2745-2760, 2782-2791) and divides by counters
+ * that may be zero, so it has no defined result to match.  gra: the image's u8 gradient map.  mode: HCOR_ARITH_*.
+ * maps[id]'s depth / normal / conf are updated in place; other images' depths may be zeroed by the fusion. */
+int hcor_postfilter(hcor_depthmap* maps, int n_maps, uint32_t id, const uint8_t* gra, const uint32_t* order, int n_order, int n_min_views_fuse,
+                    float depth_diff_threshold, float normal_diff_deg, float depthweight, float normalweight, int gap_size, int mode,
+                    uint64_t* n_filled);
 
 #ifdef __cplusplus
 }

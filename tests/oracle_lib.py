@@ -39,7 +39,8 @@ class Cloud(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("capacity", C.c_uint64), ("xyz", C.POINTER(C.c_float)),
                 ("normal", C.POINTER(C.c_float)), ("bgr", C.POINTER(C.c_uint8)), ("n_views", C.POINTER(C.c_uint32)),
                 ("n_depths", C.c_uint64), ("views_capacity", C.c_uint64), ("n_view_entries", C.c_uint64),
-                ("view_ids", C.POINTER(C.c_uint32)), ("view_weights", C.POINTER(C.c_float))]
+                ("view_ids", C.POINTER(C.c_uint32)), ("view_weights", C.POINTER(C.c_float)), ("claim_image", C.c_uint32),
+                ("claim_mask", C.POINTER(C.c_uint8))]
 
 
 _lib = None
@@ -103,6 +104,9 @@ def lib():
         L.hcor_fuse_depthmaps.restype = C.c_int
         L.hcor_estimate_point_colors.argtypes = [C.POINTER(DepthMap), C.c_int, C.c_uint64, fp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p]
         L.hcor_estimate_point_colors.restype = None
+        L.hcor_postfilter.argtypes = [C.POINTER(DepthMap), C.c_int, C.c_uint32, u8p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_float, C.c_float,
+                                      C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        L.hcor_postfilter.restype = C.c_int
     return _lib
 
 
@@ -249,3 +253,19 @@ def estimate_point_colors(maps, xyz, n_views, view_ids):
     lib().hcor_estimate_point_colors(arr, len(maps), len(x), fptr(x), nv.ctypes.data_as(C.POINTER(C.c_uint32)),
                                      vi.ctypes.data_as(C.POINTER(C.c_uint32)), u8ptr(out))
     return out
+
+
+def postfilter(maps, vid, gra, order, mode=ARITH_DEVICE, n_min_views_fuse=2, thr=0.01, normal_deg=25.0, depthweight=1.0, normalweight=1.0, gap=7):
+    """RemoveSmallSegments (fork) + GapInterpolation on image vid; maps are copied.  Returns (maps' depth copies, normal, conf of vid, n_filled)"""
+    maps = [dict(m) for m in maps]
+    maps[vid]["normal"] = np.ascontiguousarray(maps[vid]["normal"], np.float32).copy()
+    maps[vid]["conf"] = np.ascontiguousarray(maps[vid]["conf"], np.float32).copy()
+    arr, depths = make_depthmaps(maps)
+    arr[vid].normal = fptr(maps[vid]["normal"]); arr[vid].conf = fptr(maps[vid]["conf"])
+    ids = (C.c_uint32 * len(order))(*order)
+    nf = C.c_uint64()
+    g = np.ascontiguousarray(gra, np.uint8)
+    rc = lib().hcor_postfilter(arr, len(maps), vid, u8ptr(g), ids, len(order), n_min_views_fuse, thr, normal_deg, depthweight, normalweight, gap, mode,
+                               C.byref(nf))
+    assert rc == 0
+    return depths, maps[vid]["normal"], maps[vid]["conf"], nf.value

@@ -63,6 +63,7 @@ def test_densify_driver_end_to_end(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Depth-maps fused and filtered" in r.stdout
+    assert "Depth-maps filtered after outer iteration 1" in r.stdout     # the fork's post-filters (SceneDensify.cpp:3939-3958)
     # depth maps: DR format, readable, and close to the ground truth on most estimated pixels
     good = 0
     for i, v in enumerate(views):

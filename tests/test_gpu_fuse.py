@@ -154,3 +154,27 @@ def test_fuse_cloud_views_weights_colors_normals(ctx):
     assert ((gn[sub] * ref).sum(1)[well] > 0).mean() > 0.999    # same orientation
     assert np.abs(np.linalg.norm(gn, axis=1) - 1).max() < 1e-5
     assert ((gn * got["normal"]).sum(1) > 0.8).mean() > 0.7     # and they agree with the normals fusion averaged
+
+
+@pytest.mark.parametrize("vid", [0, 2])
+def test_postfilter_bit_exact(ctx, vid):
+    """the fork's RemoveSmallSegments (= a whole fusion pass, then the mask of the pixels that ended up in
+    a fused point) + GapInterpolation (rows, then columns) + merge, SceneDensify.cpp:2048-2275, 2280-3001, applied at :3939-3958.
+    Depth / normal / confidence of the image and the depths the fusion invalidates in the others: bit for bit against the
+    oracle (device-association transcendentals)."""
+    maps, order = make_maps(w=144, h=112, f=130.0, n_views=5, noise=0.002, outliers=0.05, holes=0.12)
+    for m in maps:
+        m["conf"] = np.where(m["depth"] > 0, 1.3 - m["conf"], 0).astype(np.float32)   # between outer iterations conf holds the SCORE
+    upload(ctx, maps)
+    gra = ctx.gradient_map(vid)
+    dd, nd, cd, filled = O.postfilter(maps, vid, gra, order, mode=O.ARITH_DEVICE)
+    got_filled = ctx.postfilter(vid, order)
+    assert got_filled == filled > 100
+    d, n, c = ctx.get_depthmap(vid, with_normal=True)
+    assert np.array_equal(d, dd[vid]) and np.array_equal(n, nd) and np.array_equal(c, cd)
+    for i in range(len(maps)):
+        assert np.array_equal(ctx.get_depthmap(i)[0], dd[i])
+    assert (d > 0).sum() > (maps[vid]["depth"] > 0).sum()           # holes were filled
+    gt = maps[vid]["gt"]
+    newly = (d > 0) & (maps[vid]["depth"] == 0)
+    assert (np.abs(d - gt)[newly] / gt[newly] < 0.02).mean() > 0.8   # and the filled values lie on the surface
