@@ -32,10 +32,33 @@ W, H, FOCAL, N_SRC, SWEEPS, AHW = 1920, 1080, 1600.0, 8, 8, 6
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def host_cores():
+    """the host cores this process can really run on: the scheduler affinity, cut down to the cgroup's CPU quota when there is
+    one (a GPU box hands a one-GPU job a share of its cores; spinning on more threads than that only slows the oracle down)"""
+    if os.environ.get("HCMVS_CPU_THREADS"):
+        return max(1, int(os.environ["HCMVS_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(-(-int(txt[0]) // int(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, -(-q // per)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(n_threads):
     """The CPU oracle (restatement of the reference algorithm, reference arithmetic) on a bounded sample of
     the same workload: ONE unit of it (1920x1080, 8 source views, 7x7, 8 sweeps), row-pipelined over n_threads host
-    threads (about 15 s on 16 cores)."""
+    threads (about 15 s on 16 cores; `cores` in the result is the thread count actually used = all cores of the box's share)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
@@ -49,33 +72,75 @@ def cpu_baseline(n_threads):
     dmin = ctypes.c_float(); dmax = ctypes.c_float()
     L.hcor_splat_init(ctypes.byref(ref), O.fptr(pts), len(pts), O.fptr(d0), O.fptr(n0), ctypes.byref(dmin),
                       ctypes.byref(dmax))
+    # a job on a shared box may see more cores than it is given time on (the row-pipelined oracle busy-waits between rows, so
+    # oversubscription is costly): a 2-second probe on a quarter-size image picks the thread count that is actually fastest
+    visible = n_threads
+    cands = sorted({min(visible, c) for c in (8, 16, 32, 64, 128, visible)})
+    if len(cands) > 1:
+        sv = synth.make_views(480, 270, FOCAL / 4, N_SRC, seed=2)
+        sd0 = np.zeros((270, 480), np.float32); sn0 = np.zeros((270, 480, 3), np.float32)
+        best = None
+        for c in cands:
+            pp = O.default_params(adapthalfwin=AHW, n_estimation_iters=1, arith_mode=O.ARITH_REFERENCE, order=O.ORDER_ROWS, n_threads=c)
+            t0 = time.time()
+            O.estimate(sv, pp, 5.0, 15.0, sd0, sn0)
+            dtc = time.time() - t0
+            if best is None or dtc < best[0]:
+                best = (dtc, c)
+            if dtc > 4 * best[0]:
+                break
+        n_threads = best[1]
     p = O.default_params(adapthalfwin=AHW, n_estimation_iters=SWEEPS, arith_mode=O.ARITH_REFERENCE,
                          order=O.ORDER_ROWS, n_threads=n_threads)
     t0 = time.time()
     O.estimate(views, p, dmin.value, dmax.value, d0, n0)
     dt = time.time() - t0
     return {"value": round(w * h / dt / 1e6, 4), "unit": "Mpix/s", "cores": n_threads, "kind": "port",
-            "sample": "one unit of the workload: %dx%d synthetic scene, 8 source views, 7x7 taps, 8 sweeps, one full estimate (%.1f s)" % (w, h, dt)}
+            "sample": "one unit of the workload: %dx%d synthetic scene, 8 source views, 7x7 taps, 8 sweeps, one full estimate (%.1f s) on %d threads "
+                      "(%d cores visible to the process; the count is the fastest of a short probe)" % (w, h, dt, n_threads, visible)}
 
 
-def fuse_throughput(ctx, n_views=8):
-    """Secondary figure of BASELINE.json's metric: FuseDepthMaps (SceneDensify.cpp:3265-3495) points/s on a ring of
-    n_views 1080p views whose maps are the synthetic ground truth with noise, outliers and holes; maps and images are
-    resident on the device, the cloud is copied back to the host inside the timed call."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from fusion_scene import make_maps
-    maps, order = make_maps(w=W, h=H, f=FOCAL, n_views=n_views, noise=0.002, outliers=0.03, holes=0.05)
-    out = {"views": "%d x %dx%d" % (n_views, W, H)}
-    for mode, name in ((0, "raster_order"), (1, "hashed_order")):  # hcmvs_set_fuse_order: 0 = the reference's order, bit-exact
+def fuse_throughput(ctx, views, pts, dev):
+    """Secondary figure of BASELINE.json's metric: FuseDepthMaps (SceneDensify.cpp:3265-3495) points/s on ESTIMATED maps: the
+    nine 1080p views of one synthetic scene are each estimated as the reference image against the other eight (7x7, 8 sweeps,
+    one batch), then fused (every view has the other eight as neighbours).  Maps and images are resident on the device, the
+    cloud is copied back to the host inside the timed call.  raster_order = the reference's pixel order (cloud identical to the
+    sequential algorithm's), hashed_order = hcmvs_set_fuse_order(1)."""
+    import numpy as np
+    import torch
+    binding = importlib.import_module("hc-mvs_amd.binding")
+    n = len(views)
+    HW = H * W
+    for i, v in enumerate(views):
+        g8 = np.clip(np.rint(v["gray"] * 255), 0, 255).astype(np.uint8)
+        ctx.upload_view(9000 + i, v["gray"], v["K"], v["R"], v["C"], bgr=np.stack([g8, g8, g8], -1).copy())
+    work = torch.zeros(n, 5 * HW, dtype=torch.float32, device=dev)
+    items, rng = [], []
+    for i in range(n):
+        d0, n0, dmin, dmax = ctx.splat_init(9000 + i, pts)
+        work[i, :HW] = torch.from_numpy(d0).reshape(-1).to(dev); work[i, HW:4 * HW] = torch.from_numpy(n0).reshape(-1).to(dev)
+        base = work[i].data_ptr()
+        items.append(dict(ref_id=9000 + i, src_ids=[9000 + j for j in range(n) if j != i], d_min=dmin, d_max=dmax, d_depth=base,
+                          d_normal=base + 4 * HW, d_conf=base + 16 * HW, seed_offset=100 + i))
+        rng.append((dmin, dmax))
+    p = binding.default_params(adapthalfwin=AHW, n_estimation_iters=SWEEPS, seed=777)
+    torch.cuda.synchronize()
+    ctx.estimate_batch_device(items, p)
+    ctx.synchronize()
+    est = work.clone()
+    out = {"views": "%d x %dx%d, estimated maps (7x7, 8 sweeps), 8 neighbours each" % (n, W, H)}
+    for mode, name in ((0, "raster_order"), (1, "hashed_order")):
         ctx.set_fuse_order(mode)
         best = None
         for _ in range(2):
-            for i, m in enumerate(maps):
-                ctx.upload_view(9000 + i, m["gray"], m["K"], m["R"], m["C"], bgr=m["bgr"])
-                ctx.set_depthmap(9000 + i, m["depth"], m["normal"], m["conf"], m["d_min"], m["d_max"])
-                ctx.set_neighbors(9000 + i, [9000 + j for j in m["neighbors"][:8]])
+            work.copy_(est)                                      # fusion mutates the depth maps
+            for i in range(n):
+                base = work[i].data_ptr()
+                ctx.set_depthmap_device(9000 + i, base, base + 4 * HW, base + 16 * HW, rng[i][0], rng[i][1])
+                ctx.set_neighbors(9000 + i, [9000 + j for j in range(n) if j != i])
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
-            got = ctx.fuse([9000 + i for i in order], W * H * n_views // 2)
+            got = ctx.fuse([9000 + i for i in range(n)], HW * n // 2)
             dt = time.perf_counter() - t0
             if best is None or dt < best[0]:
                 best = (dt, got["n_points"], got["n_depths"])
@@ -85,13 +150,29 @@ def fuse_throughput(ctx, n_views=8):
     return out
 
 
+def copy_bandwidth(dev):
+    """measured device copy bandwidth (read + write) of a 1 GiB float4 stream, beside the 8 TB/s spec"""
+    import torch
+    a = torch.empty(1 << 28, dtype=torch.float32, device=dev).fill_(1.0); b = torch.empty_like(a)
+    best = 0.0
+    for _ in range(4):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); b.copy_(a); e1.record(); torch.cuda.synchronize()
+        best = max(best, 2.0 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    return round(best, 1)
+
+
+PMC_FILE = "r02_pmc.json"
+
+
 def pmc_value(batch, what):
     """Per-launch counter totals of the sweep kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r01_pmc_hbm.json, made by tests/prof_bench.sh + profiles/summarize_pmc.py): `hbm_bytes` = FETCH_SIZE +
-    WRITE_SIZE, `valu_insts` = SQ_INSTS_VALU.  PMC counters cannot be collected from inside the process, so the
-    value is null for any other batch size."""
+    (profiles/r02_pmc.json, made by tools/prof_bench.sh + profiles/summarize_pmc.py): `hbm_bytes` = FETCH_SIZE + WRITE_SIZE,
+    `valu_insts` = SQ_INSTS_VALU, `valu_busy_quadcycles` = SQ_ACTIVE_INST_VALU.  PMC counters cannot be collected from inside the
+    process (rocprofv3 wraps it), so these are the committed measurement of the same command, not this run's; null for any
+    other batch size."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             return json.load(f).get("sweep_kernel_batch%d_%s_per_launch" % (batch, what))
     except OSError:
         return None
@@ -201,6 +282,7 @@ def main():
     single()
     t1 = time.perf_counter(); single()
     single_ms = (time.perf_counter() - t1) * 1e3
+    st1 = ctx.stats()  # the single unit's own kernel times and evaluation counts
 
     if rank == 0:
         P = (W - 14) * (H - 14)
@@ -232,18 +314,42 @@ def main():
             "kernel_ms": {"score_pass": round(st.ms_score, 3), "sweep_avg": round(st.ms_sweep_avg, 3),
                           "sweeps_total": round(st.ms_sweeps, 3), "end": round(st.ms_end, 3),
                           "estimate_total": round(st.ms_total, 3)},
+            # SURVEY.md 8d convention: tap-gather ALGORITHMIC bytes (every bilinear sample counts its 4 texels) over the HBM peak.
+            # The gather is served by L2 (see hbm_measured_frac): what actually bounds the kernel is the vector ALU (valu block).
             "roofline": {"kernel": "sweep_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": pmc_value(B, "hbm_bytes"),
                          "compulsory_bytes_per_launch": int(B * P * (4 * N_SRC + 4 + 40)),
-                         "valu_insts_per_launch": pmc_value(B, "valu_insts"),
                          "algorithmic_bytes_per_launch": int(bytes_sweep),
                          "avg_launch_ms": round(st.ms_sweep_avg, 3)},
         }
+        traffic = pmc_value(B, "hbm_bytes")
+        if traffic:
+            out["roofline"]["hbm_measured_frac"] = round(traffic / (st.ms_sweep_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        out["roofline"]["copy_bandwidth_measured_GBs"] = copy_bandwidth(dev)
+        vi, vb = pmc_value(B, "valu_insts"), pmc_value(B, "valu_busy_quadcycles")
+        if vi:
+            simd_cycles = 1024 * 2.4e9 * st.ms_sweep_avg * 1e-3   # 256 CUs x 4 SIMDs at the 2.4 GHz the kernel holds (GRBM_GUI_ACTIVE)
+            out["valu"] = {"insts_per_launch": vi, "insts_per_pixel_sweep": round(vi / (B * P), 1),
+                           # the guide's rate for plain f32 ops: a wave64 VALU instruction occupies the SIMD for 2 cycles
+                           "valu_issue_frac": round(vi * 2 / simd_cycles, 4),
+                           # measured on this chip (tools/valu_issue_bench.hip): fma/mul 2.3-2.8 cycles, logic 3.0, DPP / med3 / cvt /
+                           # mul24 / readlane / f64 4.2-4.7, rcp 8.2 -> this kernel's mix averages about 3 cycles per instruction
+                           "valu_pipe_frac_at_3_cycles": round(vi * 3 / simd_cycles, 4),
+                           "valu_busy_frac_rocprof_4_cycles": round(vb * 4 / simd_cycles, 4) if vb else None,
+                           "fp32_TFLOPs_if_1p6_flop_per_lane_inst": round(vi * 64 * 1.6 / (st.ms_sweep_avg * 1e-3) / 1e12, 1)}
+        # the same roofline figure for ONE image alone (SURVEY.md 8d's literal `t` = one complete estimate): latency-bound by
+        # the (W + H) x T_pixel critical path of its row wavefront
+        taps_a1 = int(np.where(ctx.gradient_map(0)[7:H - 7, 7:W - 7] > 100, 36, (AHW + 1) ** 2).astype(np.int64).sum())
+        bytes_1 = (int(st1.tap_evals) - taps_a1) / SWEEPS * N_SRC * 16.0 + P * 44.0
+        out["roofline_single_unit"] = {"kernel": "sweep_kernel (2 waves per row)", "bound": "hbm",
+                                       "achieved": round(bytes_1 / (st1.ms_sweep_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(bytes_1 / (st1.ms_sweep_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "avg_launch_ms": round(st1.ms_sweep_avg, 3), "estimate_ms": round(st1.ms_total, 2)}
         if world == 1 and not args.no_fuse:
-            out["fuse"] = fuse_throughput(ctx)
+            out["fuse"] = fuse_throughput(ctx, scenes[0][0], scenes[0][1], dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))
+            out["cpu_baseline"] = cpu_baseline(host_cores())   # every host core this process may use
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -73,6 +73,7 @@ struct hcmvs_ctx {
 	bool haveStats = false;
 	int sweepLag = 1;
 	int fuseOrder = 0; // hcmvs_set_fuse_order
+	int bandWorker = 0;  // HCMVS_BAND=1: the 8-row band worker for batches (pm_kernels.hip band_kernel)
 	int xcdAffinity = 1; // rows of an image prefer the workgroups of one XCD (HCMVS_XCD_AFFINITY=0 turns it off)
 	// filter / fuse scratch
 	DevMap* dMaps = nullptr; size_t capMaps = 0;
@@ -184,6 +185,8 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 	}
 	const char* lag = getenv("HCMVS_SWEEP_LAG");
 	if (lag && atoi(lag) >= 1) c->sweepLag = atoi(lag);
+	const char* bw = getenv("HCMVS_BAND");
+	if (bw) c->bandWorker = atoi(bw) != 0;
 	const char* aff = getenv("HCMVS_XCD_AFFINITY");
 	if (aff) c->xcdAffinity = atoi(aff) != 0;
 	const char* wpr = getenv("HCMVS_WAVES_PER_ROW"); // tuning knob: 1, 2, 3 or 4 waves cooperate on one image row
@@ -529,8 +532,21 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 		HIPCHK(c, hipMemsetAsync(c->sync + 16, 0, sizeof(int32_t) * kMaxBatch, s)); // the tickets; the error word stays sticky
 		for (int i = 0; i < n_items; ++i)
 			HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * c->hItems[i].border) * kProgressStride * sizeof(int32_t), s));
-		launch_sweep(c->dItems, n_items, maxRows, totalRows, items[0].n_src, p->adapthalfwin > kHalfWindow, sy, iter, c->sweepLag,
-		             c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : 2), c->xcdAffinity, s);
+		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : 2);
+		// the band worker serves the throughput case: 5..8 source views, patches up to 8 x 8 taps, at most 8 neighbour slots per
+		// pixel (4 at outer iteration 0; the cross pattern has 4 * ceil(halfwin / step), DepthMap.cpp:1071-1078), one wave per row
+		bool useBand = c->bandWorker && nw == 1 && hcmvs::segments_for(items[0].n_src) == 8 && p->adapthalfwin <= kHalfWindow;
+		if (useBand && p->it_external >= 1) {
+			const int step = p->propagate_step > 0 ? p->propagate_step : 1;
+			const int hw = std::min(7, std::max(5, p->propagate_halfwin));
+			useBand = (hw - 1) / step + 1 <= 2;
+		}
+		if (useBand) {
+			int totalBands = 0;
+			for (int i = 0; i < n_items; ++i) totalBands += (c->hItems[i].H - 2 * c->hItems[i].border + 7) / 8;
+			launch_band_sweep(c->dItems, n_items, totalBands, sy, iter, c->xcdAffinity, s);
+		} else
+			launch_sweep(c->dItems, n_items, maxRows, totalRows, items[0].n_src, p->adapthalfwin > kHalfWindow, sy, iter, c->sweepLag, nw, c->xcdAffinity, s);
 	}
 	HIPCHK(c, hipEventRecord(c->ev[2], s));
 	for (int i = 0; i < n_items; ++i)

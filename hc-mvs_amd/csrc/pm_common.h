@@ -74,6 +74,8 @@ void launch_score_pass(const EstConst& c, const float* depthIn, const float* nor
                        hipStream_t s);
 void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int lag,
                   int wavesPerRow, int affinity, hipStream_t s);
+// band worker (5..8 views, patches up to 8 x 8 taps, at most 8 neighbour slots): one wave per band of 8 rows
+void launch_band_sweep(const EstConst* dItems, int nItems, int totalBands, const SweepSync& sync, int iter, int affinity, hipStream_t s);
 void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s);
 
 } // namespace hcmvs

@@ -2,7 +2,7 @@
 """Condense the rocprofv3 outputs of tests/prof_bench.sh into the two files kept under profiles/:
    python3 profiles/summarize_pmc.py gpurun_out/<tag> r01 [batch]
 -> profiles/r01_bench_kernel_stats.csv (copy of the --kernel-trace --stats summary)
--> profiles/r01_pmc_hbm.json (per kernel: launches and mean per launch of every counter; FETCH_SIZE / WRITE_SIZE are
+-> profiles/<tag>_pmc.json (per kernel: launches and mean per launch of every counter; FETCH_SIZE / WRITE_SIZE are
    reported by rocprofv3 in KiB -- checked against import_kernel, which writes exactly 20 B/px = 40500 KiB at 1080p)"""
 import csv
 import glob
@@ -31,12 +31,12 @@ out = {"command": "rocprofv3 --pmc <counter> --output-format csv -- python3 benc
 for k, cs in sorted(acc.items()):
     out["counters"][k] = {c: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for c, v in sorted(cs.items())}
 for k, cs in out["counters"].items():
-    if "sweep_kernel<8, 1>" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+    if "sweep_kernel<8, 1" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         out["sweep_kernel_batch%d_hbm_bytes_per_launch" % batch] = int((cs["FETCH_SIZE"]["mean_per_launch"] + cs["WRITE_SIZE"]["mean_per_launch"]) * 1024)
-    if "sweep_kernel<8, 1>" in k and "SQ_INSTS_VALU" in cs:
+    if "sweep_kernel<8, 1" in k and "SQ_INSTS_VALU" in cs:
         out["sweep_kernel_batch%d_valu_insts_per_launch" % batch] = int(cs["SQ_INSTS_VALU"]["mean_per_launch"])
         out["sweep_kernel_batch%d_valu_busy_quadcycles_per_launch" % batch] = int(cs["SQ_ACTIVE_INST_VALU"]["mean_per_launch"])
-json.dump(out, open("profiles/%s_pmc_hbm.json" % tag, "w"), indent=1)
+json.dump(out, open("profiles/%s_pmc.json" % tag, "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k not in ("counters",)}, indent=1))
 for k, cs in out["counters"].items():
     print(k, {c: round(v["mean_per_launch"]) for c, v in cs.items()})
