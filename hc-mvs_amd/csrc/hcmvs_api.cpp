@@ -25,7 +25,7 @@ using namespace hcmvs;
 
 namespace {
 
-constexpr int kMaxBatch = 32; // reference images estimated by one call
+constexpr int kMaxBatch = HCMVS_MAX_BATCH; // reference images estimated by one call
 
 struct View {
 	int w = 0, h = 0;
@@ -179,7 +179,7 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 		if (hipEventCreate(&e) != hipSuccess) { delete c; return HCMVS_ERR_NO_DEVICE; }
 	c->hViews.resize((size_t)kMaxBatch * kMaxViews); c->hItems.resize(kMaxBatch);
 	if (hipMalloc(&c->dViews, sizeof(DevView) * kMaxViews * kMaxBatch) != hipSuccess || hipMalloc(&c->evals, 32) != hipSuccess ||
-	    hipMalloc(&c->dItems, sizeof(EstConst) * kMaxBatch) != hipSuccess || hipMalloc(&c->sync, 256) != hipSuccess) {
+	    hipMalloc(&c->dItems, sizeof(EstConst) * kMaxBatch) != hipSuccess || hipMalloc(&c->sync, 64 + sizeof(int32_t) * kMaxBatch) != hipSuccess) {
 		delete c;
 		return HCMVS_ERR_NO_DEVICE;
 	}
@@ -513,7 +513,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 	HIPCHK(c, hipMemcpyAsync(c->dViews, c->hViews.data(), sizeof(DevView) * kMaxViews * n_items, hipMemcpyHostToDevice, s));
 	HIPCHK(c, hipMemcpyAsync(c->dItems, c->hItems.data(), sizeof(EstConst) * n_items, hipMemcpyHostToDevice, s));
 	HIPCHK(c, hipMemsetAsync(c->evals, 0, 32, s));
-	HIPCHK(c, hipMemsetAsync(c->sync, 0, 256, s));
+	HIPCHK(c, hipMemsetAsync(c->sync, 0, 64 + sizeof(int32_t) * kMaxBatch, s));
 
 	HIPCHK(c, hipEventRecord(c->ev[0], s));
 	for (int i = 0; i < n_items; ++i) {

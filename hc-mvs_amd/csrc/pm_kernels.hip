@@ -539,8 +539,7 @@ __device__ __forceinline__ void make_homography(const EstConst& c, const float (
 // DepthMap.cpp:522-606 ScorePixelImage up to the ZNCC sums, all views at once: every lane warps and samples its taps of
 // its own view through H (the homography of the lane's view), the partial sums are combined inside the view group.
 // (1) warp every tap, (2) issue all loads, (3) interpolate + accumulate.  The inside-the-image test (Types.h:1633-1635)
-// is done once on the min/max of the warped coordinates; texel addresses are clamped into the image, so taps that fall
-// outside read valid memory and only raise `viewBad`.
+// is done once on the min/max of the warped coordinates; a lane with a tap outside skips (2) and (3) altogether.
 // NR: as in fill_patch_n -- steps >= NR are zero-weight repeats of step NR - 1 in every lane and are skipped; the grouped
 // reciprocal still multiplies the repeated denominators, so every remaining tap gets the same bits as with all steps.
 template <int S, int NR, class ST>
@@ -549,8 +548,7 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 	constexpr int MAXM = NR;
 	float Ppy[64 / S];
 	st.get_py(Ppy);
-	float fx[MAXM], fy[MAXM];
-	unsigned off[MAXM];
+	float qx[MAXM], qy[MAXM];
 	bool bad;
 	{
 		float Xx[MAXM], Xy[MAXM], Xz[MAXM], iz[MAXM];
@@ -611,46 +609,49 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 		float qxlo = __builtin_huge_valf(), qxhi = -__builtin_huge_valf(), qylo = __builtin_huge_valf(), qyhi = -__builtin_huge_valf();
 #pragma unroll
 		for (int m = 0; m < MAXM; ++m) {
-			const float qx = Xx[m] * iz[m], qy = Xy[m] * iz[m];
-			qxlo = fminf(qxlo, qx); qxhi = fmaxf(qxhi, qx); qylo = fminf(qylo, qy); qyhi = fmaxf(qyhi, qy);
-			// top-left texel clamped into the image (one v_med3_f32 each; same integer as clamping after the
-			// conversion, and a NaN gives 0)
-			const int lx = (int)__builtin_amdgcn_fmed3f(qx, 0.f, L.wmax), ly = (int)__builtin_amdgcn_fmed3f(qy, 0.f, L.hmax);
-			fx[m] = __builtin_amdgcn_fractf(qx);
-			fy[m] = __builtin_amdgcn_fractf(qy);
-			off[m] = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 2);
+			qx[m] = Xx[m] * iz[m]; qy[m] = Xy[m] * iz[m];
+			qxlo = fminf(qxlo, qx[m]); qxhi = fmaxf(qxhi, qx[m]); qylo = fminf(qylo, qy[m]); qyhi = fmaxf(qyhi, qy[m]);
 		}
 		bad = nan || !(qxlo >= 1.f && qylo >= 1.f && qxhi <= L.wmax && qyhi <= L.hmax);
 	}
-	float2 top[MAXM], bot[MAXM];
-	const HC_GLOBAL char* imgBase = as_global(c.imgBase);
-	const unsigned pitch = (unsigned)L.iw << 2;
-#pragma unroll
-	for (int m = 0; m < MAXM; ++m) {
-#if defined(HCMVS_ABL) && HCMVS_ABL == 1 /* diagnostic ablation: no gather loads (results are wrong) */
-		const float fake = (float)(off[m] & 255u) * (1.f / 255.f);
-		top[m] = make_float2(fake, fake * 0.9f);
-		bot[m] = make_float2(fake * 0.8f, fake * 0.7f);
-#else
-		const f32x2 tv = *(const HC_GLOBAL f32x2*)(imgBase + off[m]);
-		const f32x2 bv = *(const HC_GLOBAL f32x2*)(imgBase + (off[m] + pitch));
-		top[m] = make_float2(tv.x, tv.y);
-		bot[m] = make_float2(bv.x, bv.y);
-#endif
-	}
-	float Pw[64 / S], Ptw[64 / S];
-	st.get_w(Pw, Ptw);
+	// Only lanes whose taps all lie inside the image (Types.h:1633-1635) sample it: their texel addresses need no clamping, and
+	// a lane with a tap outside contributes nothing but the NaN that turns its view's score into thRobust below.
 	float a = 0.f, b2 = 0.f, cnum = 0.f;
+	if (!bad) {
+		float2 top[MAXM], bot[MAXM];
+		float fx[MAXM], fy[MAXM];
+		const HC_GLOBAL char* imgBase = as_global(c.imgBase);
+		const unsigned pitch = (unsigned)L.iw << 2;
 #pragma unroll
-	for (int m = 0; m < MAXM; ++m) {
-		// bilinear sample (Types.inl:2250-2258) in lerp form
-		const float t = fmaf(fx[m], top[m].y - top[m].x, top[m].x);
-		const float b = fmaf(fx[m], bot[m].y - bot[m].x, bot[m].x);
-		const float val = fmaf(fy[m], b - t, t);
-		const float vw = val * Pw[m];
-		a = a + vw;
-		b2 = fmaf(val, vw, b2);
-		cnum = fmaf(val, Ptw[m], cnum);
+		for (int m = 0; m < MAXM; ++m) {
+			const int lx = (int)qx[m], ly = (int)qy[m];
+			fx[m] = __builtin_amdgcn_fractf(qx[m]);
+			fy[m] = __builtin_amdgcn_fractf(qy[m]);
+			const unsigned off = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 2);
+#if defined(HCMVS_ABL) && HCMVS_ABL == 1 /* diagnostic ablation: no gather loads (results are wrong) */
+			const float fake = (float)(off & 255u) * (1.f / 255.f);
+			top[m] = make_float2(fake, fake * 0.9f);
+			bot[m] = make_float2(fake * 0.8f, fake * 0.7f);
+#else
+			const f32x2 tv = *(const HC_GLOBAL f32x2*)(imgBase + off);
+			const f32x2 bv = *(const HC_GLOBAL f32x2*)(imgBase + (off + pitch));
+			top[m] = make_float2(tv.x, tv.y);
+			bot[m] = make_float2(bv.x, bv.y);
+#endif
+		}
+		float Pw[64 / S], Ptw[64 / S];
+		st.get_w(Pw, Ptw);
+#pragma unroll
+		for (int m = 0; m < MAXM; ++m) {
+			// bilinear sample (Types.inl:2250-2258) in lerp form
+			const float t = fmaf(fx[m], top[m].y - top[m].x, top[m].x);
+			const float b = fmaf(fx[m], bot[m].y - bot[m].x, bot[m].x);
+			const float val = fmaf(fy[m], b - t, t);
+			const float vw = val * Pw[m];
+			a = a + vw;
+			b2 = fmaf(val, vw, b2);
+			cnum = fmaf(val, Ptw[m], cnum);
+		}
 	}
 	// a tap outside the image (or a degenerate warp) must turn the view's score into thRobust: the lane poisons its
 	// partial sum, the NaN survives the butterfly and fails the `nrmSq > 0` test of view_score
@@ -1448,7 +1449,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 constexpr int kBandRows = 8;
 struct BandPark { // LDS of one band worker (one wave)
 	float4 vh[8][3];                  // per view: A[0..8], Hm[0..2]
-	float ps[kBandRows][3][8][8];     // per pixel: py | w | tw as [column][row] (the layout score_taps reads)
+	float ps[kBandRows][2][8][8];     // per pixel: w | tw as [column][row] (the layout score_taps reads; py is recomputed)
 	float cl[kBandRows][9][8];        // per pixel: smoothness neighbours, slot k at [.][k]: X0 X1 X2 | n0 n1 n2 | k0 k1 k2
 	float4 hl[8][8][3];               // homographies of the (pair, view) of the current chunk of eight (pixel, hypothesis) pairs
 	float4 acc[8][8];                 // their ZNCC sums
@@ -1456,20 +1457,23 @@ struct BandPark { // LDS of one band worker (one wave)
 };
 struct BandStore { // what score_taps / fill_patch_64 need, pointed at one pixel of the band
 	BandPark* pk;
-	int pix;
+	int pix, y, a;   // the pixel's image row and half window: the taps' image rows are y - a + 2 * min(row, a)
 	__device__ __forceinline__ int opaque(int v) const { asm volatile("" : "+v"(v)); return v; }
-	__device__ __forceinline__ void put_patch64(int row, int col, float py_, float w_, float tw_) {
-		pk->ps[pix][0][col][row] = py_; pk->ps[pix][1][col][row] = w_; pk->ps[pix][2][col][row] = tw_;
+	__device__ __forceinline__ void put_patch64(int row, int col, float, float w_, float tw_) {
+		pk->ps[pix][0][col][row] = w_; pk->ps[pix][1][col][row] = tw_;
 	}
 	__device__ __forceinline__ void get_col(int k, int os, float (&v)[8]) const {
 		const float4* q = (const float4*)&pk->ps[pix][k][os][0];
 		const float4 a = q[0], b = q[1];
 		v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 	}
-	__device__ __forceinline__ void get_py(float (&o)[8]) const { get_col(0, opaque((int)(threadIdx.x & 7)), o); }
+	__device__ __forceinline__ void get_py(float (&o)[8]) const {
+#pragma unroll
+		for (int m = 0; m < 8; ++m) o[m] = (float)(y - a + 2 * (m < a ? m : a)); // as fill_patch_64 stores it
+	}
 	__device__ __forceinline__ void get_w(float (&w_)[8], float (&tw_)[8]) const {
 		const int os = opaque((int)(threadIdx.x & 7));
-		get_col(1, os, w_); get_col(2, os, tw_);
+		get_col(0, os, w_); get_col(1, os, tw_);
 	}
 };
 
@@ -1508,7 +1512,10 @@ __device__ __forceinline__ void group_argmin(float& v, int& i) {
 #undef HC_AM
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3))) void band_kernel(const EstConst* __restrict__ items, int nItems, SweepSync sy,
+#ifndef HCMVS_BAND_OCC
+#define HCMVS_BAND_OCC 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HCMVS_BAND_OCC, HCMVS_BAND_OCC))) void band_kernel(const EstConst* __restrict__ items, int nItems, SweepSync sy,
                                                                                               int iter, int affinity) {
 	__shared__ BandPark park;
 	__shared__ int shRow, shItem;
@@ -1627,28 +1634,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3))) void
 			// ---- patch weights of the eight pixels (fill_patch_64 per pixel, all 64 lanes) ----
 			const int a = tx > 100.f ? 5 : c.adapthalfwin;
 			float invSumW = 1.f, normSq0 = 0.f;
-			float Itap[kBandRows];
 			const unsigned long long actMask = __ballot(act);
 #pragma unroll
-			for (int p = 0; p < kBandRows; ++p) { // all tap loads first
-				Itap[p] = 0.f;
-				if ((actMask >> (8 * p)) & 1ull) {
-					const int xp = rli(x, 8 * p), yp = rli(y, 8 * p), ap = rli(a, 8 * p);
-					const int row = lane >> 3, col = lane & 7;
-					const int i = -ap + 2 * (row < ap ? row : ap), j = -ap + 2 * (col < ap ? col : ap);
-					Itap[p] = ((gcfptr)c.ref)[__mul24(yp + i, W) + (xp + j)];
-				}
-			}
+			for (int p4 = 0; p4 < kBandRows; p4 += 4) { // four pixels at a time: their tap loads first, then the weights
+				float Itap[4];
 #pragma unroll
-			for (int p = 0; p < kBandRows; ++p) {
-				if (!((actMask >> (8 * p)) & 1ull)) continue;
-				const int xp = rli(x, 8 * p), yp = rli(y, 8 * p), ap = rli(a, 8 * p);
-				PixIn<8> in;
-				in.I[0] = Itap[p]; in.center = rlf(center, 8 * p);
-				Patch<8> Pp;
-				BandStore bs; bs.pk = &park; bs.pix = p;
-				fill_patch_64(c, L, xp, yp, ap, in, Pp, bs);
-				if (pix == p) { invSumW = Pp.invSumW; normSq0 = Pp.normSq0; }
+				for (int u = 0; u < 4; ++u) {
+					const int p = p4 + u;
+					Itap[u] = 0.f;
+					if ((actMask >> (8 * p)) & 1ull) {
+						const int xp = rli(x, 8 * p), yp = rli(y, 8 * p), ap = rli(a, 8 * p);
+						const int row = lane >> 3, col = lane & 7;
+						const int i = -ap + 2 * (row < ap ? row : ap), j = -ap + 2 * (col < ap ? col : ap);
+						Itap[u] = ((gcfptr)c.ref)[__mul24(yp + i, W) + (xp + j)];
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const int p = p4 + u;
+					if (!((actMask >> (8 * p)) & 1ull)) continue;
+					const int xp = rli(x, 8 * p), yp = rli(y, 8 * p), ap = rli(a, 8 * p);
+					PixIn<8> in;
+					in.I[0] = Itap[u]; in.center = rlf(center, 8 * p);
+					Patch<8> Pp;
+					BandStore bs; bs.pk = &park; bs.pix = p; bs.y = yp; bs.a = ap;
+					fill_patch_64(c, L, xp, yp, ap, in, Pp, bs);
+					if (pix == p) { invSumW = Pp.invSumW; normSq0 = Pp.normSq0; }
+				}
 			}
 			// ---- slots -> Close (lane (p, k) = slot k of pixel p) ----
 			PixelGeom G;
@@ -1795,11 +1807,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3))) void
 						int g = 0;
 						for (unsigned long long td = chunk; td; td &= td - 1ull, ++g) {
 							const int pl = __builtin_ctzll(td), pp_ = pl >> 3;
-							const int xp = rli(x, 8 * pp_), ap = rli(a, 8 * pp_);
+							const int xp = rli(x, 8 * pp_), yp = rli(y, 8 * pp_), ap = rli(a, 8 * pp_);
 							Patch<8> Pp;
 							Pp.a = ap; Pp.x = xp; Pp.y = 0; Pp.sumW = Pp.invSumW = Pp.normSq0 = 0.f;
 							Pp.px0 = (float)(xp - ap + 2 * (L.seg < ap ? L.seg : ap));
-							BandStore bs; bs.pk = &park; bs.pix = pp_;
+							BandStore bs; bs.pk = &park; bs.pix = pp_; bs.y = yp; bs.a = ap;
 							float Hh[9];
 							{
 								const float4 a_ = park.hl[g][L.view][0], b_ = park.hl[g][L.view][1], cc = park.hl[g][L.view][2];

@@ -512,7 +512,7 @@ int main(int argc, char** argv) {
 	if (o.workdir.empty()) o.workdir = dirname_of(o.input);
 	if (o.output.empty()) o.output = o.input.substr(0, o.input.rfind('.')) + "_dense.mvs";
 	if (o.batch < 1) o.batch = 1;
-	if (o.batch > 32) o.batch = 32;
+	if (o.batch > HCMVS_MAX_BATCH) o.batch = HCMVS_MAX_BATCH;
 
 	std::vector<MvsPlatform> platforms; std::vector<MvsImage> mimages; std::vector<Vertex> verts;
 	if (!load_mvs(o.input, platforms, mimages, verts)) { fprintf(stderr, "error: can not load '%s'\n", o.input.c_str()); return EXIT_FAILURE; }

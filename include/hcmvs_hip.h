@@ -132,7 +132,7 @@ int hcmvs_estimate_device(hcmvs_ctx* ctx, uint32_t ref_id, const uint32_t* src_i
  * other's wavefront ramps (the reference overlaps images with two worker threads, SceneDensify.cpp:3699).
  * Every item produces exactly the maps hcmvs_estimate_device would produce for it with seed + seed_offset.
  * 1 <= n_items <= HCMVS_MAX_BATCH. */
-#define HCMVS_MAX_BATCH 32
+#define HCMVS_MAX_BATCH 64
 typedef struct {
 	uint32_t ref_id;
 	const uint32_t* src_ids;
