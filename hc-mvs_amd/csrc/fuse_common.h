@@ -32,7 +32,8 @@ void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsig
                         int nMinViewsAdjust, float thr, float* newDepth, float* newConf, unsigned long long* counters, hipStream_t s);
 // per-pass tables of image A (sized for the largest image / neighbour count of the call)
 struct FuseTables {
-	int32_t* targets;    // [w*h][nNeighbors]: pixel index A's pixel projects onto in neighbour q, -1 for none (SceneDensify.cpp:3387-3393)
+	int32_t* targets;    // [w*h][nNeighbors]: pixel index A's pixel projects onto in neighbour q (SceneDensify.cpp:3387-3393) + what it can do there
+	                     // (bits 29-30: merge / in front); -1 when it can do nothing
 	uint32_t* cntT;      // [nNeighbors][stride]: number of pending pixels of A that project onto each neighbour pixel
 	uint32_t* offT;      // exclusive scan of cntT: start of that neighbour pixel's list in `bidders`
 	uint32_t* fillT;     // fill cursors while the lists are written
@@ -47,11 +48,11 @@ FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_
                        uint32_t* nbrList, size_t stride);
 // ctl: 8 words, zero before the pass: [0] queue tail, [1] queue head, [2] pixels decided, [3] error flag, [4] pending pixels
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
-                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, hipStream_t s);
+                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, float thDepth, float normalError, hipStream_t s);
 void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, hipStream_t s);
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
-                      int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, int blocks, hipStream_t s);
+                      uint32_t* merged, int nMinViewsFuse, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, hipStream_t s);
 void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const uint32_t* claim, const uint8_t* gra, float* dF, float* nF,
                        int gap, float thr, unsigned long long* filled, hipStream_t s);
 void launch_point_colors(unsigned long long n, const float* xyz, const unsigned long long* voff, const uint32_t* views, const DevMap* maps, uint8_t* bgr, hipStream_t s);

@@ -212,10 +212,25 @@ __device__ __forceinline__ void list_append(bool pred, int value, uint32_t* list
 	st_u32(&list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))], (uint32_t)value);
 }
 
+// A stored target: the neighbour's pixel index in the low bits, above them what the pixel can do to it.  A target a pixel
+// can neither merge with nor invalidate (projects behind it, or the neighbour's pixel is empty or already part of a point
+// when the pass begins -- neither ever changes back) is not stored at all: it cannot influence anybody.
+constexpr int kTargetShift = 29;
+constexpr int32_t kTargetIndexMask = (1 << kTargetShift) - 1;
+constexpr int kTargetMerge = 1, kTargetInFront = 2;
+
+__device__ __forceinline__ void rotate_normal(const DevMap& M, const float* nm, float* out) { // camera -> world, SceneDensify.cpp:3384
+#pragma unroll
+	for (int k = 0; k < 3; ++k) out[k] = (float)(M.R[0 * 3 + k] * (double)nm[0] + M.R[1 * 3 + k] * (double)nm[1] + M.R[2 * 3 + k] * (double)nm[2]);
+}
+
 // pending pixels of A (valid depth, not yet claimed by an earlier image) -> first candidate list, their targets and the
-// per-target counts
+// per-target counts.  Everything about a (pixel, target) pair that does not depend on the order of the pass is settled
+// here, in parallel: where the pixel projects, and whether it would merge with the neighbour's estimate there (similar
+// depth and normal, SceneDensify.cpp:3400-3404) or lies in front of it (:3418).  The pass itself only has to look at what
+// is left of the target when the pixel's turn comes.
 __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, uint32_t* pending, uint32_t* roundCnt, uint8_t* flag,
-                                  unsigned long long* counters) {
+                                  unsigned long long* counters, float thDepth, float normalError) {
 	const int n = A.w * A.h;
 	unsigned nd = 0;
 	const int nPad = (n + 63) & ~63; // whole waves take part in list_append
@@ -229,14 +244,28 @@ __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, u
 			flag[idx] = 0;
 		}
 		if (pend) {
-			float point[3];
+			float point[3], normal[3] = {0.f, 0.f, -1.f};
 			pixel_point(A, idx, A.depth[idx], point);
+			if (A.normal) rotate_normal(A, A.normal + 3 * (size_t)idx, normal);
 			for (int q = 0; q < A.nNeighbors; ++q) {
 				const DevMap& B = maps[A.neighbors[q]];
 				float ptz; int ib = -1, xB, yB;
-				if (!B.depth || !project_target(B, point, ptz, ib, xB, yB)) ib = -1;
-				tb.targets[(size_t)idx * A.nNeighbors + q] = ib;
-				if (ib >= 0) atomicAdd(&tb.cntT[q * tb.stride + ib], 1u);
+				int32_t t = -1;
+				if (B.depth && project_target(B, point, ptz, ib, xB, yB)) {
+					const float depthB = B.depth[ib];
+					if (depthB != 0.f && B.claim[ib] == NO_ID) {
+						int cls = 0;
+						if (is_depth_similar(ptz, depthB, thDepth)) {
+							float normalB[3] = {0.f, 0.f, -1.f};
+							if (B.normal) rotate_normal(B, B.normal + 3 * (size_t)ib, normalB);
+							if (normal[0] * normalB[0] + normal[1] * normalB[1] + normal[2] * normalB[2] > normalError) cls = kTargetMerge;
+						}
+						if (!cls && ptz < depthB) cls = kTargetInFront;
+						if (cls) t = ib | (cls << kTargetShift);
+					}
+				}
+				tb.targets[(size_t)idx * A.nNeighbors + q] = t;
+				if (t >= 0) atomicAdd(&tb.cntT[q * tb.stride + ib], 1u);
 			}
 		}
 		list_append(pend, idx, pending, roundCnt + 1);
@@ -249,9 +278,9 @@ __global__ void fuse_fill_kernel(int nNb, FuseTables tb, const uint32_t* pending
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint32_t idx = pending[i];
 		for (int q = 0; q < nNb; ++q) {
-			const int ib = tb.targets[(size_t)idx * nNb + q];
-			if (ib < 0) continue;
-			const size_t t = q * tb.stride + ib;
+			const int32_t tg = tb.targets[(size_t)idx * nNb + q];
+			if (tg < 0) continue;
+			const size_t t = q * tb.stride + (size_t)(tg & kTargetIndexMask);
 			tb.bidders[tb.offT[t] + atomicAdd(&tb.fillT[t], 1u)] = idx;
 		}
 	}
@@ -268,9 +297,9 @@ __global__ void fuse_links_kernel(int nNb, FuseTables tb, const uint32_t* pendin
 		uint32_t nLow = 0, nHigh = 0;
 		const uint32_t oLow = write ? tb.offP[idx] : 0u, oHigh = write ? tb.offP[tb.stride + idx] : 0u;
 		for (int q = 0; q < nNb; ++q) {
-			const int ib = tb.targets[(size_t)idx * nNb + q];
-			if (ib < 0) continue;
-			const size_t t = q * tb.stride + ib;
+			const int32_t tg = tb.targets[(size_t)idx * nNb + q];
+			if (tg < 0) continue;
+			const size_t t = q * tb.stride + (size_t)(tg & kTargetIndexMask);
 			const uint32_t o = tb.offT[t], len = tb.cntT[t];
 			for (uint32_t k = 0; k < len; ++k) {
 				const uint32_t b = tb.bidders[o + k];
@@ -291,184 +320,215 @@ struct FusePass {
 	FuseTables tb;
 	uint32_t* queue;         // [pending] append-only ready queue, FS_EMPTY until written
 	uint32_t* ctl;           // [0] queue tail, [1] queue head, [2] pixels decided, [3] error flag, [4] pending (set by fuse_begin)
-	int nMinViewsFuse; float thDepth, normalError;
+	uint32_t* merged;        // [w*h] out: per point, which neighbours' estimates it merged (bit q = neighbour q)
+	uint32_t* levels;        // diagnostic (HCMVS_FUSE_DEBUG), else null: per-pixel depth in the dependence graph, maximum in ctl[5]
+	int nMinViewsFuse;
 };
 #define FS_EMPTY 0xFFFFFFFFu
 
-// The neighbour maps' descriptors are staged in LDS once per launch; the loop of the reference's body over the
-// neighbours is chunked: first the projections of a chunk, then all its loads back to back, then the (sequential) logic.
-constexpr int kFuseChunk = 8;
+// seed of the pass: the pending pixels nobody blocks.  A launch of its own: the pass counts the countdowns down, and a
+// pixel that reaches zero there must not be taken for a seed as well.
+__global__ void fuse_seed_kernel(FuseTables tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl) {
+	const uint32_t nPending = ctl[4];
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nPending; i += gridDim.x * blockDim.x) {
+		const uint32_t idx = pending[i];
+		if (tb.cntP[idx] == 0u) queue[atomicAdd(ctl, 1u)] = idx;
+	}
+}
 
-// MAXV: capacity of the per-pixel view lists (the image itself + its neighbours); 16 covers the reference's cap of 12
-// neighbours (nMaxViews, DepthMap.cpp:73) with fewer registers than the general 32
+// The dataflow pass.  Its run time on estimated maps is the length of the longest dependence chain (a few hundred to a few
+// thousand pixels) times the time of one hop, so a hop carries the order-dependent decision and nothing else -- which of
+// its targets a pixel still finds untouched, hence how many views agree, hence whether it becomes a point and claims /
+// invalidates them (SceneDensify.cpp:3395-3449) -- in four memory round trips:
+//   A  the pixel's stored targets and where its list of dependants lies -- together with the poll of this lane's queue slot;
+//   B  what the targets hold now (agent-scope loads) and the dependants' indices;
+//   C  the drain of my stores (claims, invalidated depths), which the dependants must see;
+//   D  the dependants' countdowns (returning atomics).
+// A pixel whose countdown I bring to zero goes to a ring in LDS and is run by a lane of this wave in the very next
+// iteration; only what exceeds the wave's 64 lanes goes to the global queue, whose slots idle lanes poll.  The points
+// themselves (double-precision sums, colours, normals, view lists) are computed afterwards, in parallel, from the merge
+// masks the pass leaves (fuse_points_kernel).
+constexpr int kFuseRing = 256;
+
+// MAXV: the image itself + its neighbours; 16 covers the reference's cap of 12 neighbours (nMaxViews, DepthMap.cpp:73)
 template <int MAXV>
 __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* maps, FusePass fp, FuseOut out, const uint32_t* pending,
                                                         unsigned long long* counters) {
-	__shared__ DevMap nbs[MAXV - 1];
+	__shared__ float* depthOf[MAXV - 1];
+	__shared__ uint32_t* claimOf[MAXV - 1];
+	__shared__ uint32_t ring[kFuseRing];
+	__shared__ uint32_t ringCnt;
 	const int nNb = A.nNeighbors;
-	{
-		static_assert(sizeof(DevMap) % 4 == 0, "DevMap is copied word by word");
-		constexpr int words = (int)(sizeof(DevMap) / 4);
-		uint32_t* dst = (uint32_t*)nbs;
-		for (int i = threadIdx.x; i < nNb * words; i += blockDim.x) {
-			const int q = i / words, w = i - q * words;
-			dst[i] = ((const uint32_t*)&maps[A.neighbors[q]])[w];
-		}
-		__syncthreads();
-	}
+	const int lane = threadIdx.x;
+	if (lane < nNb) { const DevMap& B = maps[A.neighbors[lane]]; depthOf[lane] = B.depth; claimOf[lane] = B.claim; }
+	if (lane == 0) ringCnt = 0u;
+	__syncthreads();
 	const FuseTables& tb = fp.tb;
 	const uint32_t nPending = fp.ctl[4];
 	uint32_t* const qTail = fp.ctl, *const qHead = fp.ctl + 1, *const nDone = fp.ctl + 2, *const errFlag = fp.ctl + 3;
-	// seed: the pending pixels nobody blocks
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nPending; i += gridDim.x * blockDim.x) {
-		const uint32_t idx = pending[i];
-		if (tb.cntP[idx] == 0u) st_u32(&fp.queue[atomicAdd(qTail, 1u)], idx);
-	}
-	unsigned accepted = 0, decided = 0;
-	uint32_t item = FS_EMPTY, slot = FS_EMPTY; // the pixel I run next; the queue slot I wait on
-	bool finished = false;
+	auto ring_push = [&](uint32_t v) { // a pixel that became ready: to this wave's ring, to the global queue when that is full
+		const uint32_t pos = atomicAdd(&ringCnt, 1u);
+		if (pos < (uint32_t)kFuseRing) ring[pos] = v;
+		else st_u32(&fp.queue[atomicAdd(qTail, 1u)], v);
+	};
+	unsigned accepted = 0, decided = 0, viewEntries = 0;
+	uint32_t item = FS_EMPTY, slot = atomicAdd(qHead, 1u); // the pixel I run next; the queue slot I wait on
 	unsigned spins = 0;
 	for (;;) {
-		if (!finished && item == FS_EMPTY) {
-			if (slot == FS_EMPTY) slot = atomicAdd(qHead, 1u);
-			if (slot < nPending) {
-				const uint32_t v = ld_u32(&fp.queue[slot]);
-				if (v != FS_EMPTY) { item = v; slot = FS_EMPTY; spins = 0; }
-			}
-			if (item == FS_EMPTY) {
-				// nothing for me yet: pixels handed on directly never pass through the queue, so the end of the pass is
-				// "every pending pixel decided", not "my slot is past the end"
-				if (decided) { atomicAdd(nDone, decided); decided = 0; }
-				if (ld_u32(nDone) >= nPending || ld_u32(errFlag) != 0u) finished = true;
-				else if (++spins > (1u << 22)) { st_u32(errFlag, 1u); finished = true; } // bounded: never hang the device
-			}
-		}
-		if (__ballot(!finished) == 0ull) break;
-		if (__ballot(item != FS_EMPTY) == 0ull) { __builtin_amdgcn_s_sleep(8); continue; }
+		uint32_t polled = FS_EMPTY;
+		if (slot < nPending) polled = ld_u32(&fp.queue[slot]);
+		const bool busy = __ballot(item != FS_EMPTY) != 0ull;
 		if (item != FS_EMPTY) {
 			const int idx = (int)item;
 			item = FS_EMPTY;
-			const float depth = A.depth[idx];
-			float point[3];
-			pixel_point(A, idx, depth, point);
-			// the reference's body, SceneDensify.cpp:3364-3450
-			uint32_t vimg[MAXV]; int vpix[MAXV]; float vwt[MAXV]; int nv = 0;
-			vwt[nv] = conf2weight(A.conf[idx], depth); // PointCloud::WeightArr (float), SceneDensify.cpp:3378
-			vimg[nv] = A.id; vpix[nv] = idx; ++nv;
-			double confidence = (double)vwt[0];
-			float normal[3] = {0.f, 0.f, -1.f};
-			if (A.normal) {
-				const float* nm = A.normal + 3 * (size_t)idx;
+			// round trip A
+			const uint32_t relOff = tb.offP[tb.stride + idx], relLen = tb.cntP[tb.stride + idx];
+			const int32_t* tg = tb.targets + (size_t)idx * nNb;
+			int32_t t[MAXV - 1];
 #pragma unroll
-				for (int k = 0; k < 3; ++k) normal[k] = (float)(A.R[0 * 3 + k] * (double)nm[0] + A.R[1 * 3 + k] * (double)nm[1] + A.R[2 * 3 + k] * (double)nm[2]);
+			for (int j = 0; j < MAXV - 1; ++j) t[j] = j < nNb ? tg[j] : -1;
+			// round trip B
+			float dB[MAXV - 1]; uint32_t clB[MAXV - 1];
+#pragma unroll
+			for (int j = 0; j < MAXV - 1; ++j) {
+				dB[j] = 0.f; clB[j] = 0u;
+				if (t[j] < 0) continue;
+				dB[j] = ld_f32(depthOf[j] + (t[j] & kTargetIndexMask));
+				clB[j] = ld_u32(claimOf[j] + (t[j] & kTargetIndexMask));
 			}
-			double X[3] = {(double)point[0] * confidence, (double)point[1] * confidence, (double)point[2] * confidence};
-			float Cc[3] = {0.f, 0.f, 0.f}, Nn[3];
-			if (A.bgr) for (int k = 0; k < 3; ++k) Cc[k] = (float)A.bgr[3 * (size_t)idx + k] * (float)confidence;
-			for (int k = 0; k < 3; ++k) Nn[k] = normal[k] * (float)confidence;
-			uint32_t invImg[MAXV]; int invPix[MAXV]; int ninv = 0;
-			for (int q0 = 0; q0 < nNb; q0 += kFuseChunk) {
-				// what the chunk's targets hold (independent loads; a pixel only changes targets of its own, in other maps)
-				bool ok[kFuseChunk]; int ibs[kFuseChunk], xs[kFuseChunk], ys[kFuseChunk];
-				float ptzs[kFuseChunk], dB[kFuseChunk], cfB[kFuseChunk], nB[kFuseChunk][3];
-				uint32_t clB[kFuseChunk]; uint8_t colB[kFuseChunk][3];
+			uint32_t rel[8];
 #pragma unroll
-				for (int j = 0; j < kFuseChunk; ++j) {
-					ok[j] = false; ibs[j] = 0; xs[j] = ys[j] = 0; ptzs[j] = 0.f;
-					if (q0 + j >= nNb) continue;
-					const DevMap& B = nbs[q0 + j];
-					if (!B.depth) continue;
-					ok[j] = project_target(B, point, ptzs[j], ibs[j], xs[j], ys[j]);
-				}
+			for (int j = 0; j < 8; ++j) rel[j] = (uint32_t)j < relLen ? tb.nbrList[relOff + j] : FS_EMPTY;
+			// the decision (SceneDensify.cpp:3395-3449): targets still empty-handed merge or are invalidated
+			uint32_t merge = 0u, inFront = 0u;
 #pragma unroll
-				for (int j = 0; j < kFuseChunk; ++j) {
-					dB[j] = 0.f; clB[j] = 0u; cfB[j] = 0.f; nB[j][0] = nB[j][1] = 0.f; nB[j][2] = -1.f; colB[j][0] = colB[j][1] = colB[j][2] = 0;
-					if (!ok[j]) continue;
-					const DevMap& B = nbs[q0 + j];
-					dB[j] = ld_f32(&B.depth[ibs[j]]);
-					clB[j] = ld_u32(&B.claim[ibs[j]]);
-					cfB[j] = B.conf[ibs[j]];
-					if (B.normal) { const float* nm = B.normal + 3 * (size_t)ibs[j]; nB[j][0] = nm[0]; nB[j][1] = nm[1]; nB[j][2] = nm[2]; }
-					if (B.bgr) { const uint8_t* cb = B.bgr + 3 * (size_t)ibs[j]; colB[j][0] = cb[0]; colB[j][1] = cb[1]; colB[j][2] = cb[2]; }
-				}
-#pragma unroll
-				for (int j = 0; j < kFuseChunk; ++j) {
-					if (!ok[j]) continue;
-					const DevMap& B = nbs[q0 + j];
-					const uint32_t Bid = B.id;
-					const int ib = ibs[j];
-					const float ptz = ptzs[j], depthB = dB[j];
-					if (depthB == 0.f) continue;
-					if (clB[j] != NO_ID) continue;
-					if (is_depth_similar(ptz, depthB, fp.thDepth)) {
-						float normalB[3] = {0.f, 0.f, -1.f};
-						if (B.normal) {
-#pragma unroll
-							for (int k = 0; k < 3; ++k) normalB[k] = (float)(B.R[0 * 3 + k] * (double)nB[j][0] + B.R[1 * 3 + k] * (double)nB[j][1] + B.R[2 * 3 + k] * (double)nB[j][2]);
-						}
-						if (normal[0] * normalB[0] + normal[1] * normalB[1] + normal[2] * normalB[2] > fp.normalError) {
-							const float confB = conf2weight(cfB[j], depthB);
-							int pos = nv;
-							while (pos > 0 && vimg[pos - 1] > Bid) { vimg[pos] = vimg[pos - 1]; vpix[pos] = vpix[pos - 1]; vwt[pos] = vwt[pos - 1]; --pos; }
-							vimg[pos] = Bid; vpix[pos] = ib; vwt[pos] = confB; ++nv;
-							st_u32(&B.claim[ib], 0u);
-							double XB[3];
-							i2w(B, (double)xs[j], (double)ys[j], (double)depthB, XB);
-							for (int k = 0; k < 3; ++k) X[k] += XB[k] * (double)confB;
-							if (B.bgr) for (int k = 0; k < 3; ++k) Cc[k] += (float)colB[j][k] * confB;
-							for (int k = 0; k < 3; ++k) Nn[k] += normalB[k] * confB;
-							confidence += (double)confB;
-							continue;
-						}
-					}
-					if (ptz < depthB) { invImg[ninv] = Bid; invPix[ninv] = ib; ++ninv; }
-				}
+			for (int j = 0; j < MAXV - 1; ++j) {
+				if (t[j] < 0 || dB[j] == 0.f || clB[j] != NO_ID) continue;
+				if ((t[j] >> kTargetShift) == kTargetMerge) merge |= 1u << j; else inFront |= 1u << j;
 			}
-			if (nv < fp.nMinViewsFuse) {
-				for (int v = 0; v < nv; ++v) st_u32(&maps[vimg[v]].claim[vpix[v]], NO_ID);
-			} else {
+			const int nv = 1 + __builtin_popcount(merge);
+			if (nv >= fp.nMinViewsFuse) { // a point: claim the merged estimates, remove the ones in front of it
 				st_u32(&A.claim[idx], 0u);
-				const double nrm = 1.0 / confidence;
-				for (int k = 0; k < 3; ++k) out.xyz[3 * (size_t)idx + k] = (float)(X[k] * nrm);
-				if (out.bgr) for (int k = 0; k < 3; ++k) {
-					const int c8 = (int)floorf(Cc[k] * (float)nrm + .5f);
-					out.bgr[3 * (size_t)idx + k] = (uint8_t)(c8 < 0 ? 0 : (c8 > 255 ? 255 : c8));
-				}
-				if (out.normal) {
-					const float n0 = Nn[0] * (float)nrm, n1 = Nn[1] * (float)nrm, n2 = Nn[2] * (float)nrm;
-					const float len = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
-					out.normal[3 * (size_t)idx] = n0 / len; out.normal[3 * (size_t)idx + 1] = n1 / len; out.normal[3 * (size_t)idx + 2] = n2 / len;
+#pragma unroll
+				for (int j = 0; j < MAXV - 1; ++j) {
+					if (merge >> j & 1u) st_u32(claimOf[j] + (t[j] & kTargetIndexMask), 0u);
+					if (inFront >> j & 1u) st_f32(depthOf[j] + (t[j] & kTargetIndexMask), 0.f);
 				}
 				out.nviews[idx] = (uint32_t)nv;
-				if (out.views)
-					for (int v = 0; v < nv; ++v) { out.views[(size_t)idx * out.vstride + v] = vimg[v]; out.weights[(size_t)idx * out.vstride + v] = vwt[v]; }
+				fp.merged[idx] = merge;
 				out.flag[idx] = 1;
 				++accepted;
-				for (int v = 0; v < ninv; ++v) st_f32(&maps[invImg[v]].depth[invPix[v]], 0.f);
+				viewEntries += (unsigned)nv;
 			}
-			// decided: my stores must be out before anybody I release looks at them
+			// round trip C -- decided: my stores must be out before anybody I release looks at them
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			++decided;
-			{
-				const uint32_t o = tb.offP[tb.stride + idx], len = tb.cntP[tb.stride + idx];
-				for (uint32_t k0 = 0; k0 < len; k0 += 8) {
-					uint32_t b[8], was[8];
+			if (fp.levels) {
+				const uint32_t lvl = ld_u32(&fp.levels[idx]) + 1u;
+				atomicMax(fp.ctl + 5, lvl);
+				uint32_t sink = 0;
+				for (uint32_t k = 0; k < relLen; ++k) sink += atomicMax(&fp.levels[tb.nbrList[relOff + k]], lvl);
+				asm volatile("" ::"v"(sink));
+			}
+			// round trip D: the countdowns of the pixels I block; whoever reaches zero is ready
+			for (uint32_t k0 = 0; k0 < relLen; k0 += 8) {
+				uint32_t was[8];
+				if (k0) {
 #pragma unroll
-					for (int j = 0; j < 8; ++j) b[j] = k0 + j < len ? tb.nbrList[o + k0 + j] : FS_EMPTY;
-#pragma unroll
-					for (int j = 0; j < 8; ++j) was[j] = b[j] != FS_EMPTY ? atomicSub(&tb.cntP[b[j]], 1u) : 0u;
-#pragma unroll
-					for (int j = 0; j < 8; ++j)
-						if (was[j] == 1u) { // I was its last blocker: it is mine if I have nothing yet, otherwise anybody's
-							if (item == FS_EMPTY) item = b[j];
-							else st_u32(&fp.queue[atomicAdd(qTail, 1u)], b[j]);
-						}
+					for (int j = 0; j < 8; ++j) rel[j] = k0 + j < relLen ? tb.nbrList[relOff + k0 + j] : FS_EMPTY;
 				}
+#pragma unroll
+				for (int j = 0; j < 8; ++j) was[j] = rel[j] != FS_EMPTY ? atomicSub(&tb.cntP[rel[j]], 1u) : 0u;
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					if (was[j] == 1u) ring_push(rel[j]);
 			}
 		}
+		// what arrived through the queue joins the ring; then the ring feeds the lanes (all idle here)
+		if (polled != FS_EMPTY) { ring_push(polled); slot = FS_EMPTY; }
+		__syncthreads();
+		const uint32_t nReady = ringCnt < (uint32_t)kFuseRing ? ringCnt : (uint32_t)kFuseRing;
+		__syncthreads();
+		if (nReady) {
+			if ((uint32_t)lane < nReady) item = ring[lane];
+			for (uint32_t k = 64u + (uint32_t)lane; k < nReady; k += 64u) st_u32(&fp.queue[atomicAdd(qTail, 1u)], ring[k]);
+			__syncthreads();
+			if (lane == 0) ringCnt = 0u;
+			__syncthreads();
+			spins = 0;
+		} else if (!busy) {
+			// an idle wave: pixels handed on inside a wave never pass through the queue, so the end of the pass is "every
+			// pending pixel decided", not "my slot is past the end"
+			if (decided) { atomicAdd(nDone, decided); decided = 0; }
+			const bool over = ld_u32(nDone) >= nPending || ld_u32(errFlag) != 0u;
+			if (__ballot(over) != 0ull) break;
+			if (++spins > (1u << 22)) { st_u32(errFlag, 1u); break; } // bounded: never hang the device
+			__builtin_amdgcn_s_sleep(8);
+		}
+		if (item == FS_EMPTY && slot == FS_EMPTY) slot = atomicAdd(qHead, 1u);
 	}
 	if (decided) atomicAdd(nDone, decided);
-	if (accepted) atomicAdd(&counters[3], (unsigned long long)accepted);
+	if (accepted) { atomicAdd(&counters[3], (unsigned long long)accepted); atomicAdd(&counters[4], (unsigned long long)viewEntries); }
+}
+
+// The points of the pass: position = confidence-weighted mean of the merged estimates, colour, normal, view list
+// (SceneDensify.cpp:3371-3386, 3405-3416, 3425-3446), summed in the neighbour order of the reference loop.  Merged
+// estimates are claimed, so nobody has changed them since the pass looked at them.
+template <int MAXV>
+__global__ void fuse_points_kernel(DevMap A, const DevMap* maps, FuseTables tb, const uint32_t* merged, FuseOut out, const uint32_t* pending,
+                                   const uint32_t* roundCnt) {
+	const int nNb = A.nNeighbors;
+	const int nPending = (int)roundCnt[1];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nPending; i += gridDim.x * blockDim.x) {
+		const int idx = (int)pending[i];
+		if (!out.flag[idx]) continue;
+		const uint32_t merge = merged[idx];
+		const float depth = A.depth[idx];
+		float point[3];
+		pixel_point(A, idx, depth, point);
+		uint32_t vimg[MAXV]; float vwt[MAXV]; int nv = 0;
+		vwt[nv] = conf2weight(A.conf[idx], depth); // PointCloud::WeightArr (float), SceneDensify.cpp:3378
+		vimg[nv] = A.id; ++nv;
+		double confidence = (double)vwt[0];
+		float normal[3] = {0.f, 0.f, -1.f};
+		if (A.normal) rotate_normal(A, A.normal + 3 * (size_t)idx, normal);
+		double X[3] = {(double)point[0] * confidence, (double)point[1] * confidence, (double)point[2] * confidence};
+		float Cc[3] = {0.f, 0.f, 0.f}, Nn[3];
+		if (A.bgr) for (int k = 0; k < 3; ++k) Cc[k] = (float)A.bgr[3 * (size_t)idx + k] * (float)confidence;
+		for (int k = 0; k < 3; ++k) Nn[k] = normal[k] * (float)confidence;
+		for (int q = 0; q < nNb; ++q) {
+			if (!(merge >> q & 1u)) continue;
+			const DevMap& B = maps[A.neighbors[q]];
+			const int ib = tb.targets[(size_t)idx * nNb + q] & kTargetIndexMask;
+			const int yB = ib / B.w, xB = ib - yB * B.w;
+			const float depthB = B.depth[ib];
+			float normalB[3] = {0.f, 0.f, -1.f};
+			if (B.normal) rotate_normal(B, B.normal + 3 * (size_t)ib, normalB);
+			const float confB = conf2weight(B.conf[ib], depthB);
+			int pos = nv;
+			while (pos > 0 && vimg[pos - 1] > B.id) { vimg[pos] = vimg[pos - 1]; vwt[pos] = vwt[pos - 1]; --pos; }
+			vimg[pos] = B.id; vwt[pos] = confB; ++nv;
+			double XB[3];
+			i2w(B, (double)xB, (double)yB, (double)depthB, XB);
+			for (int k = 0; k < 3; ++k) X[k] += XB[k] * (double)confB;
+			if (B.bgr) for (int k = 0; k < 3; ++k) Cc[k] += (float)B.bgr[3 * (size_t)ib + k] * confB;
+			for (int k = 0; k < 3; ++k) Nn[k] += normalB[k] * confB;
+			confidence += (double)confB;
+		}
+		const double nrm = 1.0 / confidence;
+		for (int k = 0; k < 3; ++k) out.xyz[3 * (size_t)idx + k] = (float)(X[k] * nrm);
+		if (out.bgr) for (int k = 0; k < 3; ++k) {
+			const int c8 = (int)floorf(Cc[k] * (float)nrm + .5f);
+			out.bgr[3 * (size_t)idx + k] = (uint8_t)(c8 < 0 ? 0 : (c8 > 255 ? 255 : c8));
+		}
+		if (out.normal) {
+			const float n0 = Nn[0] * (float)nrm, n1 = Nn[1] * (float)nrm, n2 = Nn[2] * (float)nrm;
+			const float len = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
+			out.normal[3 * (size_t)idx] = n0 / len; out.normal[3 * (size_t)idx + 1] = n1 / len; out.normal[3 * (size_t)idx + 2] = n2 / len;
+		}
+		if (out.views)
+			for (int v = 0; v < nv; ++v) { out.views[(size_t)idx * out.vstride + v] = vimg[v]; out.weights[(size_t)idx * out.vstride + v] = vwt[v]; }
+	}
 }
 
 // ordered compaction of the accepted pixels of one pass into the cloud
@@ -649,8 +709,8 @@ FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_
 // begin of an image pass: the pending list (its length in ctl[4]), targets, per-target lists, per-pixel link counts + offsets
 // (cntT / fillT / cntP must be zero).  fuse_links_fill writes the link lists once the host has sized them.
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
-                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, ctl + 3, flag, counters); // roundCnt[1] == ctl[4]
+                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, float thDepth, float normalError, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, ctl + 3, flag, counters, thDepth, normalError); // roundCnt[1] == ctl[4]
 	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntT, tb.offT, (int)(tb.stride * (size_t)A.nNeighbors), s);
 	hipLaunchKernelGGL(fuse_fill_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3);
 	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3, 0, order);
@@ -659,16 +719,20 @@ void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb
 void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, hipStream_t s) {
 	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3, 1, order);
 }
-// the whole image pass in one launch of dataflow workers (one wave per workgroup); any grid size is correct
+// the whole image pass in one launch of dataflow workers (one wave per workgroup; any grid size is correct), then the points
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
-                      int nMinViewsFuse, float thDepth, float normalError, unsigned long long* counters, int blocks, hipStream_t s) {
+                      uint32_t* merged, int nMinViewsFuse, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, hipStream_t s) {
 	FuseOut out{oxyz, onormal, obgr, onv, oflag, oviews, oweights, vstride};
 	FusePass fp;
-	fp.tb = tb; fp.queue = queue; fp.ctl = ctl;
-	fp.nMinViewsFuse = nMinViewsFuse; fp.thDepth = thDepth; fp.normalError = normalError;
+	fp.tb = tb; fp.queue = queue; fp.ctl = ctl; fp.merged = merged; fp.levels = levels;
+	fp.nMinViewsFuse = nMinViewsFuse;
+	hipLaunchKernelGGL(fuse_seed_kernel, kGrid, kBlock, 0, s, tb, pending, queue, ctl);
 	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_pass_kernel<16>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
 	else hipLaunchKernelGGL(fuse_pass_kernel<32>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
+	if (!wantPoints) return;
+	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_points_kernel<16>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + 3);
+	else hipLaunchKernelGGL(fuse_points_kernel<32>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + 3);
 }
 size_t fuse_scan_temp_bytes(int n) {
 	size_t bytes = 0;

@@ -19,6 +19,10 @@
 #include <map>
 #include <string>
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 using namespace hcmvs;
@@ -43,6 +47,12 @@ struct View {
 };
 
 } // namespace
+
+struct FuseLane { // one concurrent fusion pass: its stream, per-pass tables and link lists (hcmvs_fuse_cloud)
+	hipStream_t stream = nullptr;
+	char* scratch = nullptr; size_t cap = 0;
+	uint32_t* links = nullptr; size_t capLinks = 0;
+};
 
 struct hcmvs_ctx {
 	int device = 0;
@@ -79,7 +89,7 @@ struct hcmvs_ctx {
 	DevMap* dMaps = nullptr; size_t capMaps = 0;
 	unsigned long long* counters = nullptr;
 	void* fuseScratch = nullptr; size_t capFuseScratch = 0;
-	uint32_t* fuseLinks = nullptr; size_t capFuseLinks = 0; // per-pixel link lists of the fuse pass (grown to the exact size)
+	std::vector<FuseLane> fuseLanes; // per-pass scratch of the concurrent fusion passes
 	bool errPending = false; // an estimate was enqueued since the error word was last read
 	int wavesPerRow = 0; // 0 = automatic: 2 waves per row for small batches (latency), 1 when >= 3 images fill the chip
 };
@@ -215,8 +225,13 @@ void hcmvs_destroy(hcmvs_ctx* c) {
 	for (auto& kv : c->views) free_view(kv.second);
 	for (auto& sl : c->slots) for (void* p : {(void*)sl.dn, (void*)sl.conf, (void*)sl.tmpDepth, (void*)sl.progress, (void*)sl.srcSlab}) if (p) (void)hipFree(p);
 	for (void* p : {(void*)c->tmpU8, (void*)c->sDepth, (void*)c->sNormal, (void*)c->sConf, (void*)c->dViews, (void*)c->dItems, (void*)c->sync,
-	                (void*)c->evals, (void*)c->dMaps, (void*)c->counters, c->fuseScratch, (void*)c->fuseLinks})
+	                (void*)c->evals, (void*)c->dMaps, (void*)c->counters, c->fuseScratch})
 		if (p) (void)hipFree(p);
+	for (auto& L : c->fuseLanes) {
+		if (L.scratch) (void)hipFree(L.scratch);
+		if (L.links) (void)hipFree(L.links);
+		if (L.stream) (void)hipStreamDestroy(L.stream);
+	}
 	for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
 	delete c;
@@ -855,46 +870,36 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	}
 	hipStream_t s = c->stream;
 	for (auto& m : host) if (m.depth) { launch_fill_u32(m.claim, 0xFFFFFFFFu, (size_t)m.w * m.h, s); }
-	// per-pass scratch (sized for the largest image) + device cloud
 	int maxNb = 1;
 	size_t stride = maxArea; // pixels reserved per neighbour map in the per-target tables
-	for (int i = 0; i < n_order; ++i) {
-		const DevMap& A = host[order[i]];
-		maxNb = std::max(maxNb, (int)A.nNeighbors);
-	}
+	for (int i = 0; i < n_order; ++i) maxNb = std::max(maxNb, (int)host[order[i]].nNeighbors);
 	for (const auto& m : host) if (m.depth) stride = std::max(stride, (size_t)m.w * m.h);
 	const size_t tblElems = stride * (size_t)maxNb;
+	if (stride >= ((size_t)1 << 29)) return fail(c, HCMVS_ERR_CAPACITY, "fuse: maps of %zu pixels exceed the target tables (2^29 pixels)", stride);
 	if (tblElems > 0x7FFFFFFFull) return fail(c, HCMVS_ERR_CAPACITY, "fuse: %d neighbours of %zu pixels exceed the per-pass tables", maxNb, stride);
 	const size_t scanBytes = (std::max({fuse_scan_temp_bytes((int)maxArea), fuse_scan_temp_bytes((int)tblElems), fuse_scan_temp_bytes((int)(2 * stride))}) + 255) & ~(size_t)255;
 	size_t off = 0;
 	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+	// the device cloud (context scratch) ...
+	const size_t oCX = carve(wantCloud ? capacity * 12 : 0), oCN = carve(normal ? capacity * 12 : 0), oCB = carve(bgr ? capacity * 3 : 0),
+	             oCV = carve(n_views || viewCapacity ? capacity * 4 : 0), oCVI = carve(viewCapacity * 4), oCVW = carve(viewCapacity * 4);
+	rc = ensure_scratch(c, std::max(off, (size_t)256));
+	if (rc) return rc;
+	char* cb = (char*)c->fuseScratch;
+	float* cX = (float*)(cb + oCX); float* cN = normal ? (float*)(cb + oCN) : nullptr; uint8_t* cB = bgr ? (uint8_t*)(cb + oCB) : nullptr;
+	uint32_t* cV = n_views || viewCapacity ? (uint32_t*)(cb + oCV) : nullptr;
+	uint32_t* cVI = viewCapacity ? (uint32_t*)(cb + oCVI) : nullptr; float* cVW = viewCapacity ? (float*)(cb + oCVW) : nullptr;
+	// ... and the per-pass scratch of one lane (sized for the largest image)
+	off = 0;
 	const size_t oPending = carve(maxArea * 4), oQueue = carve(maxArea * 4), oTgt = carve(maxArea * 4 * (size_t)maxNb),
 	             oCntT = carve(tblElems * 4), oFillT = carve(tblElems * 4), oCntP = carve(stride * 8), oOffT = carve(tblElems * 4), oOffP = carve(stride * 8),
-	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(64),
+	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(64), oCounters = carve(64), oMerged = carve(maxArea * 4),
 	             oFlag = carve(maxArea), oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
 	             oXyz = carve(maxArea * 12), oNrm = carve(maxArea * 12), oBgr = carve(maxArea * 3), oNv = carve(maxArea * 4),
 	             oPV = carve(viewCapacity ? maxArea * 4 * (size_t)(maxNb + 1) : 0), oPW = carve(viewCapacity ? maxArea * 4 * (size_t)(maxNb + 1) : 0),
-	             oVoff = carve(viewCapacity ? maxArea * 4 : 0),
-	             oCX = carve(wantCloud ? capacity * 12 : 0), oCN = carve(normal ? capacity * 12 : 0), oCB = carve(bgr ? capacity * 3 : 0), oCV = carve(n_views || viewCapacity ? capacity * 4 : 0),
-	             oCVI = carve(viewCapacity * 4), oCVW = carve(viewCapacity * 4);
-	rc = ensure_scratch(c, off);
-	if (rc) return rc;
-	char* b = (char*)c->fuseScratch;
-	uint32_t* pendingList = (uint32_t*)(b + oPending); uint32_t* queue = (uint32_t*)(b + oQueue);
-	uint32_t* ctl = (uint32_t*)(b + oCtl);
-	int32_t* targets = (int32_t*)(b + oTgt);
-	uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders),
-	         *cntP = (uint32_t*)(b + oCntP), *offP = (uint32_t*)(b + oOffP);
-	uint8_t* flag = (uint8_t*)(b + oFlag);
-	uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos);
-	float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
-	float* cX = (float*)(b + oCX); float* cN = normal ? (float*)(b + oCN) : nullptr; uint8_t* cB = bgr ? (uint8_t*)(b + oCB) : nullptr;
-	uint32_t* cV = n_views || viewCapacity ? (uint32_t*)(b + oCV) : nullptr;
-	uint32_t* pviews = viewCapacity ? (uint32_t*)(b + oPV) : nullptr; float* pweights = viewCapacity ? (float*)(b + oPW) : nullptr;
-	uint32_t* voff = viewCapacity ? (uint32_t*)(b + oVoff) : nullptr;
-	uint32_t* cVI = viewCapacity ? (uint32_t*)(b + oCVI) : nullptr; float* cVW = viewCapacity ? (float*)(b + oCVW) : nullptr;
+	             oVoff = carve(viewCapacity ? maxArea * 4 : 0);
+	const size_t laneBytes = off;
 	const int vstride = maxNb + 1;
-	unsigned long long viewTotal = 0;
 	const float normalError = cosf(normal_diff_deg * normalweight * (3.14159274101257324f / 180.f)); // SceneDensify.cpp:3310
 	const float thDepth = depth_diff_threshold * depthweight;                                       // SceneDensify.cpp:3400
 	// dataflow workers: one wave per workgroup, a few per CU; any number is correct (no co-residency assumption)
@@ -903,64 +908,183 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	const int nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
 	int blocks = nCU * 4;
 	if (getenv("HCMVS_FUSE_BLOCKS")) blocks = std::min(nCU * 16, std::max(1, atoi(getenv("HCMVS_FUSE_BLOCKS"))));
-	unsigned long long total = 0, depths = 0;
-	for (int oi = 0; oi < n_order; ++oi) { // best connected images first (SceneDensify.cpp:3302, order given by the caller)
-		const DevMap& A = host[order[oi]];
-		const int n = A.w * A.h;
-		HIPCHK(c, hipMemsetAsync(c->counters, 0, 64, s));
-		HIPCHK(c, hipMemsetAsync(ctl, 0, 64, s));
-		HIPCHK(c, hipMemsetAsync(queue, 0xFF, (size_t)n * 4, s));                             // FS_EMPTY
-		HIPCHK(c, hipMemsetAsync(cntT, 0, (oOffT - oCntT), s));                               // per-target counts, fill cursors, per-pixel link counts
-		FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, cntP, offP, c->fuseLinks, stride);
-		launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, c->counters, c->fuseOrder, s);
-		uint32_t lastOff = 0, lastCnt = 0; // total size of the link lists = last offset + last count
-		HIPCHK(c, hipMemcpyAsync(&lastOff, offP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, s));
-		HIPCHK(c, hipMemcpyAsync(&lastCnt, cntP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, s));
-		HIPCHK(c, hipStreamSynchronize(s));
-		// the link lists hold, per pending pixel, every other pending pixel that shares a target with it: their total is
-		// only known now (a neighbour seen at a much coarser scale collects many pixels per target), so the buffer grows
-		// to the exact size instead of failing (the reference's FuseDepthMaps has no such limit)
-		const size_t links = (size_t)lastOff + lastCnt;
-		if (links > c->capFuseLinks) {
-			if (c->fuseLinks) (void)hipFree(c->fuseLinks);
-			c->fuseLinks = nullptr; c->capFuseLinks = 0;
-			const size_t want = std::max(links + links / 4, (size_t)1 << 20);
-			HIPCHK(c, hipMalloc(&c->fuseLinks, want * 4));
-			c->capFuseLinks = want;
-			tb.nbrList = c->fuseLinks;
+
+	// The pass of an image reads and writes its own maps and those of its neighbours, nothing else.  Two images whose
+	// touched sets are disjoint commute, so their passes run side by side on separate streams ("lanes"); an image waits
+	// only for the earlier images of the fusion order it shares a map with, and the cloud keeps the order of the
+	// sequential loop (SceneDensify.cpp:3302): a pass reports its point count, and its compaction writes at the
+	// offset the counts of all earlier images add up to.
+	std::vector<std::vector<uint32_t>> touched((size_t)n_order);
+	for (int i = 0; i < n_order; ++i) {
+		auto& t = touched[i];
+		t.push_back(order[i]);
+		for (uint32_t nb : c->views.find(order[i])->second.neighbors) t.push_back(nb);
+		std::sort(t.begin(), t.end());
+		t.erase(std::unique(t.begin(), t.end()), t.end());
+	}
+	std::vector<std::vector<int>> deps((size_t)n_order);
+	for (int i = 0; i < n_order; ++i)
+		for (int j = 0; j < i; ++j) {
+			const auto &ti = touched[i], &tj = touched[j];
+			size_t a = 0, b2 = 0; bool hit = false;
+			while (a < ti.size() && b2 < tj.size()) { if (ti[a] == tj[b2]) { hit = true; break; } if (ti[a] < tj[b2]) ++a; else ++b2; }
+			if (hit) deps[i].push_back(j);
 		}
-		launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, s);
-		launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
-		                 n_min_views_fuse, thDepth, normalError, c->counters, blocks, s);
-		unsigned long long cnt[4];
-		uint32_t ctlWords[5] = {0, 0, 0, 0, 0};
-		HIPCHK(c, hipMemcpyAsync(cnt, c->counters, 32, hipMemcpyDeviceToHost, s));
-		HIPCHK(c, hipMemcpyAsync(ctlWords, ctl, 20, hipMemcpyDeviceToHost, s));
-		HIPCHK(c, hipStreamSynchronize(s));
-		if (ctlWords[3] != 0 || ctlWords[2] != ctlWords[4]) {
-			// a worker gave up waiting (never expected): the claim and depth maps are half updated -- say so, the caller must
-			// not reuse them
-			return fail(c, HCMVS_ERR_TIMEOUT, "fuse: the pass of image %u stalled (%u of %u pixels decided); the registered depth maps are left partially fused",
-			            A.id, ctlWords[2], ctlWords[4]);
+	int nLanes = std::min(n_order, 4);
+	if (getenv("HCMVS_FUSE_LANES")) nLanes = std::min(n_order, std::min(16, std::max(1, atoi(getenv("HCMVS_FUSE_LANES")))));
+	if (c->fuseLanes.size() < (size_t)nLanes) c->fuseLanes.resize((size_t)nLanes);
+	for (int k = 0; k < nLanes; ++k) {
+		FuseLane& L = c->fuseLanes[k];
+		if (!L.stream) HIPCHK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+		if (L.cap < laneBytes) {
+			if (L.scratch) (void)hipFree(L.scratch);
+			L.scratch = nullptr; L.cap = 0;
+			HIPCHK(c, hipMalloc(&L.scratch, laneBytes));
+			L.cap = laneBytes;
 		}
-		if (getenv("HCMVS_FUSE_DEBUG")) fprintf(stderr, "fuse: image %u: %u pending pixels, %u through the queue, %llu accepted\n", A.id, ctlWords[4], ctlWords[0], cnt[3]);
-		depths += cnt[0];
-		const unsigned long long accepted = cnt[3];
-		if (wantCloud && total + accepted > capacity) return fail(c, HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity);
-		if (accepted && wantCloud) {
-			launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, total, capacity, cX, cN, cB, cV, pviews, pweights, vstride,
-			                    voff, viewTotal, viewCapacity, cVI, cVW, s);
-			if (viewCapacity) { // this image's share of the view lists = last offset + last count
-				uint32_t lo = 0, ln = 0;
-				HIPCHK(c, hipMemcpyAsync(&lo, voff + (n - 1), 4, hipMemcpyDeviceToHost, s));
-				HIPCHK(c, hipMemcpyAsync(&ln, flag32 + (n - 1), 4, hipMemcpyDeviceToHost, s));
-				HIPCHK(c, hipStreamSynchronize(s));
-				viewTotal += (unsigned long long)lo + ln;
-				if (viewTotal > viewCapacity) return fail(c, HCMVS_ERR_CAPACITY, "fuse: view-list capacity %llu exceeded", (unsigned long long)viewCapacity);
+	}
+	HIPCHK(c, hipStreamSynchronize(s)); // claims reset, tables uploaded: the lanes may start
+
+	struct Shared {
+		std::mutex mu; std::condition_variable cv;
+		std::vector<int> state;                       // 0 waiting, 1 running, 2 pass finished (counts known), 3 compacted
+		std::vector<unsigned long long> accepted, entries;
+		unsigned long long depths = 0;
+		int rc = 0; std::string msg;
+	} sh;
+	sh.state.assign((size_t)n_order, 0); sh.accepted.assign((size_t)n_order, 0); sh.entries.assign((size_t)n_order, 0);
+	auto laneFail = [&](int code, const char* fmt, ...) {
+		char buf[512];
+		va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+		std::lock_guard<std::mutex> g(sh.mu);
+		if (!sh.rc) { sh.rc = code; sh.msg = buf; }
+		sh.cv.notify_all();
+	};
+	const bool debug = getenv("HCMVS_FUSE_DEBUG") != nullptr;
+	auto worker = [&](int k) {
+		FuseLane& L = c->fuseLanes[k];
+		hipStream_t ls = L.stream;
+		if (hipSetDevice(c->device) != hipSuccess) { laneFail(HCMVS_ERR_HIP, "fuse: hipSetDevice failed in a lane"); return; }
+#define LANECHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { laneFail(HCMVS_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); return; } } while (0)
+		char* b = L.scratch;
+		uint32_t* pendingList = (uint32_t*)(b + oPending); uint32_t* queue = (uint32_t*)(b + oQueue);
+		uint32_t* ctl = (uint32_t*)(b + oCtl);
+		unsigned long long* counters = (unsigned long long*)(b + oCounters);
+		int32_t* targets = (int32_t*)(b + oTgt);
+		uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders),
+		         *cntP = (uint32_t*)(b + oCntP), *offP = (uint32_t*)(b + oOffP);
+		uint8_t* flag = (uint8_t*)(b + oFlag);
+		uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos); uint32_t* merged = (uint32_t*)(b + oMerged);
+		float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
+		uint32_t* pviews = viewCapacity ? (uint32_t*)(b + oPV) : nullptr; float* pweights = viewCapacity ? (float*)(b + oPW) : nullptr;
+		uint32_t* voff = viewCapacity ? (uint32_t*)(b + oVoff) : nullptr;
+		for (;;) {
+			int oi = -1;
+			{ // the first image of the order that has not started and whose earlier conflicting images have finished their passes
+				std::unique_lock<std::mutex> g(sh.mu);
+				for (;;) {
+					if (sh.rc) return;
+					bool anyLeft = false;
+					for (int i = 0; i < n_order && oi < 0; ++i) {
+						if (sh.state[i] != 0) continue;
+						anyLeft = true;
+						bool ready = true;
+						for (int j : deps[i]) if (sh.state[j] < 2) { ready = false; break; }
+						if (ready) oi = i;
+					}
+					if (oi >= 0) { sh.state[oi] = 1; break; }
+					if (!anyLeft) return;
+					sh.cv.wait(g);
+				}
+			}
+			const DevMap& A = host[order[oi]];
+			const int n = A.w * A.h;
+			LANECHK(hipMemsetAsync(counters, 0, 64, ls));
+			LANECHK(hipMemsetAsync(ctl, 0, 64, ls));
+			LANECHK(hipMemsetAsync(queue, 0xFF, (size_t)n * 4, ls));                             // FS_EMPTY
+			LANECHK(hipMemsetAsync(cntT, 0, (oOffT - oCntT), ls));                               // per-target counts, fill cursors, per-pixel link counts
+			FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, cntP, offP, L.links, stride);
+			launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, c->fuseOrder, thDepth, normalError, ls);
+			uint32_t lastOff = 0, lastCnt = 0; // total size of the link lists = last offset + last count
+			LANECHK(hipMemcpyAsync(&lastOff, offP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, ls));
+			LANECHK(hipMemcpyAsync(&lastCnt, cntP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, ls));
+			LANECHK(hipStreamSynchronize(ls));
+			// the link lists hold, per pending pixel, every other pending pixel that shares a target with it: their total is
+			// only known now (a neighbour seen at a much coarser scale collects many pixels per target), so the buffer grows
+			// to the exact size instead of failing (the reference's FuseDepthMaps has no such limit)
+			const size_t links = (size_t)lastOff + lastCnt;
+			if (links > L.capLinks) {
+				if (L.links) (void)hipFree(L.links);
+				L.links = nullptr; L.capLinks = 0;
+				const size_t want = std::max(links + links / 4, (size_t)1 << 20);
+				LANECHK(hipMalloc(&L.links, want * 4));
+				L.capLinks = want;
+				tb.nbrList = L.links;
+			}
+			launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, ls);
+			if (debug) LANECHK(hipMemsetAsync(flag32, 0, (size_t)n * 4, ls)); // diagnostic: dependence depth per pixel (the buffer is free until the compaction)
+			const auto tPass = std::chrono::steady_clock::now();
+			launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
+			                 merged, n_min_views_fuse, counters, blocks, debug ? flag32 : nullptr, wantCloud, ls);
+			unsigned long long cnt[5] = {0, 0, 0, 0, 0};
+			uint32_t ctlWords[6] = {0, 0, 0, 0, 0, 0};
+			LANECHK(hipMemcpyAsync(cnt, counters, 40, hipMemcpyDeviceToHost, ls));
+			LANECHK(hipMemcpyAsync(ctlWords, ctl, 24, hipMemcpyDeviceToHost, ls));
+			LANECHK(hipStreamSynchronize(ls));
+			if (ctlWords[3] != 0 || ctlWords[2] != ctlWords[4]) {
+				// a worker gave up waiting (never expected): the claim and depth maps are half updated -- say so, the caller must
+				// not reuse them
+				laneFail(HCMVS_ERR_TIMEOUT, "fuse: the pass of image %u stalled (%u of %u pixels decided); the registered depth maps are left partially fused",
+				         A.id, ctlWords[2], ctlWords[4]);
+				return;
+			}
+			if (debug) {
+				const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tPass).count();
+				fprintf(stderr, "fuse: lane %d image %u: %u pending pixels, %u through the queue, %llu accepted; dependence depth %u, pass %.0f us = %.2f us per level\n",
+				        k, A.id, ctlWords[4], ctlWords[0], cnt[3], ctlWords[5], us, us / std::max(1u, ctlWords[5]));
+			}
+			unsigned long long total = 0, viewTotal = 0;
+			{ // publish the counts; wait until every earlier image has published its own -> this image's place in the cloud
+				std::unique_lock<std::mutex> g(sh.mu);
+				sh.accepted[oi] = cnt[3]; sh.entries[oi] = cnt[4]; sh.depths += cnt[0];
+				sh.state[oi] = 2;
+				sh.cv.notify_all();
+				for (;;) {
+					if (sh.rc) return;
+					bool known = true;
+					for (int j = 0; j < oi; ++j) if (sh.state[j] < 2) { known = false; break; }
+					if (known) break;
+					sh.cv.wait(g);
+				}
+				for (int j = 0; j < oi; ++j) { total += sh.accepted[j]; viewTotal += sh.entries[j]; }
+			}
+			const unsigned long long accepted = cnt[3];
+			if (wantCloud && total + accepted > capacity) { laneFail(HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity); return; }
+			if (viewCapacity && viewTotal + cnt[4] > viewCapacity) { laneFail(HCMVS_ERR_CAPACITY, "fuse: view-list capacity %llu exceeded", (unsigned long long)viewCapacity); return; }
+			if (accepted && wantCloud) {
+				launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, total, capacity, cX, cN, cB, cV, pviews, pweights, vstride,
+				                    voff, viewTotal, viewCapacity, cVI, cVW, ls);
+				LANECHK(hipStreamSynchronize(ls));
+			}
+			{
+				std::lock_guard<std::mutex> g(sh.mu);
+				sh.state[oi] = 3;
+				sh.cv.notify_all();
 			}
 		}
-		total += accepted;
+#undef LANECHK
+	};
+	if (nLanes == 1) worker(0);
+	else {
+		std::vector<std::thread> th;
+		for (int k = 0; k < nLanes; ++k) th.emplace_back(worker, k);
+		for (auto& t : th) t.join();
 	}
+	if (sh.rc) return fail(c, sh.rc, "%s", sh.msg.c_str());
+	unsigned long long total = 0, viewTotal = 0;
+	for (int i = 0; i < n_order; ++i) { total += sh.accepted[i]; viewTotal += wantCloud ? sh.entries[i] : 0; }
+	if (!viewCapacity) viewTotal = 0;
+	const unsigned long long depths = sh.depths;
 	HIPCHK(c, hipGetLastError());
 	if (wantCloud) HIPCHK(c, hipMemcpyAsync(xyz, cX, total * 12, hipMemcpyDeviceToHost, s));
 	if (normal) HIPCHK(c, hipMemcpyAsync(normal, cN, total * 12, hipMemcpyDeviceToHost, s));
