@@ -40,8 +40,8 @@ struct Options { // DensifyPointCloud.cpp:139-198 (defaults from there)
 	float photometricFlow = 0.5f, depthweight = 1.f, normalweight = 1.f;
 	int initTriangulate = 1;      // 1: Delaunay init from the sparse points, 0: read the previous level's maps (SceneDensify.cpp:522-553)
 	int minViewsTrustPoint = 2;   // < 2: splat the sparse points instead (SceneDensify.cpp:783-808)
-	int fuseOrder = 1;            // hcmvs_set_fuse_order: 1 hashed order (few dependent rounds; point count within 1 % of the
-	                              // reference's), 0 reference raster order (bit-exact cloud, ~10x slower on dense scenes)
+	int fuseOrder = 0;            // hcmvs_set_fuse_order: 0 the reference's raster order (its cloud, point for point), 1 hashed order
+	                              // (shorter dependence chains; point count within 1 % of the reference's)
 	int estimateColors = 2, estimateNormals = 2;   // 2: during fusion, 1: after it (DepthMap.cpp:2125-2269), 0: none
 	int maxResolution = 3200, minResolution = 640;  // DensifyPointCloud.cpp:144-145
 	int postFilter = 1;           // the fork's RemoveSmallSegments + GapInterpolation after outer iterations 1 and 2 (SceneDensify.cpp:3939-3958)
