@@ -855,6 +855,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	if (cloud->view_ids && !cloud->view_weights) return fail(c, HCMVS_ERR_INVALID, "fuse: view_ids without view_weights");
 	if (!c) return HCMVS_ERR_INVALID;
 	if (!order || n_order < 1 || !n_points) return fail(c, HCMVS_ERR_INVALID, "fuse: bad arguments");
+	const auto tCall = std::chrono::steady_clock::now();
 	const bool wantCloud = xyz != nullptr; // without xyz only the fusion's side effects (claims, invalidated depths) and counts are produced
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -944,6 +945,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 		}
 	}
 	HIPCHK(c, hipStreamSynchronize(s)); // claims reset, tables uploaded: the lanes may start
+	const auto tPasses = std::chrono::steady_clock::now();
 
 	struct Shared {
 		std::mutex mu; std::condition_variable cv;
@@ -1086,6 +1088,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	if (!viewCapacity) viewTotal = 0;
 	const unsigned long long depths = sh.depths;
 	HIPCHK(c, hipGetLastError());
+	const auto tCopy = std::chrono::steady_clock::now();
 	if (wantCloud) HIPCHK(c, hipMemcpyAsync(xyz, cX, total * 12, hipMemcpyDeviceToHost, s));
 	if (normal) HIPCHK(c, hipMemcpyAsync(normal, cN, total * 12, hipMemcpyDeviceToHost, s));
 	if (bgr) HIPCHK(c, hipMemcpyAsync(bgr, cB, total * 3, hipMemcpyDeviceToHost, s));
@@ -1095,6 +1098,12 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 		HIPCHK(c, hipMemcpyAsync(cloud->view_weights, cVW, viewTotal * 4, hipMemcpyDeviceToHost, s));
 	}
 	HIPCHK(c, hipStreamSynchronize(s));
+	if (debug) {
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "fuse: %d images, %llu points: setup %.1f ms, passes %.1f ms, copy of the cloud to the host %.1f ms\n", n_order, total,
+		        std::chrono::duration<double, std::milli>(tPasses - tCall).count(), std::chrono::duration<double, std::milli>(tCopy - tPasses).count(),
+		        std::chrono::duration<double, std::milli>(now - tCopy).count());
+	}
 	*n_points = total;
 	if (n_depths) *n_depths = depths;
 	cloud->n_view_entries = viewTotal;

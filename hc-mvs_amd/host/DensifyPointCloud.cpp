@@ -28,6 +28,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -123,18 +124,43 @@ bool load_mvs(const std::string& path, std::vector<MvsPlatform>& platforms, std:
 	return (bool)r.f;
 }
 
-struct Writer {
+// the fused cloud's arrays: sized for the worst case before the fusion, filled by one copy from the device -- not
+// value-initialised (a std::vector would touch gigabytes that are never used)
+template <typename T>
+struct RawArray {
+	T* p = nullptr; size_t n = 0;
+	explicit RawArray(size_t count) : p(count ? (T*)malloc(count * sizeof(T)) : nullptr), n(p ? count : 0) {}
+	RawArray(const RawArray&) = delete;
+	RawArray& operator=(const RawArray&) = delete;
+	~RawArray() { free(p); }
+	T* data() { return p; }
+	const T* data() const { return p; }
+	size_t size() const { return n; }
+	void shrink(size_t count) { if (count < n) n = count; }
+	void clear() { n = 0; }
+	const T& operator[](size_t i) const { return p[i]; }
+};
+
+struct Writer { // binary output through one large buffer (a vertex is a handful of 4- and 8-byte fields)
 	std::ofstream f;
-	template <typename T> void put(const T& v) { f.write((const char*)&v, sizeof v); }
-	void str(const std::string& s) { put<uint64_t>(s.size()); f.write(s.data(), (std::streamsize)s.size()); }
+	std::vector<char> buf;
+	size_t fill = 0;
+	Writer() : buf((size_t)32 << 20) {}
+	void raw(const void* src, size_t bytes) {
+		if (bytes > buf.size() - fill) { flush(); if (bytes > buf.size()) { f.write((const char*)src, (std::streamsize)bytes); return; } }
+		memcpy(buf.data() + fill, src, bytes); fill += bytes;
+	}
+	void flush() { if (fill) f.write(buf.data(), (std::streamsize)fill); fill = 0; }
+	template <typename T> void put(const T& v) { raw(&v, sizeof v); }
+	void str(const std::string& s) { put<uint64_t>(s.size()); raw(s.data(), s.size()); }
 };
 bool save_mvs(const std::string& path, const std::vector<MvsPlatform>& platforms, const std::vector<MvsImage>& images,
-              const std::vector<float>& xyz, const std::vector<float>& normals, const std::vector<uint8_t>& bgr,
-              const std::vector<uint32_t>& nviews, const std::vector<uint32_t>& viewIds, const std::vector<float>& viewWeights) {
+              const RawArray<float>& xyz, const RawArray<float>& normals, const RawArray<uint8_t>& bgr,
+              const RawArray<uint32_t>& nviews, const RawArray<uint32_t>& viewIds, const RawArray<float>& viewWeights) {
 	Writer w;
 	w.f.open(path, std::ios::binary);
 	if (!w.f) return false;
-	w.f.write("MVSI", 4); w.put<uint32_t>(5); w.put<uint32_t>(0);
+	w.raw("MVSI", 4); w.put<uint32_t>(5); w.put<uint32_t>(0);
 	w.put<uint64_t>(platforms.size());
 	for (const auto& p : platforms) {
 		w.str(p.name);
@@ -142,10 +168,10 @@ bool save_mvs(const std::string& path, const std::vector<MvsPlatform>& platforms
 		for (const auto& c : p.cams) {
 			w.str(c.name); w.str("");
 			w.put(c.w); w.put(c.h);
-			w.f.write((const char*)c.K, 72); w.f.write((const char*)c.R, 72); w.f.write((const char*)c.C, 24);
+			w.raw(c.K, 72); w.raw(c.R, 72); w.raw(c.C, 24);
 		}
 		w.put<uint64_t>(p.poses.size());
-		for (const auto& q : p.poses) { w.f.write((const char*)q.R, 72); w.f.write((const char*)q.C, 24); }
+		for (const auto& q : p.poses) { w.raw(q.R, 72); w.raw(q.C, 24); }
 	}
 	w.put<uint64_t>(images.size());
 	for (const auto& im : images) { w.str(im.name); w.str(""); w.put(im.platformID); w.put(im.cameraID); w.put(im.poseID); w.put(im.ID); }
@@ -153,17 +179,18 @@ bool save_mvs(const std::string& path, const std::vector<MvsPlatform>& platforms
 	w.put<uint64_t>(n);
 	uint64_t vo = 0;
 	for (uint64_t i = 0; i < n; ++i) { // Interface::Vertex = X + views {imageID, confidence} (Interface.h:502-524; Scene.cpp:330-345 stores the weights as confidence)
-		w.f.write((const char*)&xyz[3 * i], 12);
+		w.raw(&xyz[3 * i], 12);
 		const uint64_t nv = i < nviews.size() ? nviews[i] : 0;
 		w.put<uint64_t>(nv);
 		for (uint64_t v = 0; v < nv; ++v) { w.put<uint32_t>(viewIds[vo + v]); w.put<float>(viewWeights[vo + v]); }
 		vo += nv;
 	}
-	w.put<uint64_t>(normals.size() / 3); w.f.write((const char*)normals.data(), (std::streamsize)normals.size() * 4);
-	w.put<uint64_t>(bgr.size() / 3); w.f.write((const char*)bgr.data(), (std::streamsize)bgr.size());
+	w.put<uint64_t>(normals.size() / 3); w.raw(normals.data(), normals.size() * 4);
+	w.put<uint64_t>(bgr.size() / 3); w.raw(bgr.data(), bgr.size());
 	for (int i = 0; i < 3; ++i) w.put<uint64_t>(0);
 	const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-	w.f.write((const char*)eye, sizeof eye);
+	w.raw(eye, sizeof eye);
+	w.flush();
 	return (bool)w.f;
 }
 
@@ -365,21 +392,25 @@ bool save_dmap(const std::string& path, const ImageData& im, const std::vector<f
 	f.close();
 	return std::rename((path + ".tmp").c_str(), path.c_str()) == 0;
 }
-bool save_ply(const std::string& path, const std::vector<float>& xyz, const std::vector<float>& nrm, const std::vector<uint8_t>& bgr) {
-	std::ofstream f(path, std::ios::binary); // PointCloud.cpp:189-240
-	if (!f) return false;
+bool save_ply(const std::string& path, const RawArray<float>& xyz, const RawArray<float>& nrm, const RawArray<uint8_t>& bgr) {
+	Writer w;
+	w.f.open(path, std::ios::binary); // PointCloud.cpp:189-240
+	if (!w.f) return false;
+	std::ostringstream f;
 	const size_t n = xyz.size() / 3;
 	const bool hasN = nrm.size() == xyz.size() && n > 0, hasC = bgr.size() == xyz.size() && n > 0; // PointCloud.cpp:105-128: only what exists
 	f << "ply\nformat binary_little_endian 1.0\nelement vertex " << n << "\nproperty float x\nproperty float y\nproperty float z\n";
 	if (hasN) f << "property float nx\nproperty float ny\nproperty float nz\n";
 	if (hasC) f << "property uchar red\nproperty uchar green\nproperty uchar blue\n";
 	f << "end_header\n";
+	w.raw(f.str().data(), f.str().size());
 	for (size_t i = 0; i < n; ++i) {
-		f.write((const char*)&xyz[3 * i], 12);
-		if (hasN) f.write((const char*)&nrm[3 * i], 12);
-		if (hasC) { const uint8_t rgb[3] = {bgr[3 * i + 2], bgr[3 * i + 1], bgr[3 * i]}; f.write((const char*)rgb, 3); }
+		w.raw(&xyz[3 * i], 12);
+		if (hasN) w.raw(&nrm[3 * i], 12);
+		if (hasC) { const uint8_t rgb[3] = {bgr[3 * i + 2], bgr[3 * i + 1], bgr[3 * i]}; w.raw(rgb, 3); }
 	}
-	return (bool)f;
+	w.flush();
+	return (bool)w.f;
 }
 
 // raw 'DR' depth map written by save_dmap / the reference (Interface.h:634-652); returns false when absent or malformed
@@ -774,8 +805,12 @@ int main(int argc, char** argv) {
 	// the complete PointCloud: points, view lists + weights (PointCloud::pointViews / pointWeights), colours, normals
 	uint64_t viewCapacity = 0;
 	for (uint32_t id : todo) viewCapacity += (uint64_t)images[id].w * images[id].h; // a point merges at most one depth per image
-	std::vector<float> xyz(capacity * 3), nrm(capacity * 3); std::vector<uint8_t> bgr(capacity * 3); std::vector<uint32_t> nviews(capacity);
-	std::vector<uint32_t> viewIds(viewCapacity); std::vector<float> viewWeights(viewCapacity);
+	RawArray<float> xyz(capacity * 3), nrm(capacity * 3); RawArray<uint8_t> bgr(capacity * 3); RawArray<uint32_t> nviews(capacity);
+	RawArray<uint32_t> viewIds(viewCapacity); RawArray<float> viewWeights(viewCapacity);
+	if (capacity && (!xyz.data() || !nrm.data() || !bgr.data() || !nviews.data() || !viewIds.data() || !viewWeights.data())) {
+		fprintf(stderr, "error: out of host memory for a cloud of up to %llu points\n", (unsigned long long)capacity);
+		return EXIT_FAILURE;
+	}
 	uint64_t nPoints = 0, nDepths = 0;
 	CHK(hcmvs_set_fuse_order(ctx, o.fuseOrder));
 	hcmvs_cloud cl;
@@ -785,8 +820,8 @@ int main(int argc, char** argv) {
 	CHK(hcmvs_fuse_cloud(ctx, order.data(), (int32_t)order.size(), std::min<int>(o.numberViewsFuse, (int)images.size()), 0.01f, 25.f, o.depthweight,
 	                     o.normalweight, &cl));
 	nPoints = cl.n_points; nDepths = cl.n_depths;
-	xyz.resize(nPoints * 3); nrm.resize(nPoints * 3); bgr.resize(nPoints * 3); nviews.resize(nPoints);
-	viewIds.resize(cl.n_view_entries); viewWeights.resize(cl.n_view_entries);
+	xyz.shrink(nPoints * 3); nrm.shrink(nPoints * 3); bgr.shrink(nPoints * 3); nviews.shrink(nPoints);
+	viewIds.shrink(cl.n_view_entries); viewWeights.shrink(cl.n_view_entries);
 	// --estimate-colors / --estimate-normals: 2 = estimated during fusion (above), 1 = re-estimated on the final cloud
 	// (SceneDensify.cpp:3544, 3567-3572), 0 = none
 	if (o.estimateColors == 1) CHK(hcmvs_estimate_point_colors(ctx, nPoints, xyz.data(), nviews.data(), viewIds.data(), bgr.data()));
@@ -803,6 +838,7 @@ int main(int argc, char** argv) {
 		fprintf(stderr, "error: can not write the output files\n");
 		return EXIT_FAILURE;
 	}
+	if (o.verbosity > 1) printf("Scene and point cloud saved in %.2f s\n", now_s() - tFused);
 	for (auto& im : images) for (float* p : {im.dDepth, im.dNormal, im.dConf, im.dHintDepth, im.dHintNormal}) if (p) (void)hipFree(p);
 	hcmvs_destroy(ctx);
 	return EXIT_SUCCESS;

@@ -171,6 +171,9 @@ def test_config2_scene_64x1080p(tmp_path):
         m = re.search(r"(\d+) depth-maps, (\d+) depths, (\d+) points.* in ([\d.]+) s", r.stdout)
         assert m and int(m.group(1)) == N
         counts[order] = (int(m.group(2)), int(m.group(3)), float(m.group(4)))
+        for ln in r.stderr.splitlines():                                   # HCMVS_FUSE_DEBUG=1: the phases of the fusion call
+            if ln.startswith("fuse:") and " images, " in ln:
+                print("config2:", ln)
         est = re.search(r"Depth-maps estimated: (\d+) images.* in ([\d.]+) s \(([\d.]+) Mpix/s", r.stdout)
         print("config2: fuse order %d: driver wall %.1f s; estimation %s s (%s Mpix/s); fusion %.2f s, %d points of %d depths" % (
             order, walls[order], est.group(2), est.group(3), counts[order][2], counts[order][1], counts[order][0]))
