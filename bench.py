@@ -16,6 +16,12 @@ repeats every 4 units (rendering 32 distinct 1080p scenes on the host would take
 With N > 1 every rank estimates its own reference image (independent units, no collective on the estimation
 path) and the packed {depth, normal, conf} maps are all-gathered over RCCL after each step, which is the
 exchange FuseDepthMaps needs (SceneDensify.cpp:3381-3449).  Prints ONE JSON line on rank 0.
+
+Beside the contract fields the line carries: `roofline` (SURVEY.md 8d tap-gather convention; `traffic` = HBM bytes per sweep
+launch measured NOW by rocprofv3 --pmc child runs of this same command, one pass per counter -- `traffic_source` says so, or
+names the committed profile used when rocprofv3 is not usable), `valu` (vector-ALU instruction counts from the same child runs),
+`roofline_single_unit`, `fuse` (FuseDepthMaps points/s on estimated maps), `cpu_baseline` (the oracle on the host cores).
+The default run takes about three minutes.
 """
 import argparse
 import ctypes
@@ -178,6 +184,45 @@ def pmc_value(batch, what):
         return None
 
 
+def live_pmc(batch, timeout_s=240):
+    """HBM traffic and VALU instruction counters of the sweep kernel, measured NOW: one `rocprofv3 --pmc` child run of this same
+    command (one step, same batch) per counter set, collected the way MI355X_MICROARCH.md prescribes (separate --pmc passes, no
+    trace domain beside them).  The children are ordinary subprocesses; this process only waits.  Returns {counter: mean per
+    sweep launch} or None when rocprofv3 cannot be used here (absent, failing, or this process is itself being profiled)."""
+    import csv, glob, shutil, subprocess, tempfile
+    if any(k.startswith(("ROCPROF", "ROCP_")) or k == "HSA_TOOLS_LIB" for k in os.environ):
+        return None
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    kernel = "sweep_kernel<8, %d" % (1 if batch >= 3 else 2)
+    tmp = tempfile.mkdtemp(prefix="hcmvs_pmc_", dir="/tmp")
+    res = {}
+    try:
+        for i, cs in enumerate((("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"))):
+            d = os.path.join(tmp, "p%d" % i)
+            cmd = [exe, "--pmc", *cs, "--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py"), "--steps", "1",
+                   "--warmup", "0", "--batch", str(batch), "--no-cpu-baseline", "--no-fuse", "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            acc = {}
+            for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel in row["Kernel_Name"]:
+                            acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for c, v in acc.items():
+                res[c] = sum(v) / len(v)
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res if all(k in res for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")) else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +231,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="independent reference images per step and GPU (1..32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse", action="store_true", help="skip the FuseDepthMaps points/s figure")
+    ap.add_argument("--no-pmc", action="store_true", help="take roofline.traffic / the VALU counters from profiles/ instead of measuring them "
+                                                          "in rocprofv3 --pmc child runs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -318,16 +365,25 @@ def main():
             # The gather is served by L2 (see hbm_measured_frac): what actually bounds the kernel is the vector ALU (valu block).
             "roofline": {"kernel": "sweep_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_value(B, "hbm_bytes"),
+                         "traffic": None,
                          "compulsory_bytes_per_launch": int(B * P * (4 * N_SRC + 4 + 40)),
                          "algorithmic_bytes_per_launch": int(bytes_sweep),
                          "avg_launch_ms": round(st.ms_sweep_avg, 3)},
         }
-        traffic = pmc_value(B, "hbm_bytes")
+        # roofline.traffic and the VALU counters: measured now in rocprofv3 --pmc child runs of this command (FETCH_SIZE / WRITE_SIZE
+        # are reported in KiB); the committed measurement of the same command only when that is not possible
+        live = live_pmc(B) if world == 1 and not args.no_pmc else None
+        if live:
+            traffic = int((live["FETCH_SIZE"] + live["WRITE_SIZE"]) * 1024)
+            vi, vb = int(live["SQ_INSTS_VALU"]), int(live.get("SQ_ACTIVE_INST_VALU", 0)) or None
+            out["roofline"]["traffic_source"] = "rocprofv3 --pmc child runs of this command, now (FETCH_SIZE + WRITE_SIZE, one pass per counter)"
+        else:
+            traffic, vi, vb = pmc_value(B, "hbm_bytes"), pmc_value(B, "valu_insts"), pmc_value(B, "valu_busy_quadcycles")
+            out["roofline"]["traffic_source"] = "profiles/%s (committed rocprofv3 --pmc measurement of this command)" % PMC_FILE
+        out["roofline"]["traffic"] = traffic
         if traffic:
             out["roofline"]["hbm_measured_frac"] = round(traffic / (st.ms_sweep_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         out["roofline"]["copy_bandwidth_measured_GBs"] = copy_bandwidth(dev)
-        vi, vb = pmc_value(B, "valu_insts"), pmc_value(B, "valu_busy_quadcycles")
         if vi:
             simd_cycles = 1024 * 2.4e9 * st.ms_sweep_avg * 1e-3   # 256 CUs x 4 SIMDs at the 2.4 GHz the kernel holds (GRBM_GUI_ACTIVE)
             out["valu"] = {"insts_per_launch": vi, "insts_per_pixel_sweep": round(vi / (B * P), 1),

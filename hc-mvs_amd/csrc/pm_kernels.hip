@@ -959,6 +959,9 @@ struct RowShared {
 };
 
 __device__ __forceinline__ int wait_progress(HC_GLOBAL int32_t* word, int need, HC_GLOBAL int32_t* err) {
+#if defined(HCMVS_ABL) && HCMVS_ABL == 3 /* diagnostic ablation: rows do not wait for each other (results are wrong) */
+	return need;
+#endif
 	int v;
 	unsigned spins = 0;
 	while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, HC_SCOPE)) < need) {
