@@ -40,11 +40,11 @@ namespace hcmvs {
 // diagnostic build only (-DHCMVS_STAMPS): per-phase cycle accounting of wave 0 of every row worker
 #ifdef HCMVS_STAMPS
 __device__ unsigned long long g_stamps[16];
-#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; }
-#define STAMP_ARGS , unsigned long long& st_last, unsigned long long (&st_acc)[12]
+#define STAMP_ARGS , unsigned long long& st_last, unsigned long long (&st_acc)[14]
 #define STAMP_PASS , st_last, st_acc
-#define STAMP_FLUSH if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[i_], st_acc[i_]); }
+#define STAMP_FLUSH if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) { for (int i_ = 0; i_ < 14; ++i_) atomicAdd(&g_stamps[i_], st_acc[i_]); }
 #else
 #define STAMP_DECL
 #define STAMP(i)
@@ -83,6 +83,16 @@ __device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, fl
 #define HC_GLOBAL __attribute__((address_space(1)))
 template <class T>
 __device__ __forceinline__ HC_GLOBAL T* as_global(T* p) { return (HC_GLOBAL T*)p; }
+// One byte of a map that no kernel of this launch writes (the gradient map), at a wave-uniform index: read through the
+// constant address space it becomes a scalar load -- it lands in an SGPR behind lgkmcnt and never makes the wave drain
+// its vector-memory queue (a vector load of a uniform byte is turned into v_readfirstlane behind `s_waitcnt vmcnt(0)`,
+// i.e. a full memory round trip per pixel with every prefetch of the pixel just issued in front of it).
+__device__ __forceinline__ uint8_t uniform_byte(const uint8_t* base, int idx) {
+	typedef __attribute__((address_space(4))) const uint32_t* cu32p;
+	const uintptr_t a = (uintptr_t)base + (uintptr_t)(unsigned)idx;
+	const uint32_t w = *(cu32p)(a & ~(uintptr_t)3);
+	return (uint8_t)(w >> (8u * (unsigned)(a & 3u)));
+}
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // agent-scope (sc1) accesses for everything another row's wave may have written in this launch
@@ -1035,18 +1045,23 @@ __device__ __forceinline__ void slot_setup(const EstConst& c, int lane, int x, i
 
 // issue the loads of pixel (x,y) that do not depend on other rows' progress in this sweep
 template <int S>
-__device__ __forceinline__ void prefetch_static(const EstConst& c, const LaneCtx<S>& L, int x, int y, int q, bool rev, PixIn<S>& in) {
+__device__ __forceinline__ void prefetch_static(const EstConst& c, const LaneCtx<S>& L, int x, int y, int q, bool rev, bool upKnown, PixIn<S>& in) {
 	slot_setup<S>(c, L.lane, x, y, rev, in);
 	if constexpr (S != 8) load_patch_inputs<S>(c, L, x, y, in); // S == 8: the sweep loads them one pixel ahead
 	const int idx = y * c.W + x;
 	in.cur = load_dn(&c.dn[idx]);
 	in.curConf = load_f(&c.conf[idx]);
-	// slots ahead of me in my row, in later rows, or left of the swept range still hold last pass's values
-	if (in.slot && !in.isUp && !(in.back > 0 && in.back <= q)) {
-		in.ndn = load_dn(&c.dn[in.ny * c.W + in.nx]);
-		in.nconf = load_f(&c.conf[in.ny * c.W + in.nx]);
-		in.loaded = true;
-	}
+	// slots ahead of me in my row, in later rows, or left of the swept range still hold last pass's values.  The load is
+	// unconditional (lanes without such a slot read the pixel itself and never look at it): behind a branch the number of
+	// loads in flight is unknown to the compiler, and the first `s_waitcnt` after it -- the hand-over of the patch inputs
+	// loaded a pixel ago -- would be set for the shorter path, i.e. wait for the loads issued just above.
+	// upKnown: the row above is already known to have passed this column, so its slots go out in the same batch (a second
+	// load into the same registers would have to wait for the first)
+	const bool want = in.slot && (!in.isUp || upKnown) && !(in.back > 0 && in.back <= q);
+	const int nidx = want ? in.ny * c.W + in.nx : idx;
+	in.ndn = load_dn(&c.dn[nidx]);
+	in.nconf = load_f(&c.conf[nidx]);
+	in.loaded = want;
 }
 template <int S>
 __device__ __forceinline__ void prefetch_up(const EstConst& c, PixIn<S>& in) {
@@ -1298,6 +1313,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 	}
 	pp.pendingPub = q + 1;
 	STAMP(9)
+
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1379,20 +1395,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 		}
 		const int x0 = rev ? c.W - 1 - bd : bd;
 		const int dx = rev ? -1 : 1;
-		pp.tx1 = as_global(c.gra)[y * c.W + x0];
+		pp.tx1 = uniform_byte(c.gra, y * c.W + x0);
 		if constexpr (S == 8) { // the patch inputs travel one pixel ahead of the pixel being processed, the gradient byte two
 			PixIn<S> first;
 			first.tx = (float)pp.tx1;
 			load_patch_inputs<S>(c, L, x0, y, first);
 			pp.nI = first.I[0]; pp.nC = first.center;
-			pp.tx2 = ncols > 1 ? as_global(c.gra)[y * c.W + x0 + dx] : (uint8_t)0;
+			pp.tx2 = ncols > 1 ? uniform_byte(c.gra, y * c.W + x0 + dx) : (uint8_t)0;
 		}
 		for (int q = 0; q < ncols && !pp.fail; ++q) {
 			const int x = rev ? c.W - 1 - bd - q : bd + q;
+			STAMP(13)
 			// all loads of this pixel that do not depend on other rows go out in one batch ...
 			PixIn<S> in;
 			in.tx = (float)pp.tx1;
-			prefetch_static<S>(c, L, x, y, q, rev, in);
+			prefetch_static<S>(c, L, x, y, q, rev, pp.known >= q + 1, in);
 			if constexpr (S == 8) {
 				in.I[0] = pp.nI; in.center = pp.nC;
 				if (q + 1 < ncols) { // next pixel's patch inputs (its gradient byte arrived a pixel ago)
@@ -1402,11 +1419,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 					pp.nI = nxt.I[0]; pp.nC = nxt.center;
 				}
 				pp.tx1 = pp.tx2;
-				if (q + 2 < ncols) pp.tx2 = as_global(c.gra)[y * c.W + x + 2 * dx];
+				if (q + 2 < ncols) pp.tx2 = uniform_byte(c.gra, y * c.W + x + 2 * dx);
 			} else {
-				if (q + 1 < ncols) pp.tx1 = as_global(c.gra)[y * c.W + x + dx];
+				if (q + 1 < ncols) pp.tx1 = uniform_byte(c.gra, y * c.W + x + dx);
 			}
-			if (pp.known >= q + 1) prefetch_up<S>(c, in);
+			STAMP(12)
 			// ... and the patch weights are computed while they (and the previous row) arrive
 			Patch<S> P;
 			fill_patch<S, BIG>(c, L, x, y, in, P, st);
