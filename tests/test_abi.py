@@ -57,3 +57,35 @@ def test_no_gpu_means_no_compute():
     with pytest.raises(binding.HcmvsError) as e:
         binding.Context(0)
     assert e.value.code == binding.ERR_NO_DEVICE
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI (what a cgo / JNI / ctypes stub would bind): the header compiles as C99 with nothing but the C
+    library's headers, and a C program links against the shared library and calls through it (no compute without a GPU)."""
+    src = tmp_path / "c_client.c"
+    src.write_text(r'''
+#include "hcmvs_hip.h"
+#include <stdio.h>
+#include <string.h>
+int main(void) {
+    hcmvs_ctx* ctx = NULL;
+    hcmvs_params p;
+    hcmvs_default_params(&p);
+    if (p.n_random_iters != 6) return 2;
+    int rc = hcmvs_create(0, &ctx);
+    if (rc == HCMVS_OK) {               /* a GPU is present: one trivial call through the context */
+        if (!hcmvs_last_error(ctx)) return 3;
+        hcmvs_destroy(ctx);
+    } else if (rc != HCMVS_ERR_NO_DEVICE && rc != HCMVS_ERR_HIP) {
+        return 4;
+    }
+    printf("c client ok %d\n", rc);
+    return 0;
+}
+''')
+    exe = tmp_path / "c_client"
+    libdir = os.path.dirname(binding.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lhcmvs_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "c client ok" in out.stdout, out.stdout + out.stderr

@@ -56,7 +56,7 @@ def test_gradient_map_matches_oracle(ctx):
     assert np.array_equal(ctx.gradient_map(0), O.gradient_map(views[0]["gray"]))
 
 
-@pytest.mark.parametrize("n_src,ahw", [(1, 6), (2, 5), (3, 6), (4, 7), (5, 6), (8, 6), (8, 7), (9, 5)])
+@pytest.mark.parametrize("n_src,ahw", [(1, 6), (2, 5), (3, 6), (4, 7), (5, 6), (8, 6), (8, 7), (9, 5), (12, 6)])
 def test_estimate_bit_exact(ctx, n_src, ahw):
     views, pts = _scene(112, 88, 100.0, n_src, seed=10 + n_src)
     _upload(ctx, views)
