@@ -10,7 +10,7 @@
 #include "pm_common.h"
 #include "fuse_common.h"
 #include "tri_init.h"
-#include "cloud_post.h"
+#include "cloud_kernels.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -1185,17 +1185,25 @@ int hcmvs_estimate_point_colors(hcmvs_ctx* c, uint64_t n, const float* xyz, cons
 
 int hcmvs_estimate_point_normals(hcmvs_ctx* c, uint64_t n, const float* xyz, const uint32_t* n_views, const uint32_t* view_ids, int32_t k, float* normal) {
 	if (!c) return HCMVS_ERR_INVALID;
-	if (!xyz || !n_views || !view_ids || !normal || k < 3) return fail(c, HCMVS_ERR_INVALID, "estimate_point_normals: bad arguments");
-	std::vector<double> firstC(3 * n);
+	if (!xyz || !n_views || !view_ids || !normal || k < 3 || k > 32) return fail(c, HCMVS_ERR_INVALID, "estimate_point_normals: bad arguments (3 <= k <= 32)");
+	if (n == 0) return HCMVS_OK;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	uint32_t maxId = 0;
+	for (auto& kv : c->views) maxId = std::max(maxId, kv.first);
+	std::vector<double> centres(3 * ((size_t)maxId + 1), 0.0); // camera centres by view id
+	for (auto& kv : c->views) for (int q = 0; q < 3; ++q) centres[3 * (size_t)kv.first + q] = kv.second.C[q];
+	std::vector<uint32_t> first(n);
 	unsigned long long off = 0;
 	for (uint64_t i = 0; i < n; ++i) {
 		if (n_views[i] < 1) return fail(c, HCMVS_ERR_INVALID, "estimate_point_normals: point %llu has no view", (unsigned long long)i);
-		auto it = c->views.find(view_ids[off]);
-		if (it == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "estimate_point_normals: unknown view %u", view_ids[off]);
-		for (int q = 0; q < 3; ++q) firstC[3 * i + q] = it->second.C[q];
+		if (!c->views.count(view_ids[off])) return fail(c, HCMVS_ERR_INVALID, "estimate_point_normals: unknown view %u", view_ids[off]);
+		first[i] = view_ids[off];
 		off += n_views[i];
 	}
-	hcmvs::pca_normals(n, xyz, firstC.data(), k, normal);
+	std::string err;
+	const int rc = hcmvs::pca_normals_device(n, xyz, first.data(), centres.data(), (size_t)maxId + 1, k, normal, c->stream, err);
+	if (rc) return fail(c, rc == 1 ? HCMVS_ERR_INVALID : HCMVS_ERR_HIP, "%s", err.c_str());
 	return HCMVS_OK;
 }
 
