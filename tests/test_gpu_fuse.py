@@ -57,6 +57,42 @@ def test_fuse_scale_mismatched_neighbour(ctx):
             assert np.array_equal(ctx.get_depthmap(i)[0], d)
 
 
+def test_fuse_concurrent_image_passes(ctx):
+    """three clusters of views that share no map (every image's neighbours lie in its own cluster), fused in an interleaved order:
+    hcmvs_fuse_cloud runs the passes of images with disjoint touched sets side by side (its "lanes"), an image waiting only for the
+    earlier images of the order it shares a map with, and the compaction keeps the cloud in the order of the sequential loop
+    (SceneDensify.cpp:3302).  Bit-exact against the sequential oracle including point order, view lists and invalidated depths;
+    also with one lane and with more lanes than images."""
+    import os
+    clusters = [make_maps(w=128, h=96, f=115.0, n_views=4, seed=21 + 5 * k, noise=0.002, outliers=0.04, holes=0.05)[0] for k in range(3)]
+    maps = []
+    for k, cl in enumerate(clusters):
+        for m in cl:
+            m = dict(m)
+            m["neighbors"] = [4 * k + j for j in m["neighbors"]]
+            maps.append(m)
+    order = [0, 4, 8, 5, 1, 9, 2, 10, 6, 11, 7, 3]            # clusters interleaved, not in lock-step
+    want = O.fuse_depthmaps(maps, order, 400000)
+    vcap = int(sum((m["depth"] != 0).sum() for m in maps))
+    old = os.environ.get("HCMVS_FUSE_LANES")
+    try:
+        for lanes in ("4", "1", "16"):
+            os.environ["HCMVS_FUSE_LANES"] = lanes
+            upload(ctx, maps)
+            got = ctx.fuse_cloud(order, 400000, vcap)
+            assert got["n_points"] == want["n_points"] > 3000 and got["n_depths"] == want["n_depths"]
+            assert np.array_equal(got["xyz"], want["xyz"]) and np.array_equal(got["n_views"], want["n_views"])
+            assert np.array_equal(got["normal"], want["normal"]) and np.array_equal(got["bgr"], want["bgr"])
+            assert np.array_equal(got["view_ids"], want["view_ids"]) and np.array_equal(got["view_weights"], want["view_weights"])
+            for i, d in enumerate(want["depths"]):
+                assert np.array_equal(ctx.get_depthmap(i)[0], d)
+    finally:
+        if old is None:
+            os.environ.pop("HCMVS_FUSE_LANES", None)
+        else:
+            os.environ["HCMVS_FUSE_LANES"] = old
+
+
 def test_fuse_options_and_capacity(ctx):
     maps, order = make_maps(noise=0.002)
     upload(ctx, maps)
