@@ -398,7 +398,7 @@ def main():
         # the (W + H) x T_pixel critical path of its row wavefront
         taps_a1 = int(np.where(ctx.gradient_map(0)[7:H - 7, 7:W - 7] > 100, 36, (AHW + 1) ** 2).astype(np.int64).sum())
         bytes_1 = (int(st1.tap_evals) - taps_a1) / SWEEPS * N_SRC * 16.0 + P * 44.0
-        out["roofline_single_unit"] = {"kernel": "sweep_kernel (2 waves per row)", "bound": "hbm",
+        out["roofline_single_unit"] = {"kernel": "sweep_kernel (3 waves per row)", "bound": "hbm",
                                        "achieved": round(bytes_1 / (st1.ms_sweep_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(bytes_1 / (st1.ms_sweep_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                        "avg_launch_ms": round(st1.ms_sweep_avg, 3), "estimate_ms": round(st1.ms_total, 2)}

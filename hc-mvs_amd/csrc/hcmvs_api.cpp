@@ -91,7 +91,7 @@ struct hcmvs_ctx {
 	void* fuseScratch = nullptr; size_t capFuseScratch = 0;
 	std::vector<FuseLane> fuseLanes; // per-pass scratch of the concurrent fusion passes
 	bool errPending = false; // an estimate was enqueued since the error word was last read
-	int wavesPerRow = 0; // 0 = automatic: 2 waves per row for small batches (latency), 1 when >= 3 images fill the chip
+	int wavesPerRow = 0; // 0 = automatic: 3 waves per row for one image, 2 for two (latency), 1 when >= 3 images fill the chip
 };
 
 static int fail(hcmvs_ctx* c, int code, const char* fmt, ...) {
@@ -547,7 +547,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 		HIPCHK(c, hipMemsetAsync(c->sync + 16, 0, sizeof(int32_t) * kMaxBatch, s)); // the tickets; the error word stays sticky
 		for (int i = 0; i < n_items; ++i)
 			HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * c->hItems[i].border) * kProgressStride * sizeof(int32_t), s));
-		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : 2);
+		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : (n_items == 2 ? 2 : 3)); // measured: profiles/r02_knobs.txt
 		// the band worker serves the throughput case: 5..8 source views, patches up to 8 x 8 taps, at most 8 neighbour slots per
 		// pixel (4 at outer iteration 0; the cross pattern has 4 * ceil(halfwin / step), DepthMap.cpp:1071-1078), one wave per row
 		bool useBand = c->bandWorker && nw == 1 && hcmvs::segments_for(items[0].n_src) == 8 && p->adapthalfwin <= kHalfWindow;
