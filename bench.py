@@ -368,7 +368,10 @@ def main():
                          "traffic": None,
                          "compulsory_bytes_per_launch": int(B * P * (4 * N_SRC + 4 + 40)),
                          "algorithmic_bytes_per_launch": int(bytes_sweep),
-                         "avg_launch_ms": round(st.ms_sweep_avg, 3)},
+                         "avg_launch_ms": round(st.ms_sweep_avg, 3),
+                         "convention": "SURVEY.md 8d: algorithmic tap-gather bytes (4 texels per bilinear sample) over the HBM peak; the gather "
+                                       "is served by L2, so frac can pass 1 -- the physical HBM traffic is `traffic` (hbm_measured_frac), "
+                                       "the kernel is VALU-bound (valu block)"},
         }
         # roofline.traffic and the VALU counters: measured now in rocprofv3 --pmc child runs of this command (FETCH_SIZE / WRITE_SIZE
         # are reported in KiB); the committed measurement of the same command only when that is not possible
