@@ -184,7 +184,7 @@ def pmc_value(batch, what):
         return None
 
 
-def live_pmc(batch, timeout_s=240):
+def live_pmc(batch, timeout_s=150):
     """HBM traffic and VALU instruction counters of the sweep kernel, measured NOW: one `rocprofv3 --pmc` child run of this same
     command (one step, same batch) per counter set, collected the way MI355X_MICROARCH.md prescribes (separate --pmc passes, no
     trace domain beside them).  The children are ordinary subprocesses; this process only waits.  Returns {counter: mean per
