@@ -176,6 +176,7 @@ template <int S>
 struct LaneCtx {
 	static constexpr int MAXM = 64 / S; // taps per lane
 	int lane, view, seg;
+	int vloc;         // view group of the lane inside the wave (= view, except in the second view set of a 9..16-view estimate)
 	bool vact;        // lane's view group exists
 	unsigned imgOff;  // byte offset of my source view from EstConst::imgBase (all views of a call lie within 4 GiB)
 	int iw, ixmax, iymax; // row pitch in pixels; largest top-left texel column / row of a bilinear footprint
@@ -184,15 +185,16 @@ struct LaneCtx {
 };
 
 template <int S>
-__device__ __forceinline__ void lane_init(const EstConst& c, LaneCtx<S>& L) {
+__device__ __forceinline__ void lane_init(const EstConst& c, LaneCtx<S>& L, int vbase = 0) {
 	L.lane = threadIdx.x & 63;
-	L.view = L.lane / S;
+	L.vloc = L.lane / S;
+	L.view = vbase + L.vloc;
 	L.seg = L.lane % S;
 	L.vact = L.view < c.V;
 	const HC_GLOBAL DevView* dv = as_global(c.views) + (L.vact ? L.view : 0); // idle groups mirror view 0 (results masked)
 	L.imgOff = dv->byteOff; L.iw = dv->w; L.ixmax = dv->w - 2; L.iymax = dv->h - 2;
 	L.wmax = (float)(dv->w - 2); L.hmax = (float)(dv->h - 2);
-	L.groupMask = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (L.view * S);
+	L.groupMask = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (L.vloc * S);
 }
 
 template <int S>
@@ -231,6 +233,10 @@ struct RegStore {
 #pragma unroll
 		for (int m = 0; m < MAXM; ++m) { py[m] = py_[m]; w[m] = w_[m]; tw[m] = tw_[m]; }
 	}
+	__device__ __forceinline__ void copy_patch(const RegStore& o) {
+#pragma unroll
+		for (int m = 0; m < MAXM; ++m) { py[m] = o.py[m]; w[m] = o.w[m]; tw[m] = o.tw[m]; }
+	}
 	__device__ __forceinline__ void get_view(float (&A_)[9], float (&Hm_)[3]) const {
 #pragma unroll
 		for (int i = 0; i < 9; ++i) A_[i] = A[i];
@@ -249,7 +255,7 @@ struct RegStore {
 template <int S>
 struct WavePark { // LDS of one wave of a row worker
 	static constexpr int MAXM = 64 / S;
-	float4 vh[64 / S][3];     // per view group: A[0..8], Hm[0..2]
+	float4 vh[S == 8 ? 16 : 64 / S][3]; // per view: A[0..8], Hm[0..2] (S == 8: two sets of eight views, see TWO in the kernels)
 	float pw[S == 8 ? 1 : 3 * MAXM][64]; // S != 8: py | w | tw per lane, see LdsStore
 	float ps[3][8][8];        // S == 8: py | w | tw as [column][row], read by every view group
 	float cl[9][kMaxSlots];   // smoothness neighbours, slot k at [.][k]: X0 X1 X2 | n0 n1 n2 | k0 k1 k2 (see Close)
@@ -739,10 +745,18 @@ __device__ __forceinline__ float two_best(const EstConst& c, float m1, float m2)
 	return c.V <= 1 ? m1 : (m2 >= c.thRobust ? m1 : (m1 + m2) / 2.f);
 }
 
-// one hypothesis, everything in one go (init-score pass)
+// the two smallest of {a1 <= a2} and {b1 <= b2}
+__device__ __forceinline__ void min2_merge(float& a1, float& a2, float b1, float b2) {
+	const float lo = fminf(a1, b1), hi = fmaxf(a1, b1);
+	a2 = fminf(hi, fminf(a2, b2));
+	a1 = lo;
+}
+
+// one hypothesis, everything in one go (init-score pass): the two best view scores of the views of L's set are merged into
+// (r1, r2); two_best() of those is the pixel's score (an estimate with 9..16 source views runs a second set of eight)
 template <int S, bool BIG, class ST>
-__device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const ST& st, float v0, float v1,
-                                             float smoothF, float depth, float n0, float n1, float n2) {
+__device__ __forceinline__ void score_pixel(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const ST& st, float v0, float v1,
+                                            float smoothF, float depth, float n0, float n1, float n2, float& r1, float& r2) {
 	float vA[9], vHm[3], H[9];
 	st.get_view(vA, vHm);
 	make_homography(c, vA, vHm, v0, v1, depth, n0, n1, n2, H);
@@ -760,7 +774,7 @@ __device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>
 	const float s = view_score(c, sum, sumSq, num, viewBad, P.invSumW, P.normSq0, smoothF);
 	float m1 = L.vact ? s : __builtin_huge_valf(), m2 = __builtin_huge_valf();
 	min2_across<S>(m1, m2);
-	return two_best(c, m1, m2);
+	min2_merge(r1, r2, m1, m2);
 }
 
 // Score one chunk of up to eight hypotheses of a round (bits of `todo`, all in [base, base + 8); lane t holds hypothesis t
@@ -768,12 +782,13 @@ __device__ __forceinline__ float score_pixel(const EstConst& c, const LaneCtx<S>
 //   (1) the homographies of all (hypothesis, view) pairs of the chunk, one pair per lane -> LDS
 //   (2) per hypothesis: the tap sums of all views (score_taps), one lane per view parks them in LDS
 //   (3) the per-view scores and the two-best-views means of the whole chunk, one (hypothesis, view) pair per lane
-// (1) and (3) cost one instruction stream per chunk instead of one per hypothesis.  Lane t of the result gets the score
-// of hypothesis t.
+// (1) and (3) cost one instruction stream per chunk instead of one per hypothesis.  Lane t gets the two best view scores of
+// hypothesis t merged into (r1, r2); two_best() of those is the hypothesis' score.  L selects the view set (views
+// L.view - L.vloc ... + 7): an estimate with 9..16 source views calls this twice per chunk.
 template <int S, bool BIG>
-__device__ __forceinline__ float score_chunk(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const LdsStore<S>& st, float v0, float v1,
-                                             float F, float hd, float h0, float h1, float h2, unsigned long long todoIn, int baseIn,
-                                             int fallbackIn, float mine, unsigned& issued) {
+__device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const LdsStore<S>& st, float v0, float v1,
+                                            float F, float hd, float h0, float h1, float h2, unsigned long long todoIn, int baseIn,
+                                            int fallbackIn, float& r1, float& r2, unsigned& issued) {
 	// the list of hypotheses is the same in every lane: keep it (and the loop over it) on the scalar unit
 	const unsigned long long todo = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(todoIn >> 32)) << 32) |
 	                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)todoIn);
@@ -782,9 +797,10 @@ __device__ __forceinline__ float score_chunk(const EstConst& c, const LaneCtx<S>
 	constexpr int HP = S < 8 ? S : 8;        // hypotheses per pair-pass (lane = g * NV + v)
 	WavePark<S>* pk = st.pk;
 	const int lane = L.lane, pv = lane % NV, pg = lane / NV;
+	const int vbase = __builtin_amdgcn_readfirstlane(L.view - L.vloc); // first view of the set
 	float vA[9], vHm[3];
 	{
-		const float4 a = pk->vh[pv][0], b = pk->vh[pv][1], cc = pk->vh[pv][2];
+		const float4 a = pk->vh[vbase + pv][0], b = pk->vh[vbase + pv][1], cc = pk->vh[vbase + pv][2];
 		vA[0] = a.x; vA[1] = a.y; vA[2] = a.z; vA[3] = a.w; vA[4] = b.x; vA[5] = b.y; vA[6] = b.z; vA[7] = b.w; vA[8] = cc.x;
 		vHm[0] = cc.y; vHm[1] = cc.z; vHm[2] = cc.w;
 	}
@@ -808,7 +824,7 @@ __device__ __forceinline__ float score_chunk(const EstConst& c, const LaneCtx<S>
 			const int g = __builtin_ctzll(td) - base;
 			float H[9];
 			{
-				const float4 a = pk->hl[g][L.view][0], b = pk->hl[g][L.view][1], cc = pk->hl[g][L.view][2];
+				const float4 a = pk->hl[g][L.vloc][0], b = pk->hl[g][L.vloc][1], cc = pk->hl[g][L.vloc][2];
 				H[0] = a.x; H[1] = a.y; H[2] = a.z; H[3] = a.w; H[4] = b.x; H[5] = b.y; H[6] = b.z; H[7] = b.w; H[8] = cc.x;
 			}
 			float sum, sumSq, num;
@@ -816,7 +832,7 @@ __device__ __forceinline__ float score_chunk(const EstConst& c, const LaneCtx<S>
 			if constexpr (NR == 0) score_taps_big<S>(c, L, st, H, sum, sumSq, num, viewBad);
 			else score_taps<S, NR>(c, L, P, st, H, sum, sumSq, num, viewBad);
 			++issued;
-			if (L.seg == 0) pk->acc[g][L.view] = make_float4(sum, sumSq, num, viewBad ? 1.f : 0.f);
+			if (L.seg == 0) pk->acc[g][L.vloc] = make_float4(sum, sumSq, num, viewBad ? 1.f : 0.f);
 		}
 	};
 	if (BIG && P.a > kHalfWindow) {
@@ -835,15 +851,14 @@ __device__ __forceinline__ float score_chunk(const EstConst& c, const LaneCtx<S>
 		const float4 r = pk->acc[g][pv];
 		const float Fg = __shfl(F, g * 8, 64);
 		const float s = view_score(c, r.x, r.y, r.z, r.w != 0.f, P.invSumW, P.normSq0, Fg);
-		float m1 = pv < c.V ? s : __builtin_huge_valf(), m2 = __builtin_huge_valf();
+		float m1 = vbase + pv < c.V ? s : __builtin_huge_valf(), m2 = __builtin_huge_valf();
 		min2_group<NV>(m1, m2);
-		const float sc = two_best(c, m1, m2);
-		// hypothesis base + p0 + k sits in lanes k * NV ... of sc
+		// hypothesis base + p0 + k sits in lanes k * NV ... of (m1, m2)
 		const int k = lane - base - p0;
-		const float got = __shfl(sc, (k >= 0 && k < HP ? k : 0) * NV, 64);
-		if (k >= 0 && k < HP && ((todo >> lane) & 1ull)) mine = got;
+		const int from = (k >= 0 && k < HP ? k : 0) * NV;
+		const float g1 = __shfl(m1, from, 64), g2 = __shfl(m2, from, 64);
+		if (k >= 0 && k < HP && ((todo >> lane) & 1ull)) min2_merge(r1, r2, g1, g2);
 	}
-	return mine;
 }
 
 // Util.inl:614-626
@@ -1088,8 +1103,10 @@ __device__ __forceinline__ float share_scores(RowShared<NW>& sh, int& par, int l
 // factors of a wave's share come from one smooth_pass, the share is scored hypothesis by hypothesis, the scores are
 // exchanged through LDS and every wave replays the reference's sequential accept logic (DepthMap.cpp:1425, 1455,
 // 1484).  Refinement trials depend on earlier accepts: after an accepted trial the later ones are regenerated.
-template <int S, int NW, bool BIG>
-__device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S>& L, RowShared<NW>& sh, int& par, int wv,
+// TWO: the estimate has 9..16 source views: a second set of eight view groups (L1: views 8..15 in the same lane layout) is
+// scored after the first, and the two best views are taken over both
+template <int S, int NW, bool BIG, bool TWO>
+__device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S>& L, const LaneCtx<S>& L1, RowShared<NW>& sh, int& par, int wv,
                                               int x, int y, int q, int iter, const PixIn<S>& in, const Patch<S>& P,
                                               const LdsStore<S>& st, RowPipe<S>& pp, unsigned& evals, unsigned& issued STAMP_ARGS) {
 	const int W = c.W, lane = L.lane;
@@ -1220,7 +1237,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		STAMP(3)
 		// ---- my share of the round: one smoothness pass per eight hypotheses, then the scorer ----
 		const int cnt = r1 - r0, per = (cnt + NW - 1) / NW, lo = r0 + wv * per, hi = (lo + per < r1 ? lo + per : r1);
-		float mine = __builtin_huge_valf();
+		float best1 = __builtin_huge_valf(), best2 = __builtin_huge_valf(); // lane t: the two best view scores of hypothesis t
 		for (int base = lo; base < hi; base += 8) {
 			const int g = base + (lane >> 3);
 			const int src = g < r1 ? g : r0;
@@ -1236,8 +1253,15 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			const int top = base + 8 < hi ? base + 8 : hi;
 			const unsigned long long todo = vmask & ((1ull << top) - 1ull) & ~((1ull << base) - 1ull); // top <= 32
 			STAMP(4)
-			if (todo) mine = score_chunk<S, BIG>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, todo, base, __builtin_ctzll(todo), mine, issued);
+			if (todo) {
+				score_chunk<S, BIG>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, todo, base, __builtin_ctzll(todo), best1, best2, issued);
+				if constexpr (TWO) {
+					unsigned again = 0;
+					score_chunk<S, BIG>(c, L1, P, st, G.v0, G.v1, F, hd, h0, h1, h2, todo, base, __builtin_ctzll(todo), best1, best2, again);
+				}
+			}
 		}
+		const float mine = two_best(c, best1, best2); // lanes without a scored hypothesis: two_best(inf, inf) = inf
 		STAMP(7)
 		const float all = share_scores<NW>(sh, par, lane, lo, hi, mine);
 		STAMP(8)
@@ -1296,8 +1320,13 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			correct_normal(G, h0, h1, h2);
 			const float hpd = -hd * dot3(h0, h1, h2, G.v0, G.v1, 1.f); // InitPlane
 			const float F = smooth_pass(c, st.pk->cl, closeMask, eligMask, lane, hd, h0, h1, h2, h0, h1, h2, hpd, 63);
-			const float sc = score_chunk<S, BIG>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, 1ull, 0, 0, __builtin_huge_valf(), issued);
-			const float nconf = rlf(sc, 0);
+			float s1 = __builtin_huge_valf(), s2 = __builtin_huge_valf();
+			score_chunk<S, BIG>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, 1ull, 0, 0, s1, s2, issued);
+			if constexpr (TWO) {
+				unsigned again = 0;
+				score_chunk<S, BIG>(c, L1, P, st, G.v0, G.v1, F, hd, h0, h1, h2, 1ull, 0, 0, s1, s2, again);
+			}
+			const float nconf = rlf(two_best(c, s1, s2), 0);
 			++evals;
 			if (conf > nconf - 0.1f) { conf = nconf; depth = hd; n0 = h0; n1 = h1; n2 = h2; }
 		}
@@ -1324,7 +1353,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 #ifndef HCMVS_OCC
 #define HCMVS_OCC 3 // waves per SIMD the register allocation of the 5..8-view sweep worker is held to (diagnostic builds vary it)
 #endif
-template <int S, int NW, bool BIG>
+template <int S, int NW, bool BIG, bool TWO = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 && !BIG ? HCMVS_OCC : 1, S >= 8 && !BIG ? HCMVS_OCC : 2))) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
                                                         int iter, int lag, int affinity) {
 	__shared__ RowShared<NW> sh;
@@ -1381,6 +1410,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 		st.pk = &park[wv]; st.lane = L.lane; st.view = L.view;
 		st.bw = (float (*)[kBigSlots])(BIG ? &bigTab[BIG ? wv : 0][0][0] : nullptr);
 		st.put_view(as_global(c.views) + (L.vact ? L.view : 0), L.seg);
+		LaneCtx<S> L1 = L; // TWO: the same lanes as views 8..15
+		if constexpr (TWO) {
+			lane_init<S>(c, L1, 64 / S);
+			LdsStore<S> s1 = st;
+			s1.view = L1.view;
+			s1.put_view(as_global(c.views) + (L1.vact ? L1.view : 0), L1.seg);
+		}
 		pp.ncols = ncols;
 		const int y = rev ? c.H - 1 - bd - r : bd + r;
 		pp.r = r; pp.y = y;
@@ -1435,7 +1471,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 			}
 			STAMP(0)
 			const unsigned e0 = evals;
-			process_pixel<S, NW, BIG>(c, L, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
+			process_pixel<S, NW, BIG, TWO>(c, L, L1, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
 			taps += (unsigned long long)(evals - e0) * (unsigned)((P.a + 1) * (P.a + 1));
 		}
 		if (pp.fail) break;
@@ -1960,7 +1996,7 @@ __global__ void import_kernel(EstConst c, const float* depthIn, const float* nor
 	}
 }
 
-template <int S, bool BIG>
+template <int S, bool BIG, bool TWO = false>
 __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long long* evalsOut) {
 	LaneCtx<S> L;
 	lane_init<S>(c, L);
@@ -1970,6 +2006,12 @@ __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long lo
 	st.stage = stage[threadIdx.x >> 6]; st.seg = L.seg;
 	st.bw = (float (*)[kBigSlots])(BIG ? &bigTab[BIG ? (threadIdx.x >> 6) : 0][0][0] : nullptr);
 	st.put_view(as_global(c.views) + (L.vact ? L.view : 0), L.seg);
+	LaneCtx<S> L1 = L;    // TWO (9..16 source views): the same lanes as views 8..15, with their own view constants
+	RegStore<S> st1 = st;
+	if constexpr (TWO) {
+		lane_init<S>(c, L1, 64 / S);
+		st1.put_view(as_global(c.views) + (L1.vact ? L1.view : 0), L1.seg);
+	}
 	const int nrows = c.H - 2 * c.border, ncols = c.W - 2 * c.border;
 	const int total = nrows * ncols;
 	const int wavesPerBlock = blockDim.x >> 6;
@@ -1996,7 +2038,13 @@ __global__ __launch_bounds__(256) void score_kernel(EstConst c, unsigned long lo
 		} else if (dot3(n0, n1, n2, G.v0, G.v1, 1.f) >= 0.f) {
 			random_normal(G, rand_unit(rk, 1u), rand_unit(rk, 2u), n0, n1, n2);
 		}
-		const float s = score_pixel<S, BIG>(c, L, P, st, G.v0, G.v1, 1.f, d, n0, n1, n2);
+		float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
+		score_pixel<S, BIG>(c, L, P, st, G.v0, G.v1, 1.f, d, n0, n1, n2, m1, m2);
+		if constexpr (TWO) {
+			st1.copy_patch(st); // the pixel's patch tables (registers) with the second set's view constants
+			score_pixel<S, BIG>(c, L1, P, st1, G.v0, G.v1, 1.f, d, n0, n1, n2, m1, m2);
+		}
+		const float s = two_best(c, m1, m2);
 		++evals;
 		taps += (unsigned)((P.a + 1) * (P.a + 1));
 		if (L.lane == 0) {
@@ -2017,7 +2065,9 @@ template <int S>
 __global__ void probe_score_kernel(EstConst c, Patch<S> P, RegStore<S> st, float F, float d, float n0, float n1, float n2, float* out) {
 	LaneCtx<S> L;
 	lane_init<S>(c, L);
-	out[threadIdx.x] = score_pixel<S, false>(c, L, P, st, 0.1f, 0.2f, F, d, n0, n1, n2);
+	float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
+	score_pixel<S, false>(c, L, P, st, 0.1f, 0.2f, F, d, n0, n1, n2, m1, m2);
+	out[threadIdx.x] = two_best(c, m1, m2);
 }
 template __global__ void probe_score_kernel<8>(EstConst, Patch<8>, RegStore<8>, float, float, float, float, float, float*);
 __global__ void probe_smooth_kernel(EstConst c, Close C, float* out) {
@@ -2124,6 +2174,8 @@ void debug_read_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
+// lane layout class of an estimate with V source views: tap segments per view group; 4 stands for "9..16 views", which run
+// the 8-segment layout twice (two sets of eight view groups, TWO in the kernels)
 int segments_for(int V) { return V <= 1 ? 64 : (V <= 2 ? 32 : (V <= 4 ? 16 : (V <= 8 ? 8 : 4))); }
 
 void launch_gray_to_u8(const float* gray, uint8_t* out, int n, hipStream_t s) {
@@ -2147,7 +2199,7 @@ static void launch_score_big(const EstConst& c, unsigned long long* evals, hipSt
 	case 32: hipLaunchKernelGGL((score_kernel<32, BIG>), grid, block, 0, s, c, evals); break;
 	case 16: hipLaunchKernelGGL((score_kernel<16, BIG>), grid, block, 0, s, c, evals); break;
 	case 8: hipLaunchKernelGGL((score_kernel<8, BIG>), grid, block, 0, s, c, evals); break;
-	default: hipLaunchKernelGGL((score_kernel<4, BIG>), grid, block, 0, s, c, evals); break;
+	default: hipLaunchKernelGGL((score_kernel<8, BIG, true>), grid, block, 0, s, c, evals); break; // 9..16 views: two sets of eight
 	}
 }
 void launch_score_pass(const EstConst& c, const float* depthIn, const float* normalIn, unsigned long long* evals,
@@ -2169,7 +2221,7 @@ static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int
 	case 32: hipLaunchKernelGGL((sweep_kernel<32, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
 	case 16: hipLaunchKernelGGL((sweep_kernel<16, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
 	case 8: hipLaunchKernelGGL((sweep_kernel<8, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
-	default: hipLaunchKernelGGL((sweep_kernel<4, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
+	default: hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break; // 9..16 views
 	}
 }
 void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int lag,

@@ -372,8 +372,7 @@ static int device_segments(int V) {
 	if (V <= 1) return 64;
 	if (V <= 2) return 32;
 	if (V <= 4) return 16;
-	if (V <= 8) return 8;
-	return 4;
+	return 8; /* 5..8 views; 9..16 views run the same layout twice (two sets of eight view groups) */
 }
 
 static void ctx_init(est_ctx* c, const hcor_view* ref, const hcor_view* srcs, int V, const uint8_t* gra,

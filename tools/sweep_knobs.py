@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 binding = importlib.import_module("hc-mvs_amd.binding")
 synth = importlib.import_module("hc-mvs_amd.synth")
-W, H, F, V = 1920, 1080, 1600.0, 8
+W, H, F, V = 1920, 1080, 1600.0, int(os.environ.get("HCMVS_KNOB_VIEWS", "8"))  # source views per reference image
 B, I = int(sys.argv[1]), int(sys.argv[2])
 configs = sys.argv[3:] or [":1"]
 dev = torch.device("cuda:0")
