@@ -246,7 +246,8 @@ int hcmvs_estimate_point_colors(hcmvs_ctx* ctx, uint64_t n_points, const float* 
                                 uint8_t* bgr);
 /* MVS::EstimatePointNormals (DepthMap.cpp:2221-2269; --estimate-normals 1): normal of the plane fitted by PCA to the
  * n_neighbors nearest points of every point (the reference calls CGAL::pca_estimate_normals with 16), oriented towards the first
- * view of the point.  Host-side helper (no device work); CGAL is absent, so the PCA is restated (parity unpinned). */
+ * view of the point.  Computed on the device (exact k-nearest search + PCA, 3 <= n_neighbors <= 32, fewer than 2^31 points);
+ * CGAL is absent, so the PCA is restated (parity unpinned).  Host arrays in and out. */
 int hcmvs_estimate_point_normals(hcmvs_ctx* ctx, uint64_t n_points, const float* xyz, const uint32_t* n_views, const uint32_t* view_ids,
                                  int32_t n_neighbors, float* normal);
 
