@@ -561,7 +561,13 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 			for (int i = 0; i < n_items; ++i) totalBands += (c->hItems[i].H - 2 * c->hItems[i].border + 7) / 8;
 			launch_band_sweep(c->dItems, n_items, totalBands, sy, iter, c->xcdAffinity, s);
 		} else
-			launch_sweep(c->dItems, n_items, maxRows, totalRows, items[0].n_src, p->adapthalfwin > kHalfWindow, sy, iter, c->sweepLag, nw, c->xcdAffinity, s);
+		{
+			// the launcher picks the kernel variant by view count: an item whose count leaves two or more view groups idle wants the
+			// pair-packing variant, which is correct for the other items of its layout class too
+			int vSel = items[0].n_src;
+			for (int i = 0; i < n_items; ++i) if (items[i].n_src % 8 != 0 && items[i].n_src % 8 != 7) vSel = items[i].n_src;
+			launch_sweep(c->dItems, n_items, maxRows, totalRows, vSel, p->adapthalfwin > kHalfWindow, sy, iter, c->sweepLag, nw, c->xcdAffinity, s);
+		}
 	}
 	HIPCHK(c, hipEventRecord(c->ev[2], s));
 	for (int i = 0; i < n_items; ++i)

@@ -785,7 +785,7 @@ __device__ __forceinline__ void score_pixel(const EstConst& c, const LaneCtx<S>&
 // (1) and (3) cost one instruction stream per chunk instead of one per hypothesis.  Lane t gets the two best view scores of
 // hypothesis t merged into (r1, r2); two_best() of those is the hypothesis' score.  L selects the view set (views
 // L.view - L.vloc ... + 7): an estimate with 9..16 source views calls this twice per chunk.
-template <int S, bool BIG>
+template <int S, bool BIG, bool PACK = false>
 __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const LdsStore<S>& st, float v0, float v1,
                                             float F, float hd, float h0, float h1, float h2, unsigned long long todoIn, int baseIn,
                                             int fallbackIn, float& r1, float& r2, unsigned& issued) {
@@ -818,8 +818,43 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 			pk->hl[g][pv][2] = make_float4(H[8], 0.f, 0.f, 0.f);
 		}
 	}
+	// views of this set that exist: with fewer than eight, the idle view groups take (hypothesis, view) pairs of their own --
+	// pair p = 8 * pass + group -> hypothesis p / nAct, view p % nAct -- so a chunk costs ceil(n * nAct / 8) tap passes instead
+	// of n.  Every pair is evaluated exactly as in the plain loop (same lanes-per-view layout), only by another group.
+	const int nAct = __builtin_amdgcn_readfirstlane(c.V - vbase < NV ? c.V - vbase : NV);
 	auto taps_of = [&](auto nr) {
 		constexpr int NR = decltype(nr)::value;
+		if constexpr (S == 8 && PACK) { // instantiated for view counts that leave groups idle (not 8 or 16 views)
+			if (nAct < NV) {
+				uint32_t slots = 0; // nibble j: slot (hypothesis index - base) of the j-th hypothesis of the chunk
+				int n = 0;
+				for (unsigned long long td = todo; td; td &= td - 1ull, ++n) slots |= (uint32_t)(__builtin_ctzll(td) - base) << (4 * n);
+				const int total = n * nAct;
+				const uint32_t inv = (65536u + (uint32_t)nAct - 1u) / (uint32_t)nAct; // p / nAct == (p * inv) >> 16 for p < 128
+				for (int k0 = 0; k0 < total; k0 += NV) {
+					const int p = k0 + L.vloc;
+					const bool valid = p < total;
+					const int pp = valid ? p : 0;
+					const int j = (int)(((uint32_t)pp * inv) >> 16), v = pp - j * nAct;
+					const int g = (int)((slots >> (4 * j)) & 15u);
+					LaneCtx<S> Lp = L; // the lane works for view vbase + v in this pass: that view's image constants
+					Lp.imgOff = (unsigned)__shfl((int)L.imgOff, v * S, 64); Lp.iw = __shfl(L.iw, v * S, 64);
+					Lp.wmax = __shfl(L.wmax, v * S, 64); Lp.hmax = __shfl(L.hmax, v * S, 64);
+					float H[9];
+					{
+						const float4 a = pk->hl[g][v][0], b = pk->hl[g][v][1], cc = pk->hl[g][v][2];
+						H[0] = a.x; H[1] = a.y; H[2] = a.z; H[3] = a.w; H[4] = b.x; H[5] = b.y; H[6] = b.z; H[7] = b.w; H[8] = cc.x;
+					}
+					float sum, sumSq, num;
+					bool viewBad;
+					if constexpr (NR == 0) score_taps_big<S>(c, Lp, st, H, sum, sumSq, num, viewBad);
+					else score_taps<S, NR>(c, Lp, P, st, H, sum, sumSq, num, viewBad);
+					if (L.seg == 0 && valid) pk->acc[g][v] = make_float4(sum, sumSq, num, viewBad ? 1.f : 0.f);
+				}
+				issued += (unsigned)n;
+				return;
+			}
+		}
 		for (unsigned long long td = todo; td; td &= td - 1ull) {
 			const int g = __builtin_ctzll(td) - base;
 			float H[9];
@@ -1105,7 +1140,7 @@ __device__ __forceinline__ float share_scores(RowShared<NW>& sh, int& par, int l
 // 1484).  Refinement trials depend on earlier accepts: after an accepted trial the later ones are regenerated.
 // TWO: the estimate has 9..16 source views: a second set of eight view groups (L1: views 8..15 in the same lane layout) is
 // scored after the first, and the two best views are taken over both
-template <int S, int NW, bool BIG, bool TWO>
+template <int S, int NW, bool BIG, bool TWO, bool PACK>
 __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S>& L, const LaneCtx<S>& L1, RowShared<NW>& sh, int& par, int wv,
                                               int x, int y, int q, int iter, const PixIn<S>& in, const Patch<S>& P,
                                               const LdsStore<S>& st, RowPipe<S>& pp, unsigned& evals, unsigned& issued STAMP_ARGS) {
@@ -1254,10 +1289,10 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			const unsigned long long todo = vmask & ((1ull << top) - 1ull) & ~((1ull << base) - 1ull); // top <= 32
 			STAMP(4)
 			if (todo) {
-				score_chunk<S, BIG>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, todo, base, __builtin_ctzll(todo), best1, best2, issued);
+				score_chunk<S, BIG, PACK>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, todo, base, __builtin_ctzll(todo), best1, best2, issued);
 				if constexpr (TWO) {
 					unsigned again = 0;
-					score_chunk<S, BIG>(c, L1, P, st, G.v0, G.v1, F, hd, h0, h1, h2, todo, base, __builtin_ctzll(todo), best1, best2, again);
+					score_chunk<S, BIG, PACK>(c, L1, P, st, G.v0, G.v1, F, hd, h0, h1, h2, todo, base, __builtin_ctzll(todo), best1, best2, again);
 				}
 			}
 		}
@@ -1321,10 +1356,10 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			const float hpd = -hd * dot3(h0, h1, h2, G.v0, G.v1, 1.f); // InitPlane
 			const float F = smooth_pass(c, st.pk->cl, closeMask, eligMask, lane, hd, h0, h1, h2, h0, h1, h2, hpd, 63);
 			float s1 = __builtin_huge_valf(), s2 = __builtin_huge_valf();
-			score_chunk<S, BIG>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, 1ull, 0, 0, s1, s2, issued);
+			score_chunk<S, BIG, PACK>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, 1ull, 0, 0, s1, s2, issued);
 			if constexpr (TWO) {
 				unsigned again = 0;
-				score_chunk<S, BIG>(c, L1, P, st, G.v0, G.v1, F, hd, h0, h1, h2, 1ull, 0, 0, s1, s2, again);
+				score_chunk<S, BIG, PACK>(c, L1, P, st, G.v0, G.v1, F, hd, h0, h1, h2, 1ull, 0, 0, s1, s2, again);
 			}
 			const float nconf = rlf(two_best(c, s1, s2), 0);
 			++evals;
@@ -1353,7 +1388,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 #ifndef HCMVS_OCC
 #define HCMVS_OCC 3 // waves per SIMD the register allocation of the 5..8-view sweep worker is held to (diagnostic builds vary it)
 #endif
-template <int S, int NW, bool BIG, bool TWO = false>
+template <int S, int NW, bool BIG, bool TWO = false, bool PACK = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 && !BIG ? HCMVS_OCC : 1, S >= 8 && !BIG ? HCMVS_OCC : 2))) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
                                                         int iter, int lag, int affinity) {
 	__shared__ RowShared<NW> sh;
@@ -1471,7 +1506,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 			}
 			STAMP(0)
 			const unsigned e0 = evals;
-			process_pixel<S, NW, BIG, TWO>(c, L, L1, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
+			process_pixel<S, NW, BIG, TWO, PACK>(c, L, L1, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
 			taps += (unsigned long long)(evals - e0) * (unsigned)((P.a + 1) * (P.a + 1));
 		}
 		if (pp.fail) break;
@@ -2220,8 +2255,17 @@ static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int
 	case 64: hipLaunchKernelGGL((sweep_kernel<64, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
 	case 32: hipLaunchKernelGGL((sweep_kernel<32, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
 	case 16: hipLaunchKernelGGL((sweep_kernel<16, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
-	case 8: hipLaunchKernelGGL((sweep_kernel<8, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
-	default: hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break; // 9..16 views
+	// 5..8 and 9..16 views: the 8 x 8 lane layout, once or twice; a view count that leaves two or more view groups idle takes
+	// the variant whose idle groups work on (hypothesis, view) pairs of their own (score_chunk PACK; with one idle group it costs
+	// more than it saves)
+	case 8:
+		if (V % 8 == 0 || V % 8 == 7) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
+		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, true>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
+		break;
+	default:
+		if (V % 8 == 0 || V % 8 == 7) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
+		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, true>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
+		break;
 	}
 }
 void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int lag,
