@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="independent reference images per step and GPU (1..32)")
+    ap.add_argument("--batch", type=int, default=32, help="independent reference images per step and GPU (1..64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse", action="store_true", help="skip the FuseDepthMaps points/s figure")
     ap.add_argument("--no-pmc", action="store_true", help="take roofline.traffic / the VALU counters from profiles/ instead of measuring them "
