@@ -550,7 +550,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : (n_items == 2 ? 2 : 3)); // measured: profiles/r02_knobs.txt
 		// the band worker serves the throughput case: 5..8 source views, patches up to 8 x 8 taps, at most 8 neighbour slots per
 		// pixel (4 at outer iteration 0; the cross pattern has 4 * ceil(halfwin / step), DepthMap.cpp:1071-1078), one wave per row
-		bool useBand = c->bandWorker && nw == 1 && hcmvs::segments_for(items[0].n_src) == 8 && p->adapthalfwin <= kHalfWindow;
+		bool useBand = c->bandWorker && nw == 1 && hcmvs::segments_for(items[0].n_src) == 8 && items[0].n_src >= 5 && p->adapthalfwin <= kHalfWindow;
 		if (useBand && p->it_external >= 1) {
 			const int step = p->propagate_step > 0 ? p->propagate_step : 1;
 			const int hw = std::min(7, std::max(5, p->propagate_halfwin));

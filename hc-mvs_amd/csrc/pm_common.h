@@ -62,8 +62,8 @@ struct SweepSync {
 	unsigned long long* evals;  // [0] ScorePixel calls of the sequential algorithm, [1] evaluations issued (incl. speculative), [2] patch taps of [0]
 };
 
-// lane layout class for V source views = lanes per view group: 1 -> 64, 2 -> 32, 3..4 -> 16, 5..8 -> 8; 4 stands for 9..16 views, which run
-// the 8-lane layout twice (two sets of eight view groups)
+// lane layout class for V source views (the items of a batch must share it): 8 for up to 8 views, 4 for 9..16 views, which run
+// the 8 x 8 lane layout twice (two sets of eight view groups)
 int segments_for(int V);
 
 // launch wrappers (pm_kernels.hip)

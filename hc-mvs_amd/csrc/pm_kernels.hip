@@ -2209,9 +2209,10 @@ void debug_read_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
-// lane layout class of an estimate with V source views: tap segments per view group; 4 stands for "9..16 views", which run
-// the 8-segment layout twice (two sets of eight view groups, TWO in the kernels)
-int segments_for(int V) { return V <= 1 ? 64 : (V <= 2 ? 32 : (V <= 4 ? 16 : (V <= 8 ? 8 : 4))); }
+// lane layout class of an estimate with V source views.  Every estimate runs the 8 view groups x 8 tap segments layout: once
+// for up to 8 views (class 8), twice for 9..16 (class 4: two sets of eight view groups, TWO in the kernels); view counts that
+// leave groups idle let them work on (hypothesis, view) pairs of their own (PACK)
+int segments_for(int V) { return V <= 8 ? 8 : 4; }
 
 void launch_gray_to_u8(const float* gray, uint8_t* out, int n, hipStream_t s) {
 	hipLaunchKernelGGL(gray_to_u8_kernel, dim3(2048), dim3(256), 0, s, gray, out, n);
@@ -2229,13 +2230,9 @@ void launch_median3(const float* in, float* out, int W, int H, hipStream_t s) {
 template <bool BIG>
 static void launch_score_big(const EstConst& c, unsigned long long* evals, hipStream_t s) {
 	const dim3 grid(4096), block(256);
-	switch (segments_for(c.V)) {
-	case 64: hipLaunchKernelGGL((score_kernel<64, BIG>), grid, block, 0, s, c, evals); break;
-	case 32: hipLaunchKernelGGL((score_kernel<32, BIG>), grid, block, 0, s, c, evals); break;
-	case 16: hipLaunchKernelGGL((score_kernel<16, BIG>), grid, block, 0, s, c, evals); break;
-	case 8: hipLaunchKernelGGL((score_kernel<8, BIG>), grid, block, 0, s, c, evals); break;
-	default: hipLaunchKernelGGL((score_kernel<8, BIG, true>), grid, block, 0, s, c, evals); break; // 9..16 views: two sets of eight
-	}
+	if (c.V <= 8) hipLaunchKernelGGL((score_kernel<8, BIG>), grid, block, 0, s, c, evals);
+	else hipLaunchKernelGGL((score_kernel<8, BIG, true>), grid, block, 0, s, c, evals); // 9..16 views: two sets of eight
+
 }
 void launch_score_pass(const EstConst& c, const float* depthIn, const float* normalIn, unsigned long long* evals,
                        hipStream_t s) {
@@ -2251,22 +2248,17 @@ static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int
 	int grid = totalRows < 8192 ? totalRows : 8192;
 	if (grid < 1) return;
 	const dim3 g(grid), b(64 * NW);
-	switch (segments_for(V)) {
-	case 64: hipLaunchKernelGGL((sweep_kernel<64, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
-	case 32: hipLaunchKernelGGL((sweep_kernel<32, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
-	case 16: hipLaunchKernelGGL((sweep_kernel<16, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity); break;
-	// 5..8 and 9..16 views: the 8 x 8 lane layout, once or twice; a view count that leaves two or more view groups idle takes
-	// the variant whose idle groups work on (hypothesis, view) pairs of their own (score_chunk PACK; with one idle group it costs
-	// more than it saves)
-	case 8:
-		if (V % 8 == 0 || V % 8 == 7) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
+	// a view count that leaves two or more of a set's eight view groups idle takes the variant whose idle groups work on
+	// (hypothesis, view) pairs of their own (score_chunk PACK; with one idle group it costs more than it saves)
+	const bool pack = V % 8 != 0 && V % 8 != 7;
+	if (V <= 8) {
+		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
 		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, true>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
-		break;
-	default:
-		if (V % 8 == 0 || V % 8 == 7) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
+	} else {
+		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
 		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, true>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
-		break;
 	}
+
 }
 void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int lag,
                   int wavesPerRow, int affinity, hipStream_t s) {

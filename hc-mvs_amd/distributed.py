@@ -114,7 +114,7 @@ def densify_scene(ctx, views, srcs, neighbors, order, init, params, group=None, 
         rng[j, 0], rng[j, 1] = float(dmin), float(dmax)
         base = slabs[j].data_ptr()
         v = len(srcs[img])
-        cls = 1 if v <= 1 else 2 if v <= 2 else 4 if v <= 4 else 8 if v <= 8 else 16   # one kernel lane layout per class
+        cls = 8 if v <= 8 else 16   # the items of a batch share a lane-layout class (up to 8 views, or 9..16)
         items_by_class.setdefault(cls, []).append(dict(ref_id=img, src_ids=list(srcs[img]), d_min=float(dmin), d_max=float(dmax),
                                                        d_depth=base, d_normal=base + 4 * hw, d_conf=base + 16 * hw, seed_offset=img))
     torch.cuda.synchronize(dev)

@@ -128,7 +128,7 @@ int hcmvs_estimate_device(hcmvs_ctx* ctx, uint32_t ref_id, const uint32_t* src_i
                           const hcmvs_params* params, float d_min, float d_max, float* d_depth, float* d_normal,
                           float* d_conf);
 /* A batch of independent EstimateDepthMap calls (different reference images, the same options, source-view counts
- * of one class: 1, 2, 3-4, 5-8 or 9-16) in ONE set of launches: the sweep kernel interleaves the rows of all items, so the images fill each
+ * of one class: up to 8, or 9-16) in ONE set of launches: the sweep kernel interleaves the rows of all items, so the images fill each
  * other's wavefront ramps (the reference overlaps images with two worker threads, SceneDensify.cpp:3699).
  * Every item produces exactly the maps hcmvs_estimate_device would produce for it with seed + seed_offset.
  * 1 <= n_items <= HCMVS_MAX_BATCH. */

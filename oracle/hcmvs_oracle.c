@@ -369,10 +369,9 @@ typedef struct {
 } est_ctx;
 
 static int device_segments(int V) {
-	if (V <= 1) return 64;
-	if (V <= 2) return 32;
-	if (V <= 4) return 16;
-	return 8; /* 5..8 views; 9..16 views run the same layout twice (two sets of eight view groups) */
+	(void)V;
+	return 8; /* the kernels run one lane layout for every view count: 8 tap segments per view (9..16 views: two sets of eight
+	           * view groups; the per-view arithmetic does not depend on which lane group evaluates it) */
 }
 
 static void ctx_init(est_ctx* c, const hcor_view* ref, const hcor_view* srcs, int V, const uint8_t* gra,

@@ -242,8 +242,8 @@ def _batch_run(ctx, torch, scenes, pg, seed_offsets, refs=None):
 
 
 def test_batch_more_than_eight_views_and_cross_pattern(ctx):
-    """the S = 4 lane layout (9..16 source views, two patch columns per segment) and the outer-iteration cross pattern
-    inside a batch: every item equals the oracle bit for bit"""
+    """9..16 source views (two sets of eight view groups, pair packing in the partly filled one) and the outer-iteration cross
+    pattern inside a batch: every item equals the oracle bit for bit"""
     torch = pytest.importorskip("torch")
     scenes = [_scene(88, 72, 90.0, 10, seed=41), _scene(88, 72, 90.0, 10, seed=42), _scene(72, 88, 90.0, 10, seed=43)]
     pg, po = _params(adapthalfwin=6, n_estimation_iters=2, seed=77, it_external=1, n_external_iters=3, propagate_halfwin=5,
@@ -309,16 +309,17 @@ def test_full_size_schedule_invariance():
 
 
 def test_batch_mixed_view_counts(ctx):
-    """items with 5, 7 and 8 source views share one launch (same lane layout class); 3 and 8 do not"""
+    """items with 5, 8, 7 and 3 source views share one launch (one lane layout class up to 8 views: idle view groups of an item
+    take (hypothesis, view) pairs of their own); 9 and 8 views do not"""
     torch = pytest.importorskip("torch")
-    scenes = [_scene(96, 80, 90.0, 5, seed=71), _scene(96, 80, 90.0, 8, seed=72), _scene(80, 96, 90.0, 7, seed=73)]
+    scenes = [_scene(96, 80, 90.0, 5, seed=71), _scene(96, 80, 90.0, 8, seed=72), _scene(80, 96, 90.0, 7, seed=73), _scene(88, 72, 90.0, 3, seed=76)]
     pg, po = _params(adapthalfwin=6, n_estimation_iters=2, seed=33)
-    got, keep = _batch_run(ctx, torch, scenes, pg, [0, 1, 2])
+    got, keep = _batch_run(ctx, torch, scenes, pg, [0, 1, 2, 3])
     for si, ((views, pts), g, k) in enumerate(zip(scenes, got, keep)):
         po.seed = 33 + si
         _compare(g, O.estimate(views, po, k[5], k[6], k[3], k[4])[:3])
     with pytest.raises(binding.HcmvsError):
-        _batch_run(ctx, torch, [_scene(96, 80, 90.0, 3, seed=74), _scene(96, 80, 90.0, 8, seed=75)], pg, [0, 1])
+        _batch_run(ctx, torch, [_scene(96, 80, 90.0, 9, seed=74), _scene(96, 80, 90.0, 8, seed=75)], pg, [0, 1])
 
 
 def test_matches_committed_golden(ctx):
