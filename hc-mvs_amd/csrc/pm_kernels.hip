@@ -200,7 +200,7 @@ __device__ __forceinline__ void lane_init(const EstConst& c, LaneCtx<S>& L, int 
 template <int S>
 struct Patch { // DepthMap.h:202-212 WeightedPatchFix, spread over the lanes of a group
 	static constexpr int MAXM = 64 / S;
-	float px0;        // image column of the lane's first tap (S >= 8: of all its taps)
+	float px0;        // image column of the lane's taps (a segment owns one patch column)
 	float sumW, invSumW, normSq0;
 	int x, y, a;
 };
@@ -214,10 +214,10 @@ struct RegStore {
 	static constexpr int MAXM = 64 / S;
 	float A[9], Hm[3];
 	float py[MAXM], w[MAXM], tw[MAXM];
-	float (*stage)[8][8]; // S == 8: [3][column][row] LDS of this wave, the hand-over between the patch and the scorer lane layouts
+	float (*stage)[8][8]; // [3][column][row] LDS of this wave, the hand-over between the patch and the scorer lane layouts
 	float (*bw)[kBigSlots]; // big-patch kernels: [4][slot] px | py | w | tw of this wave (LDS), see fill_patch_big
 	int seg;
-	// S == 8: the lane that computed tap (row, col) hands it to the scorer lanes of column col
+	// the lane that computed tap (row, col) hands it to the scorer lanes of column col
 	__device__ __forceinline__ void put_patch64(int row, int col, float py_, float w_, float tw_) {
 		stage[0][col][row] = py_; stage[1][col][row] = w_; stage[2][col][row] = tw_; // same-wave LDS accesses are ordered
 #pragma unroll
@@ -228,10 +228,6 @@ struct RegStore {
 		for (int i = 0; i < 9; ++i) A[i] = dv->A[i];
 #pragma unroll
 		for (int i = 0; i < 3; ++i) Hm[i] = dv->Hm[i];
-	}
-	__device__ __forceinline__ void put_patch(const float (&py_)[MAXM], const float (&w_)[MAXM], const float (&tw_)[MAXM]) {
-#pragma unroll
-		for (int m = 0; m < MAXM; ++m) { py[m] = py_[m]; w[m] = w_[m]; tw[m] = tw_[m]; }
 	}
 	__device__ __forceinline__ void copy_patch(const RegStore& o) {
 #pragma unroll
@@ -255,9 +251,8 @@ struct RegStore {
 template <int S>
 struct WavePark { // LDS of one wave of a row worker
 	static constexpr int MAXM = 64 / S;
-	float4 vh[S == 8 ? 16 : 64 / S][3]; // per view: A[0..8], Hm[0..2] (S == 8: two sets of eight views, see TWO in the kernels)
-	float pw[S == 8 ? 1 : 3 * MAXM][64]; // S != 8: py | w | tw per lane, see LdsStore
-	float ps[3][8][8];        // S == 8: py | w | tw as [column][row], read by every view group
+	float4 vh[16][3];         // per view: A[0..8], Hm[0..2] (two sets of eight views, see TWO in the kernels)
+	float ps[3][8][8];        // py | w | tw as [column][row], read by every view group
 	float cl[9][kMaxSlots];   // smoothness neighbours, slot k at [.][k]: X0 X1 X2 | n0 n1 n2 | k0 k1 k2 (see Close)
 	float4 hl[8][64 / S][3];  // homographies of the (hypothesis, view) pairs of the current chunk of eight hypotheses
 	float4 acc[8][64 / S];    // their ZNCC sums: sum, sumSq, num, 1 if a tap left the image
@@ -265,7 +260,6 @@ struct WavePark { // LDS of one wave of a row worker
 template <int S>
 struct LdsStore {
 	static constexpr int MAXM = 64 / S;
-	static constexpr bool V4 = MAXM % 4 == 0; // 16-byte LDS accesses when a lane holds whole groups of four taps
 	WavePark<S>* pk;
 	float (*bw)[kBigSlots]; // big-patch kernels: [4][slot] px | py | w | tw of this wave (LDS), see fill_patch_big
 	int lane, view;
@@ -276,36 +270,10 @@ struct LdsStore {
 			pk->vh[view][2] = make_float4(dv->A[8], dv->Hm[0], dv->Hm[1], dv->Hm[2]);
 		}
 	}
-	__device__ __forceinline__ void put_arr(int base, const float (&v)[MAXM]) {
-		if constexpr (V4) {
-			float4* q = (float4*)&pk->pw[0][0];
-#pragma unroll
-			for (int k = 0; k < MAXM / 4; ++k) q[(base / 4 + k) * 64 + lane] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-		} else {
-#pragma unroll
-			for (int m = 0; m < MAXM; ++m) pk->pw[base + m][lane] = v[m];
-		}
-	}
-	__device__ __forceinline__ void get_arr(int base, int ol, float (&v)[MAXM]) const {
-		if constexpr (V4) {
-			const float4* q = (const float4*)&pk->pw[0][0];
-#pragma unroll
-			for (int k = 0; k < MAXM / 4; ++k) {
-				const float4 t = q[(base / 4 + k) * 64 + ol];
-				v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
-			}
-		} else {
-#pragma unroll
-			for (int m = 0; m < MAXM; ++m) v[m] = pk->pw[base + m][ol];
-		}
-	}
-	__device__ __forceinline__ void put_patch(const float (&py_)[MAXM], const float (&w_)[MAXM], const float (&tw_)[MAXM]) {
-		put_arr(0, py_); put_arr(MAXM, w_); put_arr(2 * MAXM, tw_);
-	}
-	__device__ __forceinline__ void put_patch64(int row, int col, float py_, float w_, float tw_) { // S == 8
+	__device__ __forceinline__ void put_patch64(int row, int col, float py_, float w_, float tw_) {
 		pk->ps[0][col][row] = py_; pk->ps[1][col][row] = w_; pk->ps[2][col][row] = tw_;
 	}
-	__device__ __forceinline__ void get_col(int k, int os, float (&v)[MAXM]) const { // S == 8: eight rows of my column
+	__device__ __forceinline__ void get_col(int k, int os, float (&v)[MAXM]) const { // the eight rows of my column
 		const float4* q = (const float4*)&pk->ps[k][os][0];
 		const float4 a = q[0], b = q[1];
 		v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -319,17 +287,11 @@ struct LdsStore {
 		Hm_[0] = cc.y; Hm_[1] = cc.z; Hm_[2] = cc.w;
 	}
 	__device__ __forceinline__ void get_py(float (&o)[MAXM]) const {
-		if constexpr (S == 8) get_col(0, opaque(lane & 7), o);
-		else get_arr(0, opaque(lane), o);
+		get_col(0, opaque(lane & 7), o);
 	}
 	__device__ __forceinline__ void get_w(float (&w_)[MAXM], float (&tw_)[MAXM]) const {
-		if constexpr (S == 8) {
-			const int os = opaque(lane & 7);
-			get_col(1, os, w_); get_col(2, os, tw_);
-		} else {
-			const int ol = opaque(lane);
-			get_arr(MAXM, ol, w_); get_arr(2 * MAXM, ol, tw_);
-		}
+		const int os = opaque(lane & 7);
+		get_col(1, os, w_); get_col(2, os, tw_);
 	}
 };
 
@@ -354,92 +316,25 @@ struct PixIn {
 
 __device__ __forceinline__ int patch_halfwin(const EstConst& c, float tx) { return tx > 100.f ? 5 : c.adapthalfwin; } // DepthMap.cpp:455-461
 
-// Tap handled by segment `seg` at step m.  A segment owns ONE patch column and walks down its rows
-// (S = 8: all rows; 16/32/64: a half / quarter / single row run; S = 4: two columns), so (a) the lanes of a
-// view group read the same source-image row in each load instruction -- a handful of cache lines per
-// wave-instruction instead of 64 -- and (b) a lane's warped position is affine in m.
-// Row/column indices past the patch clamp to the last one (those taps get zero weight).
-template <int S>
-__device__ __forceinline__ bool tap_offset(int a, int seg, int m, int& i, int& j) {
-	const int nside = a + 1;
-	int row, col;
-	if constexpr (S >= 8) {
-		constexpr int RH = 64 / S; // rows per segment
-		col = seg & 7;
-		row = (seg >> 3) * RH + m;
-	} else {
-		col = seg * 2 + (m >> 3);
-		row = m & 7;
-	}
-	const bool valid = row < nside && col < nside;
-	row = row < nside ? row : nside - 1;
-	col = col < nside ? col : nside - 1;
-	i = -a + 2 * row; j = -a + 2 * col;
-	return valid;
-}
-
+// The scorer's lanes are 8 view groups x 8 tap segments: a segment owns ONE patch column and walks down its rows, so (a) the
+// lanes of a view group read the same source-image row in each load instruction -- a handful of cache lines per wave-instruction
+// instead of 64 -- and (b) a lane's warped position is affine in the step.  (Round 2 started with one layout per view-count class;
+// every view count now runs this one.)
 template <int S>
 __device__ __forceinline__ void load_patch_inputs(const EstConst& c, const LaneCtx<S>& L, int x, int y, PixIn<S>& in) {
-	constexpr int MAXM = 64 / S;
+	static_assert(S == 8, "one lane layout: 8 view groups x 8 tap segments");
 	gcfptr ref = (gcfptr)c.ref;
 	const int a = patch_halfwin(c, in.tx);
 	in.center = ref[y * c.W + x];
-	if constexpr (S == 8) { // one tap of the patch per lane: lane = 8 * row + column (lanes past the patch repeat its last row / column)
-		const int row = L.lane >> 3, col = L.lane & 7;
-		const int i = -a + 2 * (row < a ? row : a), j = -a + 2 * (col < a ? col : a);
-		in.I[0] = ref[__mul24(y + i, c.W) + (x + j)];
-	} else {
-#pragma unroll
-		for (int m = 0; m < MAXM; ++m) {
-			int i, j;
-			tap_offset<S>(a, L.seg, m, i, j);
-			in.I[m] = ref[__mul24(y + i, c.W) + (x + j)];
-		}
-	}
+	// one tap of the patch per lane: lane = 8 * row + column (lanes past the patch repeat its last row / column)
+	const int row = L.lane >> 3, col = L.lane & 7;
+	const int i = -a + 2 * (row < a ? row : a), j = -a + 2 * (col < a ? col : a);
+	in.I[0] = ref[__mul24(y + i, c.W) + (x + j)];
 }
 
 // DepthMap.cpp:450-519 FillPixelPatch + DepthMap.h:537-548 GetWeight.
 // Lanes whose tap index is past the patch repeat the last tap with zero weights: they add exactly +0.
-// NR: steps of a lane that can carry a tap (S == 8: the a + 1 rows of the patch; otherwise all 64 / S); the steps
-// past NR are such zero-weight repeats in every lane, so their arithmetic is skipped -- the sums are the same bits.
-template <int S, int NR, class ST>
-__device__ __forceinline__ void fill_patch_n(const EstConst& c, const LaneCtx<S>& L, int x, int y, int a, const PixIn<S>& in, Patch<S>& P, ST& st) {
-	constexpr int MAXM = 64 / S;
-	float Pw[MAXM], Ptw[MAXM], Ppy[MAXM];
-	const float sigmaColor = -1.f / (2.f * HC_SQ(0.2f));
-	const float sigmaSpatial = -1.f / (2.f * (float)HC_SQ(a));
-	float sa = 0.f, sb = 0.f;
-#pragma unroll
-	for (int m = 0; m < MAXM; ++m) {
-		int i, j;
-		const bool valid = tap_offset<S>(a, L.seg, m, i, j);
-		Ppy[m] = (float)(y + i);
-		if (m == 0) P.px0 = (float)(x + j);
-		if (m >= NR) { Pw[m] = 0.f; continue; }
-		const float wColor = HC_SQ(in.I[m] - in.center) * sigmaColor;
-		const float wSpatial = (float)(HC_SQ(j) + HC_SQ(i)) * sigmaSpatial;
-		const float w = pm_expf(wColor + wSpatial);
-		Pw[m] = valid ? w : 0.f;
-		sa = fmaf(in.I[m], Pw[m], sa);
-		sb = sb + Pw[m];
-	}
-	const float swi = group_sum<S>(sa), sw = group_sum<S>(sb);
-	const float tm = swi / sw;
-	sa = 0.f;
-#pragma unroll
-	for (int m = 0; m < MAXM; ++m) {
-		if (m >= NR) { Ptw[m] = 0.f; continue; }
-		const float t = in.I[m] - tm;
-		Ptw[m] = Pw[m] * t;
-		sa = fmaf(Ptw[m], t, sa);
-	}
-	P.sumW = sw;
-	P.invSumW = 1.0f / sw;
-	P.normSq0 = group_sum<S>(sa);
-	P.x = x; P.y = y; P.a = a;
-	st.put_patch(Ppy, Pw, Ptw);
-}
-// 5..8 source views (S == 8): every tap of the (a + 1)^2 patch gets its own lane for the weights (lane = 8 * row + column;
+// Every tap of the (a + 1)^2 patch gets its own lane for the weights (lane = 8 * row + column;
 // lanes past the patch add exactly +0), the three sums are 64-lane butterflies, and the results are handed to the
 // scorer's layout (a segment = one column, all view groups alike) through 768 bytes of LDS.
 template <class ST>
@@ -515,8 +410,7 @@ __device__ __forceinline__ void fill_patch(const EstConst& c, const LaneCtx<S>& 
 	if constexpr (BIG) {
 		if (a > kHalfWindow) { fill_patch_big<S>(c, L, x, y, a, in.center, P, st); return; }
 	}
-	if constexpr (S == 8) fill_patch_64(c, L, x, y, a, in, P, st);
-	else fill_patch_n<S, 64 / S>(c, L, x, y, a, in, P, st);
+	fill_patch_64(c, L, x, y, a, in, P, st);
 }
 
 // smoothness neighbours (DepthMap.h:376-382 NeighborEstimate): slot k lives in lane k
@@ -568,26 +462,17 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 	bool bad;
 	{
 		float Xx[MAXM], Xy[MAXM], Xz[MAXM], iz[MAXM];
-		// a segment walks down one patch column: the column term of the warp is hoisted (S >= 8).  Steps past the
-		// patch repeat the last row (zero weights), so they change neither the sums nor the inside test.
+		// a segment walks down one patch column: the column term of the warp is hoisted.  Steps past the patch repeat the
+		// last row (zero weights), so they change neither the sums nor the inside test.
 		const float bx = fmaf(H[0], P.px0, H[2]), by = fmaf(H[3], P.px0, H[5]), bz = fmaf(H[6], P.px0, H[8]);
 #pragma unroll
 		for (int m = 0; m < MAXM; ++m) {
 			const float py = Ppy[m];
-			if constexpr (S >= 8) {
-				Xx[m] = fmaf(H[1], py, bx); Xy[m] = fmaf(H[4], py, by); Xz[m] = fmaf(H[7], py, bz);
-			} else { // S == 4: a segment covers two columns
-				int ti, tj;
-				tap_offset<S>(P.a, L.seg, m, ti, tj);
-				const float px = (float)(P.x + tj);
-				Xx[m] = fmaf(H[1], py, fmaf(H[0], px, H[2]));
-				Xy[m] = fmaf(H[4], py, fmaf(H[3], px, H[5]));
-				Xz[m] = fmaf(H[7], py, fmaf(H[6], px, H[8]));
-			}
+			Xx[m] = fmaf(H[1], py, bx); Xy[m] = fmaf(H[4], py, by); Xz[m] = fmaf(H[7], py, bz);
 		}
 		bool nan = false;
-		// perspective divide: ONE IEEE reciprocal per group of up to four taps (1/z_i = (1/prod z) * prod_{j!=i} z_j)
-		if constexpr (S == 8) { // one reciprocal for the (up to) eight steps of the lane; steps past the patch repeat the last row
+		// perspective divide
+		{ // ONE IEEE reciprocal for the (up to) eight steps of the lane, 1/z_i = (1/prod z) * prod_{j!=i} z_j; steps past the patch repeat the last row
 			constexpr int last = MAXM - 1;
 			const float z4 = Xz[4 < last ? 4 : last], z5 = Xz[5 < last ? 5 : last], z6 = Xz[6 < last ? 6 : last], z7 = Xz[last];
 			const float p01 = Xz[0] * Xz[1], p23 = Xz[2] * Xz[3], p45 = z4 * z5, p67 = z6 * z7;
@@ -600,27 +485,6 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 			iz[4] = r45 * z5; iz[5] = r45 * z4;
 			if constexpr (MAXM > 6) iz[6] = r67 * z7;
 			if constexpr (MAXM > 7) iz[7] = r67 * z6;
-		} else if constexpr (MAXM >= 4) {
-#pragma unroll
-			for (int g = 0; g < MAXM; g += 4) {
-				constexpr int last = MAXM - 1;
-				const int i1 = g + 1 < last ? g + 1 : last, i2 = g + 2 < last ? g + 2 : last, i3 = g + 3 < last ? g + 3 : last;
-				const float p01 = Xz[g] * Xz[i1], p23 = Xz[i2] * Xz[i3];
-				const float r = 1.0f / (p01 * p23);
-				nan = nan || !(fabsf(r) < __builtin_huge_valf()); // a zero / non-finite denominator poisons the group
-				const float r01 = r * p23, r23 = r * p01;
-				iz[g] = r01 * Xz[i1];
-				if (g + 1 <= last) iz[g + 1] = r01 * Xz[g];
-				if (g + 2 <= last) iz[g + 2] = r23 * Xz[i3];
-				if (g + 3 <= last) iz[g + 3] = r23 * Xz[i2];
-			}
-		} else if constexpr (MAXM == 2) {
-			const float r = 1.0f / (Xz[0] * Xz[1]);
-			nan = nan || !(fabsf(r) < __builtin_huge_valf());
-			iz[0] = r * Xz[1]; iz[1] = r * Xz[0];
-		} else {
-			iz[0] = 1.0f / Xz[0];
-			nan = nan || !(fabsf(iz[0]) < __builtin_huge_valf());
 		}
 		float qxlo = __builtin_huge_valf(), qxhi = -__builtin_huge_valf(), qylo = __builtin_huge_valf(), qyhi = -__builtin_huge_valf();
 #pragma unroll
@@ -764,12 +628,10 @@ __device__ __forceinline__ void score_pixel(const EstConst& c, const LaneCtx<S>&
 	bool viewBad;
 	if (BIG && P.a > kHalfWindow) {
 		score_taps_big<S>(c, L, st, H, sum, sumSq, num, viewBad);
-	} else if constexpr (S == 8) {
+	} else {
 		if (P.a == 6) score_taps<S, 7>(c, L, P, st, H, sum, sumSq, num, viewBad);
 		else if (P.a == 5) score_taps<S, 6>(c, L, P, st, H, sum, sumSq, num, viewBad);
 		else score_taps<S, 8>(c, L, P, st, H, sum, sumSq, num, viewBad);
-	} else {
-		score_taps<S, 64 / S>(c, L, P, st, H, sum, sumSq, num, viewBad);
 	}
 	const float s = view_score(c, sum, sumSq, num, viewBad, P.invSumW, P.normSq0, smoothF);
 	float m1 = L.vact ? s : __builtin_huge_valf(), m2 = __builtin_huge_valf();
@@ -794,7 +656,7 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 	                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)todoIn);
 	const int base = __builtin_amdgcn_readfirstlane(baseIn), fallback = __builtin_amdgcn_readfirstlane(fallbackIn);
 	constexpr int NV = 64 / S;               // views (lane groups) of a wave
-	constexpr int HP = S < 8 ? S : 8;        // hypotheses per pair-pass (lane = g * NV + v)
+	constexpr int HP = 8;                    // hypotheses per pair-pass (lane = g * NV + v)
 	WavePark<S>* pk = st.pk;
 	const int lane = L.lane, pv = lane % NV, pg = lane / NV;
 	const int vbase = __builtin_amdgcn_readfirstlane(L.view - L.vloc); // first view of the set
@@ -824,7 +686,7 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 	const int nAct = __builtin_amdgcn_readfirstlane(c.V - vbase < NV ? c.V - vbase : NV);
 	auto taps_of = [&](auto nr) {
 		constexpr int NR = decltype(nr)::value;
-		if constexpr (S == 8 && PACK) { // instantiated for view counts that leave groups idle (not 8 or 16 views)
+		if constexpr (PACK) { // instantiated for view counts that leave groups idle (not 7, 8, 15 or 16 views)
 			if (nAct < NV) {
 				uint32_t slots = 0; // nibble j: slot (hypothesis index - base) of the j-th hypothesis of the chunk
 				int n = 0;
@@ -872,12 +734,10 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 	};
 	if (BIG && P.a > kHalfWindow) {
 		taps_of(std::integral_constant<int, 0>()); // the big-patch scorer
-	} else if constexpr (S == 8) {
+	} else {
 		if (P.a == 6) taps_of(std::integral_constant<int, 7>());
 		else if (P.a == 5) taps_of(std::integral_constant<int, 6>());
 		else taps_of(std::integral_constant<int, 8>());
-	} else {
-		taps_of(std::integral_constant<int, 64 / S>());
 	}
 #pragma unroll
 	for (int p0 = 0; p0 < 8; p0 += HP) {
@@ -1043,8 +903,8 @@ __device__ __forceinline__ int wait_progress(HC_GLOBAL int32_t* word, int need, 
 template <int S>
 struct RowPipe {
 	uint8_t tx1;      // gradient-map byte of the next column (kept raw so that nothing waits on the load)
-	uint8_t tx2;      // S == 8: ... and of the one after it
-	float nI, nC;     // S == 8: reference-image tap / centre of the NEXT pixel, loaded a whole pixel ahead
+	uint8_t tx2;      // ... and of the one after it
+	float nI, nC;     // reference-image tap / centre of the NEXT pixel, loaded a whole pixel ahead
 	int known;        // columns the previous logical row is known to have finished
 	int poll;         // progress value of an in-flight poll
 	int pendingPub;   // > 0: results up to this column are stored but not yet published
@@ -1097,7 +957,6 @@ __device__ __forceinline__ void slot_setup(const EstConst& c, int lane, int x, i
 template <int S>
 __device__ __forceinline__ void prefetch_static(const EstConst& c, const LaneCtx<S>& L, int x, int y, int q, bool rev, bool upKnown, PixIn<S>& in) {
 	slot_setup<S>(c, L.lane, x, y, rev, in);
-	if constexpr (S != 8) load_patch_inputs<S>(c, L, x, y, in); // S == 8: the sweep loads them one pixel ahead
 	const int idx = y * c.W + x;
 	in.cur = load_dn(&c.dn[idx]);
 	in.curConf = load_f(&c.conf[idx]);
@@ -1389,7 +1248,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 #define HCMVS_OCC 3 // waves per SIMD the register allocation of the 5..8-view sweep worker is held to (diagnostic builds vary it)
 #endif
 template <int S, int NW, bool BIG, bool TWO = false, bool PACK = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 && !BIG ? HCMVS_OCC : 1, S >= 8 && !BIG ? HCMVS_OCC : 2))) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? HCMVS_OCC : 1, !BIG ? HCMVS_OCC : 2))) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
                                                         int iter, int lag, int affinity) {
 	__shared__ RowShared<NW> sh;
 	__shared__ WavePark<S> park[NW];
@@ -1467,7 +1326,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 		const int x0 = rev ? c.W - 1 - bd : bd;
 		const int dx = rev ? -1 : 1;
 		pp.tx1 = uniform_byte(c.gra, y * c.W + x0);
-		if constexpr (S == 8) { // the patch inputs travel one pixel ahead of the pixel being processed, the gradient byte two
+		{ // the patch inputs travel one pixel ahead of the pixel being processed, the gradient byte two
 			PixIn<S> first;
 			first.tx = (float)pp.tx1;
 			load_patch_inputs<S>(c, L, x0, y, first);
@@ -1481,19 +1340,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(S >= 8 
 			PixIn<S> in;
 			in.tx = (float)pp.tx1;
 			prefetch_static<S>(c, L, x, y, q, rev, pp.known >= q + 1, in);
-			if constexpr (S == 8) {
-				in.I[0] = pp.nI; in.center = pp.nC;
-				if (q + 1 < ncols) { // next pixel's patch inputs (its gradient byte arrived a pixel ago)
-					PixIn<S> nxt;
-					nxt.tx = (float)pp.tx2;
-					load_patch_inputs<S>(c, L, x + dx, y, nxt);
-					pp.nI = nxt.I[0]; pp.nC = nxt.center;
-				}
-				pp.tx1 = pp.tx2;
-				if (q + 2 < ncols) pp.tx2 = uniform_byte(c.gra, y * c.W + x + 2 * dx);
-			} else {
-				if (q + 1 < ncols) pp.tx1 = uniform_byte(c.gra, y * c.W + x + dx);
+			in.I[0] = pp.nI; in.center = pp.nC;
+			if (q + 1 < ncols) { // next pixel's patch inputs (its gradient byte arrived a pixel ago)
+				PixIn<S> nxt;
+				nxt.tx = (float)pp.tx2;
+				load_patch_inputs<S>(c, L, x + dx, y, nxt);
+				pp.nI = nxt.I[0]; pp.nC = nxt.center;
 			}
+			pp.tx1 = pp.tx2;
+			if (q + 2 < ncols) pp.tx2 = uniform_byte(c.gra, y * c.W + x + 2 * dx);
 			STAMP(12)
 			// ... and the patch weights are computed while they (and the previous row) arrive
 			Patch<S> P;
