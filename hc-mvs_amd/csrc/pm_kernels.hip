@@ -16,11 +16,13 @@
  *     + a per-row progress word.  The maps are identical to the sequential sweep.  The rows of several
  *     independent reference images share one launch (ticket t -> row t / nItems of item t % nItems) so the ramp
  *     of one image's wavefront is filled by the others.
- *   - INSIDE A WAVE the 64 lanes are (view group) x (tap segment): lane = view*S + seg.  A segment owns one
- *     patch column and walks down its rows; partial sums are combined with DPP butterflies inside the group, the
- *     per-view ZNCC epilogue runs lane-parallel over views and the "two best views" selection is a second
- *     butterfly across groups.  Hypothesis generation and the plane-smoothness terms are lane-parallel too.
- *     LDS holds only the row's own recent results (hist ring) and, for NW > 1, the 32-byte score exchange.
+ *   - INSIDE A WAVE the 64 lanes are 8 view groups x 8 tap segments: lane = 8 * view + seg, for every number of source
+ *     views (9..16 views: two sets of eight groups, TWO; view counts that leave groups idle let them score (hypothesis,
+ *     view) pairs of their own, PACK).  A segment owns one patch column and walks down its rows; partial sums are
+ *     combined with DPP butterflies inside the group, the per-view ZNCC epilogue runs lane-parallel over (hypothesis,
+ *     view) pairs and the "two best views" selection is a second butterfly across groups.  Hypothesis generation and the
+ *     plane-smoothness terms are lane-parallel too.  LDS holds the per-wave tables (patch weights, view constants,
+ *     neighbour slots, chunk homographies), the row's own recent results (hist ring) and, for NW > 1, the score exchange.
  *   - Rows are handed out by an atomic ticket in dependency order, so a waiting worker always waits on one
  *     that is already running: no deadlock for any grid size or dispatch order.  Every spin is bounded.
  *
