@@ -442,14 +442,8 @@ static int dev_tap(int S, int a, int seg, int m, int* ti, int* tj) {
 		*ti = kk / nside; *tj = kk % nside;
 		return k < nt;
 	}
-	if (S >= 8) {
-		const int RH = 64 / S;
-		col = seg & 7;
-		row = (seg >> 3) * RH + m;
-	} else {
-		col = seg * 2 + (m >> 3);
-		row = m & 7;
-	}
+	col = seg & 7; /* 8 tap segments per view: a segment owns one patch column and walks down its rows */
+	row = m;
 	const int valid = row < nside && col < nside;
 	*ti = row < nside ? row : nside - 1;
 	*tj = col < nside ? col : nside - 1;
@@ -503,8 +497,8 @@ static void fill_patch(const est_ctx* c, pix_state* ps, int x, int y) {
 	} else {
 		const int S = c->S, big = a > HCOR_HALF_WINDOW, MAXM = big ? (HCOR_MAX_TAPS + S - 1) / S : 64 / S, nside = ps->nside;
 		float pa[64], pb[64];
-		if (S == 8 && !big) {
-			/* 5..8 source views: the kernels give every tap of the patch its own lane (lane = 8 * row + column, lanes past
+		if (!big) {
+			/* up to 64 taps: the kernels give every tap of the patch its own lane (lane = 8 * row + column, lanes past
 			 * the patch add exactly +0) and sum the 64 lanes with the xor butterfly */
 			for (int l = 0; l < 64; ++l) {
 				const int row = l >> 3, col = l & 7;
@@ -525,7 +519,7 @@ static void fill_patch(const est_ctx* c, pix_state* ps, int x, int y) {
 				pa[l] = ps->tw[k] * t;
 			}
 			ps->sumW = sw; ps->normSq0 = butterfly_sum(pa, 64);
-		} else {
+		} else { /* patches beyond 64 taps: the taps are dealt round-robin to the S lanes of a view group (dev_tap) */
 		for (int s = 0; s < S; ++s) {
 			float sa = 0, sb = 0;
 			for (int m = 0; m < MAXM; ++m) {
@@ -688,7 +682,7 @@ static float score_view_dev(const est_ctx* c, const pix_state* ps, int v, float 
 		}
 		if (big) { /* beyond 64 taps: one IEEE reciprocal per tap */
 			for (int m = 0; m < MAXM; ++m) iz[m] = 1.0f / Xz[m];
-		} else if (S == 8) { /* 5..8 views: one IEEE reciprocal for the eight steps of a lane (steps past the patch repeat the last row) */
+		} else { /* one IEEE reciprocal for the eight steps of a lane (steps past the patch repeat the last row) */
 			const float q01 = Xz[0] * Xz[1], q23 = Xz[2] * Xz[3], q45 = Xz[4] * Xz[5], q67 = Xz[6] * Xz[7];
 			const float qa = q01 * q23, qb = q45 * q67;
 			const float r = 1.0f / (qa * qb);
@@ -696,19 +690,6 @@ static float score_view_dev(const est_ctx* c, const pix_state* ps, int v, float 
 			const float r01 = ra * q23, r23 = ra * q01, r45 = rb * q67, r67 = rb * q45;
 			iz[0] = r01 * Xz[1]; iz[1] = r01 * Xz[0]; iz[2] = r23 * Xz[3]; iz[3] = r23 * Xz[2];
 			iz[4] = r45 * Xz[5]; iz[5] = r45 * Xz[4]; iz[6] = r67 * Xz[7]; iz[7] = r67 * Xz[6];
-		} else if (MAXM >= 4) { /* one IEEE reciprocal per group of four taps */
-			for (int g = 0; g < MAXM; g += 4) {
-				const float q01 = Xz[g] * Xz[g + 1], q23 = Xz[g + 2] * Xz[g + 3];
-				const float r = 1.0f / (q01 * q23);
-				const float r01 = r * q23, r23 = r * q01;
-				iz[g] = r01 * Xz[g + 1]; iz[g + 1] = r01 * Xz[g];
-				iz[g + 2] = r23 * Xz[g + 3]; iz[g + 3] = r23 * Xz[g + 2];
-			}
-		} else if (MAXM == 2) {
-			const float r = 1.0f / (Xz[0] * Xz[1]);
-			iz[0] = r * Xz[1]; iz[1] = r * Xz[0];
-		} else {
-			iz[0] = 1.0f / Xz[0];
 		}
 		float sum = 0, sumSq = 0, num = 0;
 		for (int m = 0; m < MAXM; ++m) {
