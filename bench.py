@@ -17,10 +17,14 @@ With N > 1 every rank estimates its own reference image (independent units, no c
 path) and the packed {depth, normal, conf} maps are all-gathered over RCCL after each step, which is the
 exchange FuseDepthMaps needs (SceneDensify.cpp:3381-3449).  Prints ONE JSON line on rank 0.
 
-Beside the contract fields the line carries: `roofline` (SURVEY.md 8d tap-gather convention; `traffic` = HBM bytes per sweep
-launch measured NOW by rocprofv3 --pmc child runs of this same command, one pass per counter -- `traffic_source` says so, or
-names the committed profile used when rocprofv3 is not usable), `valu` (vector-ALU instruction counts from the same child runs),
-`roofline_single_unit`, `fuse` (FuseDepthMaps points/s on estimated maps), `cpu_baseline` (the oracle on the host cores).
+Beside the contract fields the line carries: `roofline` = the bound that limits the sweep kernel, the VECTOR ALU: `achieved` = wave64
+VALU instructions per second (SQ_INSTS_VALU of one launch / its duration), `peak` = 1024 SIMDs x 2.4 GHz / 2 cycles, `frac` = the
+issue fraction, `useful_flop_frac` = the flops SURVEY.md 8d counts (1.6 kflop per evaluation and view) over the 157.3 TFLOP/s vector
+peak, `traffic` = HBM bytes per launch; the counters are measured NOW by rocprofv3 --pmc child runs of this same command, one pass per
+counter set (`counter_source` says so, or names the committed profile used when rocprofv3 is not usable).  `roofline_convention` keeps
+the SURVEY.md 8d tap-gather figure (algorithmic bytes over the HBM peak; it passes 1.0 because the gather is served by L2 -- printed,
+not capped).  Also `roofline_single_unit`, `fuse` (FuseDepthMaps points/s on estimated maps), `cpu_baseline` (the oracle on the host
+cores).
 The default run takes about three minutes.
 """
 import argparse
@@ -36,6 +40,10 @@ sys.path.insert(0, ROOT)
 
 W, H, FOCAL, N_SRC, SWEEPS, AHW = 1920, 1080, 1600.0, 8, 8, 6
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+N_SIMD, CLOCK_HZ = 1024, 2.4e9        # 256 CUs x 4 SIMDs at the 2.4 GHz the kernel holds (GRBM_GUI_ACTIVE, MI355X_MICROARCH.md)
+VALU_PEAK_INSTS = N_SIMD * CLOCK_HZ / 2.0   # wave64 VALU instructions per second: one per 2 cycles and SIMD (plain f32 ops; the guide's rate)
+FP32_VECTOR_PEAK = 157.3e12           # MI355X vector fp32 peak, flop/s
+FLOP_PER_EVAL_VIEW = 1600.0           # useful flops of one ScorePixelImage evaluation (49 taps x ~32 flop)
 
 
 def host_cores():
@@ -168,7 +176,7 @@ def copy_bandwidth(dev):
     return round(best, 1)
 
 
-PMC_FILE = "r02_pmc.json"
+PMC_FILE = "r03_pmc.json"
 
 
 def pmc_value(batch, what):
@@ -361,47 +369,56 @@ def main():
             "kernel_ms": {"score_pass": round(st.ms_score, 3), "sweep_avg": round(st.ms_sweep_avg, 3),
                           "sweeps_total": round(st.ms_sweeps, 3), "end": round(st.ms_end, 3),
                           "estimate_total": round(st.ms_total, 3)},
-            # SURVEY.md 8d convention: tap-gather ALGORITHMIC bytes (every bilinear sample counts its 4 texels) over the HBM peak.
-            # The gather is served by L2 (see hbm_measured_frac): what actually bounds the kernel is the vector ALU (valu block).
-            "roofline": {"kernel": "sweep_kernel", "bound": "hbm", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None,
-                         "compulsory_bytes_per_launch": int(B * P * (4 * N_SRC + 4 + 40)),
-                         "algorithmic_bytes_per_launch": int(bytes_sweep),
-                         "avg_launch_ms": round(st.ms_sweep_avg, 3),
-                         "convention": "SURVEY.md 8d: algorithmic tap-gather bytes (4 texels per bilinear sample) over the HBM peak; the gather "
-                                       "is served by L2, so frac can pass 1 -- the physical HBM traffic is `traffic` (hbm_measured_frac), "
-                                       "the kernel is VALU-bound (valu block)"},
+            # SURVEY.md 8d convention, kept for continuity: tap-gather ALGORITHMIC bytes (every bilinear sample counts its 4 texels)
+            # over the HBM peak.  The gather is served by L2, so the fraction can pass 1: it says how many taps per second are
+            # sampled, not what limits the kernel -- that is `roofline` below (the vector ALU).
+            "roofline_convention": {"kernel": "sweep_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                    "compulsory_bytes_per_launch": int(B * P * (4 * N_SRC + 4 + 40)),
+                                    "algorithmic_bytes_per_launch": int(bytes_sweep),
+                                    "avg_launch_ms": round(st.ms_sweep_avg, 3),
+                                    "convention": "SURVEY.md 8d: algorithmic tap-gather bytes (4 texels per bilinear sample) over the HBM peak"},
         }
-        # roofline.traffic and the VALU counters: measured now in rocprofv3 --pmc child runs of this command (FETCH_SIZE / WRITE_SIZE
-        # are reported in KiB); the committed measurement of the same command only when that is not possible
+        # the counters of the sweep kernel: measured now in rocprofv3 --pmc child runs of this command (FETCH_SIZE / WRITE_SIZE are
+        # reported in KiB); the committed measurement of the same command only when that is not possible
         live = live_pmc(B) if world == 1 and not args.no_pmc else None
         if live:
             traffic = int((live["FETCH_SIZE"] + live["WRITE_SIZE"]) * 1024)
             vi, vb = int(live["SQ_INSTS_VALU"]), int(live.get("SQ_ACTIVE_INST_VALU", 0)) or None
-            out["roofline"]["traffic_source"] = "rocprofv3 --pmc child runs of this command, now (FETCH_SIZE + WRITE_SIZE, one pass per counter)"
+            source = "rocprofv3 --pmc child runs of this command, now (SQ_INSTS_VALU + SQ_ACTIVE_INST_VALU, FETCH_SIZE, WRITE_SIZE: one pass per set)"
         else:
             traffic, vi, vb = pmc_value(B, "hbm_bytes"), pmc_value(B, "valu_insts"), pmc_value(B, "valu_busy_quadcycles")
-            out["roofline"]["traffic_source"] = "profiles/%s (committed rocprofv3 --pmc measurement of this command)" % PMC_FILE
-        out["roofline"]["traffic"] = traffic
+            source = "profiles/%s (committed rocprofv3 --pmc measurement of this command)" % PMC_FILE
+        t_launch = st.ms_sweep_avg * 1e-3
+        evals_launch = (st.evals - B * P) / SWEEPS                   # ScorePixel evaluations of one sweep launch (each covers all views)
+        useful_flops = evals_launch * N_SRC * FLOP_PER_EVAL_VIEW
+        roof = {"kernel": "sweep_kernel<8,1> (batched row worker)", "bound": "valu",
+                "achieved": round(vi / t_launch, 1) if vi else None, "peak": VALU_PEAK_INSTS, "unit": "wave64 VALU instructions/s",
+                "frac": round(vi / t_launch / VALU_PEAK_INSTS, 4) if vi else None,
+                "useful_flop_frac": round(useful_flops / t_launch / FP32_VECTOR_PEAK, 4),
+                "useful_TFLOPs": round(useful_flops / t_launch / 1e12, 2),
+                "traffic": traffic, "avg_launch_ms": round(st.ms_sweep_avg, 3), "counter_source": source,
+                "peak_definition": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (plain f32 rate, MI355X_MICROARCH.md); useful flops = "
+                                   "evaluations x views x 1.6 kflop (SURVEY.md 8d) over the 157.3 TFLOP/s vector fp32 peak"}
         if traffic:
-            out["roofline"]["hbm_measured_frac"] = round(traffic / (st.ms_sweep_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-        out["roofline"]["copy_bandwidth_measured_GBs"] = copy_bandwidth(dev)
+            roof["hbm_frac"] = round(traffic / t_launch / 1e9 / HBM_PEAK_GBS, 5)
         if vi:
-            simd_cycles = 1024 * 2.4e9 * st.ms_sweep_avg * 1e-3   # 256 CUs x 4 SIMDs at the 2.4 GHz the kernel holds (GRBM_GUI_ACTIVE)
-            out["valu"] = {"insts_per_launch": vi, "insts_per_pixel_sweep": round(vi / (B * P), 1),
-                           # the guide's rate for plain f32 ops: a wave64 VALU instruction occupies the SIMD for 2 cycles
-                           "valu_issue_frac": round(vi * 2 / simd_cycles, 4),
-                           # measured on this chip (tools/valu_issue_bench.hip): fma/mul 2.3-2.8 cycles, logic 3.0, DPP / med3 / cvt /
-                           # mul24 / readlane / f64 4.2-4.7, rcp 8.2 -> this kernel's mix averages about 3 cycles per instruction
-                           "valu_pipe_frac_at_3_cycles": round(vi * 3 / simd_cycles, 4),
-                           "valu_busy_frac_rocprof_4_cycles": round(vb * 4 / simd_cycles, 4) if vb else None,
-                           "fp32_TFLOPs_if_1p6_flop_per_lane_inst": round(vi * 64 * 1.6 / (st.ms_sweep_avg * 1e-3) / 1e12, 1)}
+            simd_cycles = N_SIMD * CLOCK_HZ * t_launch
+            roof["insts_per_launch"] = vi
+            roof["insts_per_pixel_sweep"] = round(vi / (B * P), 1)
+            # the same instruction count priced at what this mix costs: measured on this chip (profiles/r02_valu_issue_bench.jsonl)
+            # fma/mul 2.3-2.8 cycles, logic 3.0, DPP / cvt / mul24 / readlane / f64 4.2-4.7, rcp 8.2 -> about 3 cycles per
+            # instruction; and rocprof's own busy counter (SQ_ACTIVE_INST_VALU, 4-cycle units)
+            roof["pipe_frac_at_3_cycles"] = round(vi * 3 / simd_cycles, 4)
+            roof["busy_frac_rocprof_4_cycles"] = round(vb * 4 / simd_cycles, 4) if vb else None
+        out["roofline"] = roof
+        out["roofline_convention"]["copy_bandwidth_measured_GBs"] = copy_bandwidth(dev)
         # the same roofline figure for ONE image alone (SURVEY.md 8d's literal `t` = one complete estimate): latency-bound by
         # the (W + H) x T_pixel critical path of its row wavefront
         taps_a1 = int(np.where(ctx.gradient_map(0)[7:H - 7, 7:W - 7] > 100, 36, (AHW + 1) ** 2).astype(np.int64).sum())
         bytes_1 = (int(st1.tap_evals) - taps_a1) / SWEEPS * N_SRC * 16.0 + P * 44.0
-        out["roofline_single_unit"] = {"kernel": "sweep_kernel (3 waves per row)", "bound": "hbm",
+        out["roofline_single_unit"] = {"kernel": "sweep_kernel<8,3> (one image alone: 3 waves per row, hcmvs_api.cpp waves-per-row policy)",
+                                       "bound": "latency of the row wavefront; the figure is in the SURVEY.md 8d convention (hbm)",
                                        "achieved": round(bytes_1 / (st1.ms_sweep_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(bytes_1 / (st1.ms_sweep_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                        "avg_launch_ms": round(st1.ms_sweep_avg, 3), "estimate_ms": round(st1.ms_total, 2)}

@@ -58,7 +58,7 @@ SYMBOLS = ["hcmvs_default_params", "hcmvs_create", "hcmvs_destroy", "hcmvs_last_
            "hcmvs_get_gradient_map", "hcmvs_estimate", "hcmvs_estimate_device", "hcmvs_estimate_batch_device", "hcmvs_get_stats",
            "hcmvs_splat_init", "hcmvs_triangulate_init", "hcmvs_triangulate_points", "hcmvs_set_depthmap", "hcmvs_set_depthmap_device", "hcmvs_get_depthmap",
            "hcmvs_set_neighbors", "hcmvs_filter", "hcmvs_set_fuse_order", "hcmvs_fuse", "hcmvs_fuse_cloud", "hcmvs_estimate_point_colors",
-           "hcmvs_estimate_point_normals", "hcmvs_postfilter"]
+           "hcmvs_estimate_point_normals", "hcmvs_postfilter", "hcmvs_resize_area_up"]
 
 
 def triangulate_points(w, h, K, R, Cc, points_xyz, avg_depth=0.0, add_corners=True):
@@ -72,6 +72,17 @@ def triangulate_points(w, h, K, R, Cc, points_xyz, avg_depth=0.0, add_corners=Tr
     if rc != 0:
         raise HcmvsError(rc, "triangulate_points failed")
     return depth, normal, dmin.value, dmax.value
+
+
+def resize_area_up(src, dst_w, dst_h):
+    """hcmvs_resize_area_up: cv::resize INTER_AREA enlarging an f32 map (h, w) or (h, w, channels); pure host code"""
+    s = np.ascontiguousarray(src, np.float32)
+    ch = 1 if s.ndim == 2 else s.shape[2]
+    out = np.empty((dst_h, dst_w) if s.ndim == 2 else (dst_h, dst_w, ch), np.float32)
+    rc = lib().hcmvs_resize_area_up(_f(s), s.shape[1], s.shape[0], ch, _f(out), dst_w, dst_h)
+    if rc != 0:
+        raise HcmvsError(rc, "resize_area_up failed")
+    return out
 
 
 def lib():
@@ -126,9 +137,10 @@ def lib():
         L.hcmvs_fuse.argtypes = [vp, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint64,
                                  fp, fp, u8p, u32p, u64p, u64p]
         L.hcmvs_fuse_cloud.argtypes = [vp, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Cloud)]
-        L.hcmvs_postfilter.argtypes = [vp, C.c_uint32, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, u64p]
+        L.hcmvs_postfilter.argtypes = [vp, C.c_uint32, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, u64p]
         L.hcmvs_estimate_point_colors.argtypes = [vp, C.c_uint64, fp, u32p, u32p, u8p]
         L.hcmvs_estimate_point_normals.argtypes = [vp, C.c_uint64, fp, u32p, u32p, C.c_int32, fp]
+        L.hcmvs_resize_area_up.argtypes = [fp, C.c_int32, C.c_int32, C.c_int32, fp, C.c_int32, C.c_int32]
         _lib = L
     return _lib
 
@@ -359,11 +371,9 @@ class Context:
                                                      vi.ctypes.data_as(C.POINTER(C.c_uint32)), n_neighbors, _f(out)))
         return out
 
-    def postfilter(self, vid, order, n_min_views_fuse=2, depth_diff_threshold=0.01, normal_diff_deg=25.0, depthweight=1.0, normalweight=1.0,
-                   gap_size=7):
+    def postfilter(self, vid, order, n_min_views_fuse=2, depth_diff_threshold=0.01, normal_diff_deg=25.0, gap_size=7):
         """RemoveSmallSegments (fork version) + GapInterpolation on the registered device maps of view vid; returns pixels filled"""
         ids = (C.c_uint32 * len(order))(*order)
         nf = C.c_uint64()
-        self._chk(lib().hcmvs_postfilter(self._h, vid, ids, len(order), n_min_views_fuse, depth_diff_threshold, normal_diff_deg, depthweight,
-                                         normalweight, gap_size, C.byref(nf)))
+        self._chk(lib().hcmvs_postfilter(self._h, vid, ids, len(order), n_min_views_fuse, depth_diff_threshold, normal_diff_deg, gap_size, C.byref(nf)))
         return nf.value

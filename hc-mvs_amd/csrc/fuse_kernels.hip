@@ -638,7 +638,9 @@ __global__ void gap_lines_kernel(float* dF, float* nF, float* conf, const uint8_
 			else {
 				const float t0 = (float)gra[i0], t1 = (float)gra[iu];
 				const float ratio = (t1 - t0) / t0;
-				fill = ratio <= 0.1f || is_depth_similar(depthFirst, depth, thr);
+				// the reference compares the float against the DOUBLE literal 0.1 (SceneDensify.cpp:2390 rows, :2720 columns): a ratio that
+				// rounds to 0.1f -- gradient pairs (10, 11), (20, 22) ... -- is above it and does not fill
+				fill = (double)ratio <= 0.1 || is_depth_similar(depthFirst, depth, thr);
 			}
 			if (fill) {
 				const float cnt1 = (float)(count + 1);

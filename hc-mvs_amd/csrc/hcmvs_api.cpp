@@ -36,6 +36,7 @@ struct View {
 	float* gray = nullptr;   // device
 	uint8_t* bgr = nullptr;  // device or null
 	uint8_t* gra = nullptr;  // device gradient map (lazy)
+	float4* quads = nullptr; // device 2 x 2 footprint layout of the gray image, built when the view first serves as a source view
 	bool owned = false;
 	double K[9], R[9], C[3];
 	// estimated maps registered for filter / fuse
@@ -83,7 +84,6 @@ struct hcmvs_ctx {
 	bool haveStats = false;
 	int sweepLag = 1;
 	int fuseOrder = 0; // hcmvs_set_fuse_order
-	int bandWorker = 0;  // HCMVS_BAND=1: the 8-row band worker for batches (pm_kernels.hip band_kernel)
 	int xcdAffinity = 1; // rows of an image prefer the workgroups of one XCD (HCMVS_XCD_AFFINITY=0 turns it off)
 	// filter / fuse scratch
 	DevMap* dMaps = nullptr; size_t capMaps = 0;
@@ -195,8 +195,6 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 	}
 	const char* lag = getenv("HCMVS_SWEEP_LAG");
 	if (lag && atoi(lag) >= 1) c->sweepLag = atoi(lag);
-	const char* bw = getenv("HCMVS_BAND");
-	if (bw) c->bandWorker = atoi(bw) != 0;
 	const char* aff = getenv("HCMVS_XCD_AFFINITY");
 	if (aff) c->xcdAffinity = atoi(aff) != 0;
 	const char* wpr = getenv("HCMVS_WAVES_PER_ROW"); // tuning knob: 1, 2, 3 or 4 waves cooperate on one image row
@@ -213,6 +211,7 @@ static void free_maps(View& v) {
 static void free_view(View& v) {
 	if (v.owned) { if (v.gray) (void)hipFree(v.gray); if (v.bgr) (void)hipFree(v.bgr); }
 	if (v.gra) (void)hipFree(v.gra);
+	if (v.quads) (void)hipFree(v.quads);
 	if (v.dNeighbors) (void)hipFree(v.dNeighbors);
 	free_maps(v);
 	v = View();
@@ -399,6 +398,15 @@ static int ensure_gradient(hcmvs_ctx* c, View& v) {
 	return HCMVS_OK;
 }
 
+// the layout the scorer samples a source view from (pm_kernels.hip quad_kernel), built once per view
+static int ensure_quads(hcmvs_ctx* c, View& v) {
+	if (v.quads) return HCMVS_OK;
+	HIPCHK(c, hipMalloc(&v.quads, (size_t)v.w * v.h * sizeof(float4)));
+	launch_quads(v.gray, v.quads, v.w, v.h, c->stream);
+	HIPCHK(c, hipGetLastError());
+	return HCMVS_OK;
+}
+
 int hcmvs_get_gradient_map(hcmvs_ctx* c, uint32_t id, uint8_t* out) {
 	if (!c || !out) return HCMVS_ERR_INVALID;
 	auto it = c->views.find(id);
@@ -441,7 +449,9 @@ static int build_item(hcmvs_ctx* c, int slot, const hcmvs_batch_item& it, const 
 	for (int v = 0; v < n_src; ++v) {
 		auto sit = c->views.find(it.src_ids[v]);
 		if (sit == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "estimate: unknown source view %u", it.src_ids[v]);
-		const View& s = sit->second;
+		View& s = sit->second;
+		rc = ensure_quads(c, s);
+		if (rc) return rc;
 		double KR[9], Hl[9], A[9];
 		mat3_mul(s.K, s.R, KR);
 		mat3_mul_bt(KR, ref.R, Hl);
@@ -450,7 +460,7 @@ static int build_item(hcmvs_ctx* c, int slot, const hcmvs_batch_item& it, const 
 		mat3_mul(Hl, Hr, A);
 		for (int i = 0; i < 9; ++i) hv[v].A[i] = (float)A[i];
 		hv[v].w = s.w; hv[v].h = s.h;
-		const uintptr_t b = (uintptr_t)s.gray, e = b + (size_t)s.w * s.h * 4;
+		const uintptr_t b = (uintptr_t)s.quads, e = b + (size_t)s.w * s.h * sizeof(float4);
 		if (b < lo) lo = b;
 		if (e > hi) hi = e;
 	}
@@ -459,10 +469,10 @@ static int build_item(hcmvs_ctx* c, int slot, const hcmvs_batch_item& it, const 
 	// compact slab owned by the context.
 	if (hi - lo < 0xFFFF0000ull) {
 		k.imgBase = (const char*)lo;
-		for (int v = 0; v < n_src; ++v) hv[v].byteOff = (uint32_t)((uintptr_t)c->views.find(it.src_ids[v])->second.gray - lo);
+		for (int v = 0; v < n_src; ++v) hv[v].byteOff = (uint32_t)((uintptr_t)c->views.find(it.src_ids[v])->second.quads - lo);
 	} else {
 		size_t total = 0;
-		for (int v = 0; v < n_src; ++v) { const View& s = c->views.find(it.src_ids[v])->second; total += ((size_t)s.w * s.h * 4 + 255) & ~(size_t)255; }
+		for (int v = 0; v < n_src; ++v) { const View& s = c->views.find(it.src_ids[v])->second; total += ((size_t)s.w * s.h * sizeof(float4) + 255) & ~(size_t)255; }
 		if (total >= 0xFFFF0000ull) return fail(c, HCMVS_ERR_INVALID, "estimate: the source images of one item exceed 4 GiB");
 		hcmvs_ctx::Slot& sl = c->slots[slot];
 		if (total > sl.capSlab) {
@@ -475,8 +485,8 @@ static int build_item(hcmvs_ctx* c, int slot, const hcmvs_batch_item& it, const 
 		size_t off = 0;
 		for (int v = 0; v < n_src; ++v) {
 			const View& s = c->views.find(it.src_ids[v])->second;
-			const size_t bytes = (size_t)s.w * s.h * 4;
-			HIPCHK(c, hipMemcpyAsync(sl.srcSlab + off, s.gray, bytes, hipMemcpyDeviceToDevice, c->stream));
+			const size_t bytes = (size_t)s.w * s.h * sizeof(float4);
+			HIPCHK(c, hipMemcpyAsync(sl.srcSlab + off, s.quads, bytes, hipMemcpyDeviceToDevice, c->stream));
 			hv[v].byteOff = (uint32_t)off;
 			off += (bytes + 255) & ~(size_t)255;
 		}
@@ -516,7 +526,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 	int maxRows = 0, totalRows = 0;
 	for (int i = 0; i < n_items; ++i) {
 		if (items[i].n_src < 1 || items[i].n_src > kMaxViews || hcmvs::segments_for(items[i].n_src) != hcmvs::segments_for(items[0].n_src))
-			return fail(c, HCMVS_ERR_INVALID, "estimate: the items of a batch must use source-view counts of one class (1, 2, 3-4, 5-8 or 9-16)");
+			return fail(c, HCMVS_ERR_INVALID, "estimate: the items of a batch must use source-view counts of one class (1-8 or 9-16)");
 		int rc = build_item(c, i, items[i], p, c->hItems[i]);
 		if (rc) return rc;
 		const int rows = c->hItems[i].H - 2 * c->hItems[i].border;
@@ -548,19 +558,6 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 		for (int i = 0; i < n_items; ++i)
 			HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * c->hItems[i].border) * kProgressStride * sizeof(int32_t), s));
 		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : (n_items == 2 ? 2 : 3)); // measured: profiles/r02_knobs.txt
-		// the band worker serves the throughput case: 5..8 source views, patches up to 8 x 8 taps, at most 8 neighbour slots per
-		// pixel (4 at outer iteration 0; the cross pattern has 4 * ceil(halfwin / step), DepthMap.cpp:1071-1078), one wave per row
-		bool useBand = c->bandWorker && nw == 1 && hcmvs::segments_for(items[0].n_src) == 8 && items[0].n_src >= 5 && p->adapthalfwin <= kHalfWindow;
-		if (useBand && p->it_external >= 1) {
-			const int step = p->propagate_step > 0 ? p->propagate_step : 1;
-			const int hw = std::min(7, std::max(5, p->propagate_halfwin));
-			useBand = (hw - 1) / step + 1 <= 2;
-		}
-		if (useBand) {
-			int totalBands = 0;
-			for (int i = 0; i < n_items; ++i) totalBands += (c->hItems[i].H - 2 * c->hItems[i].border + 7) / 8;
-			launch_band_sweep(c->dItems, n_items, totalBands, sy, iter, c->xcdAffinity, s);
-		} else
 		{
 			// the launcher picks the kernel variant by view count: an item whose count leaves two or more view groups idle wants the
 			// pair-packing variant, which is correct for the other items of its layout class too
@@ -692,6 +689,46 @@ int hcmvs_triangulate_init(hcmvs_ctx* c, uint32_t id, const float* pts, int32_t 
 	const View& v = it->second;
 	if (hcmvs_triangulate_points(v.w, v.h, v.K, v.R, v.C, pts, n, avg_depth, add_corners, depth, normal, d_min, d_max) != HCMVS_OK)
 		return fail(c, HCMVS_ERR_INVALID, "triangulate_init: no sparse point in front of view %u", id);
+	return HCMVS_OK;
+}
+
+// cv::resize INTER_AREA, enlarging (OpenCV 4.2 imgproc/src/resize.cpp: the bilinear kernel driven by "area mode" tables):
+// per destination column / row the left / upper source index and the weight of its right / lower partner
+int hcmvs_resize_area_up(const float* src, int32_t sw, int32_t sh, int32_t ch, float* dst, int32_t dw, int32_t dh) {
+	if (!src || !dst || sw < 1 || sh < 1 || ch < 1 || dw < sw || dh < sh) return HCMVS_ERR_INVALID;
+	struct Tab { std::vector<int> ofs; std::vector<float> w; };
+	auto table = [](int ssize, int dsize, bool columns) {
+		Tab t; t.ofs.resize((size_t)dsize); t.w.resize((size_t)dsize);
+		const double scale = (double)ssize / dsize, inv = (double)dsize / ssize;
+		for (int d = 0; d < dsize; ++d) {
+			int s = (int)std::floor(d * scale);
+			float f = (float)((d + 1) - (s + 1) * inv);
+			f = f <= 0 ? 0.f : f - std::floor(f);
+			if (columns && s >= ssize - 1) { f = 0.f; s = ssize - 1; } // no right partner: the sample alone (HResizeLinear past xmax)
+			t.ofs[(size_t)d] = s; t.w[(size_t)d] = f;
+		}
+		return t;
+	};
+	const Tab tx = table(sw, dw, true), ty = table(sh, dh, false);
+	std::vector<float> row0((size_t)dw * ch), row1((size_t)dw * ch);
+	auto hresize = [&](int sy, std::vector<float>& out) {
+		const float* S = src + (size_t)sy * sw * ch;
+		for (int x = 0; x < dw; ++x) {
+			const int sx = tx.ofs[(size_t)x];
+			const float a1 = tx.w[(size_t)x], a0 = 1.f - a1;
+			for (int c = 0; c < ch; ++c)
+				out[(size_t)x * ch + c] = sx + 1 >= sw ? S[(size_t)sx * ch + c] : S[(size_t)sx * ch + c] * a0 + S[(size_t)(sx + 1) * ch + c] * a1;
+		}
+	};
+	int have0 = -1, have1 = -1;
+	for (int y = 0; y < dh; ++y) {
+		const int r0 = std::min(std::max(ty.ofs[(size_t)y], 0), sh - 1), r1 = std::min(std::max(ty.ofs[(size_t)y] + 1, 0), sh - 1);
+		if (have0 != r0) { if (have1 == r0) { row0.swap(row1); std::swap(have0, have1); } else { hresize(r0, row0); have0 = r0; } }
+		if (have1 != r1) { hresize(r1, row1); have1 = r1; }
+		const float b1 = ty.w[(size_t)y], b0 = 1.f - b1;
+		float* D = dst + (size_t)y * dw * ch;
+		for (size_t k = 0; k < (size_t)dw * ch; ++k) D[k] = row0[k] * b0 + row1[k] * b1;
+	}
 	return HCMVS_OK;
 }
 
@@ -1131,7 +1168,7 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 }
 
 int hcmvs_postfilter(hcmvs_ctx* c, uint32_t id, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
-                     float normal_diff_deg, float depthweight, float normalweight, int32_t gap_size, uint64_t* n_filled) {
+                     float normal_diff_deg, int32_t gap_size, uint64_t* n_filled) {
 	if (!c) return HCMVS_ERR_INVALID;
 	auto it = c->views.find(id);
 	if (it == c->views.end() || !it->second.mDepth || !it->second.mNormal) return fail(c, HCMVS_ERR_INVALID, "postfilter: view %u has no registered depth + normal maps", id);
@@ -1140,7 +1177,8 @@ int hcmvs_postfilter(hcmvs_ctx* c, uint32_t id, const uint32_t* order, int32_t n
 	// RemoveSmallSegments (fork version): the whole fusion, for its claim maps and invalidations only
 	hcmvs_cloud cl;
 	memset(&cl, 0, sizeof cl);
-	int rc = hcmvs_fuse_cloud(c, order, n_order, n_min_views_fuse, depth_diff_threshold, normal_diff_deg, depthweight, normalweight, &cl);
+	// (plain thresholds: COS(FD2R(fNormalDiffThreshold)) and IsDepthSimilar(.., fDepthDiffThreshold), SceneDensify.cpp:2083, 2177)
+	int rc = hcmvs_fuse_cloud(c, order, n_order, n_min_views_fuse, depth_diff_threshold, normal_diff_deg, 1.f, 1.f, &cl);
 	if (rc) return rc;
 	View& v = c->views.find(id)->second;
 	rc = ensure_gradient(c, v);

@@ -22,7 +22,7 @@ constexpr int kProgressStride = 16; // ints between the progress words of consec
 
 // per source view constants, one lane group reads its own view's entry (DepthMap.h:412-444 ViewData)
 struct DevView {
-	uint32_t byteOff; // image start relative to EstConst::imgBase
+	uint32_t byteOff; // start of the view's footprint image (launch_quads) relative to EstConst::imgBase
 	int32_t w, h;
 	float A[9];  // Hl * Hr = Kj Rj Ri^T Ki^-1 (computed in double on the host, held as float)
 	float Hm[3]; // Kj Rj (Ci - Cj)
@@ -36,7 +36,7 @@ struct EstConst {
 	const float* ref;
 	const uint8_t* gra;
 	const DevView* views;
-	const char* imgBase;    // lowest source-image address of this call (32-bit offsets from here)
+	const char* imgBase;    // lowest source footprint-image address of this call (32-bit offsets from here)
 	float Hr[9];            // Ki^-1 (double on the host, held as float)
 	double cx, cy, ifx, ify; // reference principal point and 1/focal (Camera.h:299-312)
 	float dMin, dMax, dMinSqr, dMaxSqr;
@@ -71,12 +71,11 @@ void launch_gray_to_u8(const float* gray, uint8_t* out, int n, hipStream_t s);
 void launch_bgr_to_u8(const uint8_t* bgr, uint8_t* out, int n, hipStream_t s);
 void launch_gradient_map(const uint8_t* g8, uint8_t* gra, int W, int H, hipStream_t s);
 void launch_median3(const float* in, float* out, int W, int H, hipStream_t s);
+void launch_quads(const float* gray, float4* out, int W, int H, hipStream_t s); // 2 x 2 footprint layout of a source view
 void launch_score_pass(const EstConst& c, const float* depthIn, const float* normalIn, unsigned long long* evals,
                        hipStream_t s);
 void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int lag,
                   int wavesPerRow, int affinity, hipStream_t s);
-// band worker (5..8 views, patches up to 8 x 8 taps, at most 8 neighbour slots): one wave per band of 8 rows
-void launch_band_sweep(const EstConst* dItems, int nItems, int totalBands, const SweepSync& sync, int iter, int affinity, hipStream_t s);
 void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s);
 
 } // namespace hcmvs

@@ -41,15 +41,32 @@ namespace hcmvs {
 
 // diagnostic build only (-DHCMVS_STAMPS): per-phase cycle accounting of wave 0 of every row worker
 #ifdef HCMVS_STAMPS
-__device__ unsigned long long g_stamps[16];
-#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__device__ unsigned long long g_stamps[32]; // [0, 14) cycles per phase, [16, 32) executions of the blocks of BLOCK()
+#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned st_cnt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; }
-#define STAMP_ARGS , unsigned long long& st_last, unsigned long long (&st_acc)[14]
-#define STAMP_PASS , st_last, st_acc
-#define STAMP_FLUSH if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) { for (int i_ = 0; i_ < 14; ++i_) atomicAdd(&g_stamps[i_], st_acc[i_]); }
+#define STAMP_ARGS , unsigned long long& st_last, unsigned long long (&st_acc)[14], unsigned (&st_cnt)[16]
+#define STAMP_PASS , st_last, st_acc, st_cnt
+#define STAMP_FLUSH if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) { for (int i_ = 0; i_ < 14; ++i_) atomicAdd(&g_stamps[i_], st_acc[i_]); for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_stamps[16 + i_], (unsigned long long)st_cnt[i_]); }
+#define SUBMARK(name)
+#define BLOCK(name, i) ++st_cnt[i];
+#define BLOCKN(name, i, n) st_cnt[i] += (unsigned)(n);
+#elif defined(HCMVS_MARK)
+// diagnostic ISA listing only (-DHCMVS_MARK -S, tools/isa_budget.py): the phase boundaries of the stamps build as comments in the
+// assembly, plus sub-phases of the scorer, so that the static instruction mix can be attributed to the source phases
+#define STAMP_DECL
+#define STAMP(i) asm volatile("; HCMARK " #i);
+#define SUBMARK(name) asm volatile("; HCMARK " #name);
+#define BLOCK(name, i) asm volatile("; HCMARK " #name);
+#define BLOCKN(name, i, n) asm volatile("; HCMARK " #name);
+#define STAMP_ARGS
+#define STAMP_PASS
+#define STAMP_FLUSH
 #else
 #define STAMP_DECL
 #define STAMP(i)
+#define SUBMARK(name)
+#define BLOCK(name, i)
+#define BLOCKN(name, i, n)
 #define STAMP_ARGS
 #define STAMP_PASS
 #define STAMP_FLUSH
@@ -96,6 +113,7 @@ __device__ __forceinline__ uint8_t uniform_byte(const uint8_t* base, int idx) {
 	return (uint8_t)(w >> (8u * (unsigned)(a & 3u)));
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // agent-scope (sc1) accesses for everything another row's wave may have written in this launch
 __device__ __forceinline__ float4 load_dn(const float4* p) {
@@ -180,7 +198,7 @@ struct LaneCtx {
 	int lane, view, seg;
 	int vloc;         // view group of the lane inside the wave (= view, except in the second view set of a 9..16-view estimate)
 	bool vact;        // lane's view group exists
-	unsigned imgOff;  // byte offset of my source view from EstConst::imgBase (all views of a call lie within 4 GiB)
+	unsigned imgOff;  // byte offset of my source view's footprint image from EstConst::imgBase (all views of a call lie within 4 GiB)
 	int iw, ixmax, iymax; // row pitch in pixels; largest top-left texel column / row of a bilinear footprint
 	float wmax, hmax; // inside-with-border-1 limits of my view
 	unsigned long long groupMask;
@@ -257,7 +275,7 @@ struct WavePark { // LDS of one wave of a row worker
 	float ps[3][8][8];        // py | w | tw as [column][row], read by every view group
 	float cl[9][kMaxSlots];   // smoothness neighbours, slot k at [.][k]: X0 X1 X2 | n0 n1 n2 | k0 k1 k2 (see Close)
 	float4 hl[8][64 / S][3];  // homographies of the (hypothesis, view) pairs of the current chunk of eight hypotheses
-	float4 acc[8][64 / S];    // their ZNCC sums: sum, sumSq, num, 1 if a tap left the image
+	float part[3][8][64 / S][S]; // their ZNCC sums (sum | sumSq | num) as the S lanes of the view group left them: added up per chunk, not per evaluation
 };
 template <int S>
 struct LdsStore {
@@ -454,10 +472,13 @@ __device__ __forceinline__ void make_homography(const EstConst& c, const float (
 // is done once on the min/max of the warped coordinates; a lane with a tap outside skips (2) and (3) altogether.
 // NR: as in fill_patch_n -- steps >= NR are zero-weight repeats of step NR - 1 in every lane and are skipped; the grouped
 // reciprocal still multiplies the repeated denominators, so every remaining tap gets the same bits as with all steps.
-template <int S, int NR, class ST>
+// REDUCE = false: the lane's own partial sums are returned (the sweep parks them in LDS and adds them up once per chunk of
+// hypotheses, in the butterfly's association: see score_chunk)
+template <int S, int NR, class ST, bool REDUCE = true>
 __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& L, const Patch<S>& P, const ST& st, const float (&H)[9],
                                            float& sum, float& sumSq, float& num, bool& viewBad) {
 	constexpr int MAXM = NR;
+	SUBMARK(tap_warp)
 	float Ppy[64 / S];
 	st.get_py(Ppy);
 	float qx[MAXM], qy[MAXM];
@@ -499,26 +520,26 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 	// Only lanes whose taps all lie inside the image (Types.h:1633-1635) sample it: their texel addresses need no clamping, and
 	// a lane with a tap outside contributes nothing but the NaN that turns its view's score into thRobust below.
 	float a = 0.f, b2 = 0.f, cnum = 0.f;
+	SUBMARK(tap_sample)
 	if (!bad) {
 		float2 top[MAXM], bot[MAXM];
 		float fx[MAXM], fy[MAXM];
 		const HC_GLOBAL char* imgBase = as_global(c.imgBase);
-		const unsigned pitch = (unsigned)L.iw << 2;
 #pragma unroll
 		for (int m = 0; m < MAXM; ++m) {
 			const int lx = (int)qx[m], ly = (int)qy[m];
 			fx[m] = __builtin_amdgcn_fractf(qx[m]);
 			fy[m] = __builtin_amdgcn_fractf(qy[m]);
-			const unsigned off = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 2);
+			// the source views are held as 2 x 2 footprints (quad_kernel): ONE 16-byte gather per bilinear sample
+			const unsigned off = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 4);
 #if defined(HCMVS_ABL) && HCMVS_ABL == 1 /* diagnostic ablation: no gather loads (results are wrong) */
 			const float fake = (float)(off & 255u) * (1.f / 255.f);
 			top[m] = make_float2(fake, fake * 0.9f);
 			bot[m] = make_float2(fake * 0.8f, fake * 0.7f);
 #else
-			const f32x2 tv = *(const HC_GLOBAL f32x2*)(imgBase + off);
-			const f32x2 bv = *(const HC_GLOBAL f32x2*)(imgBase + (off + pitch));
-			top[m] = make_float2(tv.x, tv.y);
-			bot[m] = make_float2(bv.x, bv.y);
+			const f32x4 fp = *(const HC_GLOBAL f32x4*)(imgBase + off);
+			top[m] = make_float2(fp.x, fp.y);
+			bot[m] = make_float2(fp.z, fp.w);
 #endif
 		}
 		float Pw[64 / S], Ptw[64 / S];
@@ -538,18 +559,20 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 	// a tap outside the image (or a degenerate warp) must turn the view's score into thRobust: the lane poisons its
 	// partial sum, the NaN survives the butterfly and fails the `nrmSq > 0` test of view_score
 	viewBad = false;
-	sum = group_sum<S>(bad ? __builtin_nanf("") : a); sumSq = group_sum<S>(b2); num = group_sum<S>(cnum);
+	SUBMARK(tap_reduce)
+	if constexpr (REDUCE) { sum = group_sum<S>(bad ? __builtin_nanf("") : a); sumSq = group_sum<S>(b2); num = group_sum<S>(cnum); }
+	else { sum = bad ? __builtin_nanf("") : a; sumSq = b2; num = cnum; }
+	SUBMARK(tap_end)
 }
 
 // score_taps for the patches of fill_patch_big: tap k = m * S + seg from the LDS tables, one IEEE reciprocal per tap, four
 // taps in flight at a time; same poisoning of the partial sum when a tap leaves the image
-template <int S, class ST>
+template <int S, class ST, bool REDUCE = true>
 __device__ __forceinline__ void score_taps_big(const EstConst& c, const LaneCtx<S>& L, const ST& st, const float (&H)[9], float& sum, float& sumSq,
                                                float& num, bool& viewBad) {
 	constexpr int MB = (kBigTaps + S - 1) / S, CH = 4;
 	const float (*bw)[kBigSlots] = st.bw;
 	const HC_GLOBAL char* imgBase = as_global(c.imgBase);
-	const unsigned pitch = (unsigned)L.iw << 2;
 	float a = 0.f, b2 = 0.f, cnum = 0.f;
 	bool bad = false;
 	for (int m0 = 0; m0 < MB; m0 += CH) {
@@ -569,13 +592,13 @@ __device__ __forceinline__ void score_taps_big(const EstConst& c, const LaneCtx<
 			const int lx = (int)__builtin_amdgcn_fmed3f(qx, 0.f, L.wmax), ly = (int)__builtin_amdgcn_fmed3f(qy, 0.f, L.hmax);
 			fx[u] = __builtin_amdgcn_fractf(qx);
 			fy[u] = __builtin_amdgcn_fractf(qy);
-			off[u] = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 2);
+			off[u] = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 4);
 		}
 		f32x2 tv[CH], bv[CH];
 #pragma unroll
 		for (int u = 0; u < CH; ++u) {
-			tv[u] = *(const HC_GLOBAL f32x2*)(imgBase + off[u]);
-			bv[u] = *(const HC_GLOBAL f32x2*)(imgBase + (off[u] + pitch));
+			const f32x4 fp = *(const HC_GLOBAL f32x4*)(imgBase + off[u]);
+			tv[u].x = fp.x; tv[u].y = fp.y; bv[u].x = fp.z; bv[u].y = fp.w;
 		}
 #pragma unroll
 		for (int u = 0; u < CH; ++u) {
@@ -591,7 +614,8 @@ __device__ __forceinline__ void score_taps_big(const EstConst& c, const LaneCtx<
 		}
 	}
 	viewBad = false;
-	sum = group_sum<S>(bad ? __builtin_nanf("") : a); sumSq = group_sum<S>(b2); num = group_sum<S>(cnum);
+	if constexpr (REDUCE) { sum = group_sum<S>(bad ? __builtin_nanf("") : a); sumSq = group_sum<S>(b2); num = group_sum<S>(cnum); }
+	else { sum = bad ? __builtin_nanf("") : a; sumSq = b2; num = cnum; }
 }
 
 // DepthMap.cpp:597-615, 890-893: score of one view from its ZNCC sums, times the smoothness factor of the hypothesis
@@ -660,6 +684,7 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 	constexpr int NV = 64 / S;               // views (lane groups) of a wave
 	constexpr int HP = 8;                    // hypotheses per pair-pass (lane = g * NV + v)
 	WavePark<S>* pk = st.pk;
+	SUBMARK(sc_hom)
 	const int lane = L.lane, pv = lane % NV, pg = lane / NV;
 	const int vbase = __builtin_amdgcn_readfirstlane(L.view - L.vloc); // first view of the set
 	float vA[9], vHm[3];
@@ -686,6 +711,7 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 	// pair p = 8 * pass + group -> hypothesis p / nAct, view p % nAct -- so a chunk costs ceil(n * nAct / 8) tap passes instead
 	// of n.  Every pair is evaluated exactly as in the plain loop (same lanes-per-view layout), only by another group.
 	const int nAct = __builtin_amdgcn_readfirstlane(c.V - vbase < NV ? c.V - vbase : NV);
+	SUBMARK(sc_taps)
 	auto taps_of = [&](auto nr) {
 		constexpr int NR = decltype(nr)::value;
 		if constexpr (PACK) { // instantiated for view counts that leave groups idle (not 7, 8, 15 or 16 views)
@@ -711,9 +737,9 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 					}
 					float sum, sumSq, num;
 					bool viewBad;
-					if constexpr (NR == 0) score_taps_big<S>(c, Lp, st, H, sum, sumSq, num, viewBad);
-					else score_taps<S, NR>(c, Lp, P, st, H, sum, sumSq, num, viewBad);
-					if (L.seg == 0 && valid) pk->acc[g][v] = make_float4(sum, sumSq, num, viewBad ? 1.f : 0.f);
+					if constexpr (NR == 0) score_taps_big<S, LdsStore<S>, false>(c, Lp, st, H, sum, sumSq, num, viewBad);
+					else score_taps<S, NR, LdsStore<S>, false>(c, Lp, P, st, H, sum, sumSq, num, viewBad);
+					if (valid) { pk->part[0][g][v][L.seg] = sum; pk->part[1][g][v][L.seg] = sumSq; pk->part[2][g][v][L.seg] = num; }
 				}
 				issued += (unsigned)n;
 				return;
@@ -728,10 +754,10 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 			}
 			float sum, sumSq, num;
 			bool viewBad;
-			if constexpr (NR == 0) score_taps_big<S>(c, L, st, H, sum, sumSq, num, viewBad);
-			else score_taps<S, NR>(c, L, P, st, H, sum, sumSq, num, viewBad);
+			if constexpr (NR == 0) score_taps_big<S, LdsStore<S>, false>(c, L, st, H, sum, sumSq, num, viewBad);
+			else score_taps<S, NR, LdsStore<S>, false>(c, L, P, st, H, sum, sumSq, num, viewBad);
 			++issued;
-			if (L.seg == 0) pk->acc[g][L.vloc] = make_float4(sum, sumSq, num, viewBad ? 1.f : 0.f);
+			pk->part[0][g][L.vloc][L.seg] = sum; pk->part[1][g][L.vloc][L.seg] = sumSq; pk->part[2][g][L.vloc][L.seg] = num;
 		}
 	};
 	if (BIG && P.a > kHalfWindow) {
@@ -741,13 +767,23 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 		else if (P.a == 5) taps_of(std::integral_constant<int, 6>());
 		else taps_of(std::integral_constant<int, 8>());
 	}
+	SUBMARK(sc_epi)
 #pragma unroll
 	for (int p0 = 0; p0 < 8; p0 += HP) {
 		if ((todo >> (base + p0)) == 0ull) break;
 		const int g = p0 + (pg < HP ? pg : 0);
-		const float4 r = pk->acc[g][pv];
+		// the sums over the S lanes of the pair's view group, in the association of the xor butterfly (group_sum):
+		// ((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7)) -- the same bits, one instruction stream per chunk instead of per evaluation
+		float rs[3];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+			static_assert(S == 8, "tree below is written for 8 lanes per view group");
+			const float4* q = (const float4*)&pk->part[k][g][pv][0];
+			const float4 a = q[0], b = q[1];
+			rs[k] = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+		}
 		const float Fg = __shfl(F, g * 8, 64);
-		const float s = view_score(c, r.x, r.y, r.z, r.w != 0.f, P.invSumW, P.normSq0, Fg);
+		const float s = view_score(c, rs[0], rs[1], rs[2], false, P.invSumW, P.normSq0, Fg);
 		float m1 = vbase + pv < c.V ? s : __builtin_huge_valf(), m2 = __builtin_huge_valf();
 		min2_group<NV>(m1, m2);
 		// hypothesis base + p0 + k sits in lanes k * NV ... of (m1, m2)
@@ -756,6 +792,7 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 		const float g1 = __shfl(m1, from, 64), g2 = __shfl(m2, from, 64);
 		if (k >= 0 && k < HP && ((todo >> lane) & 1ull)) min2_merge(r1, r2, g1, g2);
 	}
+	SUBMARK(sc_end)
 }
 
 // Util.inl:614-626
@@ -840,6 +877,7 @@ __device__ __forceinline__ float smooth_pass(const EstConst& c, const float (*cl
 	const int nChunks = (64 - __builtin_clzll(closeMask) + 7) >> 3;
 	const int j = lane & 7;
 	for (int ch = 0; ch < nChunks; ++ch) {
+		SUBMARK(blk_smooth_chunk)
 		const int slot = ch * 8 + j;
 		const float X0 = cl[0][slot], X1 = cl[1][slot], X2 = cl[2][slot];
 		const float o0 = cl[3][slot], o1 = cl[4][slot], o2 = cl[5][slot];
@@ -860,6 +898,7 @@ __device__ __forceinline__ float smooth_pass(const EstConst& c, const float (*cl
 		f = f * lane_xor<4>(f);
 		F = ch == 0 ? f : F * f;
 	}
+	SUBMARK(blk_smooth_end)
 	return F;
 }
 
@@ -1072,6 +1111,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 	bool hooked = false;
 	for (;;) {
 		if (phase == PH_PICK) { // the RefineIters label, DepthMap.cpp:1443-1448
+			BLOCK(blk_pick, 0)
 			if (!hooked) {
 				// pipeline hook: publish the previous column (its stores were issued a whole scoring round ago, so this
 				// wait is free) and refresh the progress of the row above with an asynchronous poll
@@ -1102,10 +1142,12 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		int hlimit = 63, r0, r1;
 		bool hv = false, planeOwn = true;
 		if (phase == PH_PROP) {
+			BLOCK(blk_gen_prop, 1)
 			r0 = cb; r1 = cb + 8 * NW < nc ? cb + 8 * NW : nc;
 			hd = qd; h0 = q0; h1 = q1; h2 = q2; hlimit = candSlot;
 			hv = lane >= r0 && lane < r1;
 		} else if (phase == PH_RAND) {
+			BLOCK(blk_gen_rand, 2)
 			r0 = 0; r1 = nR; planeOwn = false; // the smoothness plane is whatever the propagation left (DepthMap.cpp:1450-1463)
 			if (lane < nR) {
 				// few pixels ever get here; the laundered key keeps this (loop-invariant, speculatable) arithmetic from being
@@ -1117,6 +1159,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 				hv = true;
 			}
 		} else {
+			BLOCK(blk_gen_refine, 3)
 			r0 = t0; r1 = nR;
 			if (lane >= t0 && lane < nR) {
 				const uint32_t cbase = 64u + 3u * lane;
@@ -1135,6 +1178,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		const int cnt = r1 - r0, per = (cnt + NW - 1) / NW, lo = r0 + wv * per, hi = (lo + per < r1 ? lo + per : r1);
 		float best1 = __builtin_huge_valf(), best2 = __builtin_huge_valf(); // lane t: the two best view scores of hypothesis t
 		for (int base = lo; base < hi; base += 8) {
+			BLOCK(blk_chunk, 4)
 			const int g = base + (lane >> 3);
 			const int src = g < r1 ? g : r0;
 			const float gd = __shfl(hd, src, 64), g0 = __shfl(h0, src, 64), g1 = __shfl(h1, src, 64), g2 = __shfl(h2, src, 64);
@@ -1144,12 +1188,14 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 #if defined(HCMVS_ABL) && HCMVS_ABL == 2 /* diagnostic ablation: no smoothness pass */
 			const float F = 1.f + 0.f * (gd + g0 + g1 + g2 + gp0 + gp1 + gp2 + gpd + (float)glimit);
 #else
+			BLOCKN(blk_smooth_chunks, 10, closeMask ? (64 - __builtin_clzll(closeMask) + 7) >> 3 : 0)
 			const float F = smooth_pass(c, st.pk->cl, closeMask, eligMask, lane, gd, g0, g1, g2, gp0, gp1, gp2, gpd, glimit);
 #endif
 			const int top = base + 8 < hi ? base + 8 : hi;
 			const unsigned long long todo = vmask & ((1ull << top) - 1ull) & ~((1ull << base) - 1ull); // top <= 32
 			STAMP(4)
 			if (todo) {
+				BLOCK(blk_score_chunk, 5)
 				score_chunk<S, BIG, PACK>(c, L, P, st, G.v0, G.v1, F, hd, h0, h1, h2, todo, base, __builtin_ctzll(todo), best1, best2, issued);
 				if constexpr (TWO) {
 					unsigned again = 0;
@@ -1163,7 +1209,9 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		STAMP(8)
 		// ---- every wave replays the sequential accept logic ----
 		if (phase == PH_PROP) {
+			BLOCK(blk_acc_prop, 6)
 			for (int i = r0; i < r1; ++i) {
+				BLOCK(blk_acc_prop_cand, 7)
 				const float nconf = rlf(all, i);
 				++evals;
 				if (conf > nconf) { conf = nconf; depth = rlf(hd, i); n0 = rlf(h0, i); n1 = rlf(h1, i); n2 = rlf(h2, i); }
@@ -1172,6 +1220,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			cb = r1;
 			if (cb >= nc) phase = PH_PICK;
 		} else if (phase == PH_RAND) {
+			BLOCK(blk_acc_rand, 8)
 			bool again = false;
 			for (int t = 0; t < nR && !again; ++t) {
 				const float nconf = rlf(all, t);
@@ -1185,6 +1234,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		} else {
 			// the sequential scan stops at the first valid trial that beats the estimate (DepthMap.cpp:1484): found with
 			// one ballot; the trials before it were scored and rejected, the ones behind it are regenerated
+			BLOCK(blk_acc_refine, 9)
 			int tnext = nR;
 			const unsigned long long range = ((1ull << nR) - 1ull) & ~((1ull << t0) - 1ull);
 			const unsigned long long live = vmask & range;
@@ -1206,6 +1256,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		STAMP(11)
 		if (phase == PH_DONE) break;
 	}
+	SUBMARK(blk_pixel_tail)
 	if (c.hintDepth && iter == c.hintIter) {
 		// restore variant, last sweep of the last outer iteration (restore/libs/MVS/DepthMap.cpp:1527-1549): the estimate of the
 		// up-sampled coarser level is one more hypothesis; it wins even when up to 0.1 worse.  Every wave evaluates it itself.
@@ -1382,495 +1433,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// BAND WORKER (5..8 source views, patches up to 8 x 8 taps, at most 8 neighbour slots per pixel)
-//
-// One wave owns a band of 8 consecutive logical rows and advances them together, row j one column behind row j-1: at step t
-// it processes the eight pixels (column t - j of row j).  That stagger satisfies the same dependence as between the rows of
-// the row worker (left / up already updated, right / down not yet), so the maps are the same bits.  What changes is the cost
-// of everything that is not a tap loop: slots, interpolation, normal correction, hypothesis generation, the accept logic and
-// the per-step memory round trips (own state, neighbours, the hand-off from the band above) are done for eight pixels by one
-// instruction stream, lane = 8 * pixel + k, where the row worker spent a whole wave-instruction on 4-8 useful lanes per pixel.
-// The tap loops (score_taps) and the patch weights are unchanged: 64 lanes = 8 views x 8 columns for one (pixel, hypothesis).
-// Only the band's row 0 waits on another wave (the band above, one progress word per band); rows 1..7 take their upper
-// neighbours from the band's own ring in LDS.
-
-constexpr int kBandRows = 8;
-struct BandPark { // LDS of one band worker (one wave)
-	float4 vh[8][3];                  // per view: A[0..8], Hm[0..2]
-	float ps[kBandRows][2][8][8];     // per pixel: w | tw as [column][row] (the layout score_taps reads; py is recomputed)
-	float cl[kBandRows][9][8];        // per pixel: smoothness neighbours, slot k at [.][k]: X0 X1 X2 | n0 n1 n2 | k0 k1 k2
-	float4 hl[8][8][3];               // homographies of the (pair, view) of the current chunk of eight (pixel, hypothesis) pairs
-	float4 acc[8][8];                 // their ZNCC sums
-	float hist[kBandRows][kHist][5];  // per row: ring of its latest results (depth, normal, score)
-};
-struct BandStore { // what score_taps / fill_patch_64 need, pointed at one pixel of the band
-	BandPark* pk;
-	int pix, y, a;   // the pixel's image row and half window: the taps' image rows are y - a + 2 * min(row, a)
-	__device__ __forceinline__ int opaque(int v) const { asm volatile("" : "+v"(v)); return v; }
-	__device__ __forceinline__ void put_patch64(int row, int col, float, float w_, float tw_) {
-		pk->ps[pix][0][col][row] = w_; pk->ps[pix][1][col][row] = tw_;
-	}
-	__device__ __forceinline__ void get_col(int k, int os, float (&v)[8]) const {
-		const float4* q = (const float4*)&pk->ps[pix][k][os][0];
-		const float4 a = q[0], b = q[1];
-		v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-	}
-	__device__ __forceinline__ void get_py(float (&o)[8]) const {
-#pragma unroll
-		for (int m = 0; m < 8; ++m) o[m] = (float)(y - a + 2 * (m < a ? m : a)); // as fill_patch_64 stores it
-	}
-	__device__ __forceinline__ void get_w(float (&w_)[8], float (&tw_)[8]) const {
-		const int os = opaque((int)(threadIdx.x & 7));
-		get_col(0, os, w_); get_col(1, os, tw_);
-	}
-};
-
-// smooth_pass for one pixel of a band: lane = 8 * g + j handles hypothesis g and neighbour slot j (at most 8 slots); the same
-// arithmetic as smooth_pass with a single chunk of slots
-__device__ __forceinline__ float band_smooth(const EstConst& c, const float (*cl)[8], unsigned closeByte, unsigned eligByte, int lane, float hd, float h0,
-                                             float h1, float h2, float hp0, float hp1, float hp2, float hpd, int limit) {
-	if (closeByte == 0u) return 1.f;
-	const int j = lane & 7;
-	const float X0 = cl[0][j], X1 = cl[1][j], X2 = cl[2][j];
-	const float o0 = cl[3][j], o1 = cl[4][j], o2 = cl[5][j];
-	const float k0 = cl[6][j], k1 = cl[7][j], k2 = cl[8][j];
-	const bool valid = (closeByte >> j) & 1u;
-	const bool corr = ((eligByte >> j) & 1u) && j <= limit;
-	const float c0 = corr ? k0 : o0, c1 = corr ? k1 : o1, c2 = corr ? k2 : o2;
-	const float dist = dot3(hp0, hp1, hp2, X0, X1, X2) + hpd;
-	const float fd = pm_expf(HC_SQ(dist / hd) * c.smoothSigmaDepth);
-	float ca = dot3(h0, h1, h2, c0, c1, c2);
-	ca = ca < -1.f ? -1.f : (ca > 1.f ? 1.f : ca);
-	const float ang = pm_acosf(ca);
-	const float fn = pm_expf(HC_SQ(ang) * c.smoothSigmaNormal);
-	float f = (1.f - c.smoothBonusDepth * fd) * (1.f - c.smoothBonusNormal * fn);
-	f = valid ? f : 1.f;
-	f = f * lane_xor<1>(f);
-	f = f * lane_xor<2>(f);
-	f = f * lane_xor<4>(f);
-	return f;
-}
-
-// smallest (value, index) of the 8 lanes of a group, ties to the smaller index: what a sequential `if (best > v)` scan keeps
-__device__ __forceinline__ void group_argmin(float& v, int& i) {
-#define HC_AM(STEP) { const float ov = lane_xor<STEP>(v); const int oi = __float_as_int(lane_xor<STEP>(__int_as_float(i))); \
-	const bool take = ov < v || (ov == v && oi < i); v = take ? ov : v; i = take ? oi : i; }
-	// lane_xor<4> is a mirror that equals the xor partner's value only once 4-lane blocks are uniform, which the steps 1, 2 ensure
-	HC_AM(1) HC_AM(2) HC_AM(4)
-#undef HC_AM
-}
-
-#ifndef HCMVS_BAND_OCC
-#define HCMVS_BAND_OCC 3
-#endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HCMVS_BAND_OCC, HCMVS_BAND_OCC))) void band_kernel(const EstConst* __restrict__ items, int nItems, SweepSync sy,
-                                                                                              int iter, int affinity) {
-	__shared__ BandPark park;
-	__shared__ int shRow, shItem;
-	const bool rev = (iter & 1) != 0;
-	const int lane = threadIdx.x & 63, pix = lane >> 3, sub = lane & 7;
-	unsigned myEvals = 0, issued = 0;
-	unsigned long long myTaps = 0;
-	int rot = (int)blockIdx.x;
-	HC_GLOBAL int32_t* err = as_global(sy.error);
-	for (;;) {
-		if (threadIdx.x == 0) { // the next band of some image, bands of one image in dependence order (as sweep_kernel hands out rows)
-			int item = -1, row = 0;
-			const int G = nItems < 8 ? nItems : 8;
-			const int home = affinity ? (int)(__builtin_amdgcn_s_getreg(6164) & 7u) % G : 0;
-			const int nHome = affinity ? (nItems - home + G - 1) / G : nItems;
-			for (int k = 0; k < nItems && item < 0; ++k) {
-				int cand;
-				if (!affinity) cand = (rot + k) % nItems;
-				else if (k < nHome) cand = home + ((rot + k) % nHome) * G;
-				else { cand = k - nHome; cand += cand / (G - 1) + (cand % (G - 1) >= home ? 1 : 0); }
-				const int nb_ = (items[cand].H - 2 * items[cand].border + kBandRows - 1) / kBandRows;
-				HC_GLOBAL int32_t* tk = as_global(sy.ticket) + cand;
-				if (__hip_atomic_load(tk, __ATOMIC_RELAXED, HC_SCOPE) >= nb_) continue;
-				const int r_ = atomicAdd(sy.ticket + cand, 1);
-				if (r_ < nb_) { item = cand; row = r_; }
-			}
-			++rot;
-			shRow = row; shItem = item;
-		}
-		__syncthreads();
-		const int itemIdx = __builtin_amdgcn_readfirstlane(shItem);
-		if (itemIdx < 0) break;
-		const int band = __builtin_amdgcn_readfirstlane(shRow);
-		__syncthreads();
-		const EstConst& c = items[itemIdx];
-		const int bd = c.border, W = c.W;
-		const int nrows = c.H - 2 * bd, ncols = c.W - 2 * bd;
-		LaneCtx<8> L;
-		lane_init<8>(c, L);
-		if (L.seg == 0) {
-			const HC_GLOBAL DevView* dv = as_global(c.views) + (L.vact ? L.view : 0);
-			park.vh[L.view][0] = make_float4(dv->A[0], dv->A[1], dv->A[2], dv->A[3]);
-			park.vh[L.view][1] = make_float4(dv->A[4], dv->A[5], dv->A[6], dv->A[7]);
-			park.vh[L.view][2] = make_float4(dv->A[8], dv->Hm[0], dv->Hm[1], dv->Hm[2]);
-		}
-		HC_GLOBAL int32_t* upWord = as_global(c.progress) + (size_t)(band > 0 ? band - 1 : 0) * kProgressStride;
-		HC_GLOBAL int32_t* myWord = as_global(c.progress) + (size_t)band * kProgressStride;
-		int known = band > 0 ? 0 : 0x7fffffff, polled = 0;
-		bool fail = false;
-		const int r = band * kBandRows + pix;             // my logical row
-		const bool rowOk = r < nrows;
-		const int y = rev ? c.H - 1 - bd - r : bd + r;
-		const int nSteps = ncols + kBandRows - 1;
-		for (int t = 0; t < nSteps && !fail; ++t) {
-			const int q = t - pix;                           // my logical column
-			const bool act = rowOk && q >= 0 && q < ncols;
-			const int x = rev ? c.W - 1 - bd - q : bd + q;
-			const int idx = act ? y * W + x : 0;
-			// ---- the hand-off from the band above: its last row must have finished column t ----
-			if (polled > known) known = polled; // the poll issued during the previous step
-			if (band > 0 && t < ncols && known < t + 1) {
-				known = wait_progress(upWord, t + 1, err);
-				if (known < 0) { fail = true; break; }
-			}
-			// ---- loads of the step: own state, gradient byte, centre texel, neighbour slot k of pixel p in lane (p, k) ----
-			float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
-			float curConf = 2.f, tx = 0.f, center = 0.f;
-			if (act) {
-				cur = load_dn(&c.dn[idx]);
-				curConf = load_f(&c.conf[idx]);
-				tx = (float)as_global(c.gra)[idx];
-				center = ((gcfptr)c.ref)[idx];
-			}
-			int nx = x, ny = y;
-			bool slot = false, sprop = false;
-			if (act) { // DepthMap.cpp:1064-1391, as slot_setup
-				if (c.itExternal >= 1) {
-					int phw = tx > 150.f ? 5 : c.propHalfwin;
-					if (phw > 7) phw = 7;
-					const int step = c.propStep > 0 ? c.propStep : 1;
-					int i = 0;
-					if (x > phw && y > phw && x < W - phw && y < c.H - phw) {
-						const int ni = phw >= 1 ? (phw - 1) / step + 1 : 0;
-						if (sub < 4 * ni) { i = 1 + (sub >> 2) * step; slot = true; }
-					} else if (x > c.border && y > c.border && x < W - c.border && y < c.H - c.border) {
-						if (sub < 4) { i = 1; slot = true; }
-					}
-					const int tt = sub & 3;
-					nx = x + (tt == 2 ? -i : (tt == 3 ? i : 0));
-					ny = y + (tt == 0 ? -i : (tt == 1 ? i : 0));
-					sprop = slot;
-				} else if (sub < 4) {
-					const int d = rev ? ((sub + 2) & 3) : sub; // 0 left, 1 up, 2 right, 3 down
-					nx = x + (d == 0 ? -1 : (d == 2 ? 1 : 0));
-					ny = y + (d == 1 ? -1 : (d == 3 ? 1 : 0));
-					slot = d == 0 ? x > c.border : (d == 1 ? y > c.border : (d == 2 ? x < W - c.border : y < c.H - c.border));
-					sprop = sub < 2;
-				}
-			}
-			// where the slot's estimate comes from: sweep-relative offsets (dq, dr); already updated this sweep iff dq + dr < 0
-			const int dq = rev ? x - nx : nx - x, dr = rev ? y - ny : ny - y;
-			const int qn = q + dq, jn = pix + dr;
-			const bool doneNb = slot && (dq + dr) < 0 && qn >= 0;
-			const bool fromRing = doneNb && jn >= 0;                   // a row of this band: its ring holds it
-			float4 ndn = make_float4(0.f, 0.f, 0.f, 0.f);
-			float nconf = 0.f;
-			if (slot && !fromRing) { // the band above (finished, see the wait), a later row / column (last sweep's value) or the border
-				ndn = load_dn(&c.dn[ny * W + nx]);
-				nconf = load_f(&c.conf[ny * W + nx]);
-			}
-			if (fromRing) {
-				const float* hrec = park.hist[jn][qn & (kHist - 1)];
-				ndn = make_float4(hrec[0], hrec[1], hrec[2], hrec[3]); nconf = hrec[4];
-			}
-			if (band > 0 && t + 1 < ncols) polled = __hip_atomic_load(upWord, __ATOMIC_RELAXED, HC_SCOPE); // consumed at the next step
-			// ---- patch weights of the eight pixels (fill_patch_64 per pixel, all 64 lanes) ----
-			const int a = tx > 100.f ? 5 : c.adapthalfwin;
-			float invSumW = 1.f, normSq0 = 0.f;
-			const unsigned long long actMask = __ballot(act);
-#pragma unroll
-			for (int p4 = 0; p4 < kBandRows; p4 += 4) { // four pixels at a time: their tap loads first, then the weights
-				float Itap[4];
-#pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const int p = p4 + u;
-					Itap[u] = 0.f;
-					if ((actMask >> (8 * p)) & 1ull) {
-						const int xp = rli(x, 8 * p), yp = rli(y, 8 * p), ap = rli(a, 8 * p);
-						const int row = lane >> 3, col = lane & 7;
-						const int i = -ap + 2 * (row < ap ? row : ap), j = -ap + 2 * (col < ap ? col : ap);
-						Itap[u] = ((gcfptr)c.ref)[__mul24(yp + i, W) + (xp + j)];
-					}
-				}
-#pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const int p = p4 + u;
-					if (!((actMask >> (8 * p)) & 1ull)) continue;
-					const int xp = rli(x, 8 * p), yp = rli(y, 8 * p), ap = rli(a, 8 * p);
-					PixIn<8> in;
-					in.I[0] = Itap[u]; in.center = rlf(center, 8 * p);
-					Patch<8> Pp;
-					BandStore bs; bs.pk = &park; bs.pix = p; bs.y = yp; bs.a = ap;
-					fill_patch_64(c, L, xp, yp, ap, in, Pp, bs);
-					if (pix == p) { invSumW = Pp.invSumW; normSq0 = Pp.normSq0; }
-				}
-			}
-			// ---- slots -> Close (lane (p, k) = slot k of pixel p) ----
-			PixelGeom G;
-			pixel_geom(c, x, y, G);
-			const bool closeV = slot && ndn.x > 0.f;
-			const unsigned long long closeAll = __ballot(closeV);
-			float cX0, cX1, cX2;
-			{
-				const double z = ndn.x;
-				cX0 = (float)(((double)nx - c.cx) * z * c.ifx);
-				cX1 = (float)(((double)ny - c.cy) * z * c.ify);
-				cX2 = (float)z;
-			}
-			const bool elig = closeV && sprop && !(nconf >= c.thKeep);
-			const unsigned long long eligAll = __ballot(elig);
-			float kd = ndn.x, k0 = ndn.y, k1 = ndn.z, k2 = ndn.w;
-			if (elig) {
-				kd = interpolate_pixel(c, G, nx, ny, ndn.x, ndn.y, ndn.z, ndn.w);
-				correct_normal(G, k0, k1, k2);
-			}
-			{
-				float (*cl)[8] = park.cl[pix];
-				cl[0][sub] = cX0; cl[1][sub] = cX1; cl[2][sub] = cX2;
-				cl[3][sub] = ndn.y; cl[4][sub] = ndn.z; cl[5][sub] = ndn.w;
-				cl[6][sub] = k0; cl[7][sub] = k1; cl[8][sub] = k2;
-			}
-			const unsigned eligByte = (unsigned)(eligAll >> (8 * pix)) & 0xffu;
-			// ---- per-pixel state (uniform inside a lane group) ----
-			float conf = curConf, depth = cur.x, n0 = cur.y, n1 = cur.z, n2 = cur.w;
-			init_plane(G, depth, n0, n1, n2);
-			const int nc = __builtin_popcount(eligByte);
-			int candSlot = 0; // lane (p, i) <- slot of the i-th candidate of pixel p
-			{
-				unsigned mk = eligByte;
-				for (int i = 0; i < 8; ++i) {
-					const int s_ = mk ? __builtin_ctz(mk) : 0;
-					if (sub == i) candSlot = s_;
-					mk &= mk - 1u;
-				}
-			}
-			const int srcC = (lane & ~7) + candSlot;
-			const float qd = __shfl(kd, srcC, 64), q0 = __shfl(k0, srcC, 64), q1 = __shfl(k1, srcC, 64), q2 = __shfl(k2, srcC, 64);
-			const uint32_t rk = rand_key(c.seed, (uint32_t)idx, (uint32_t)c.itExternal * 64u + 1u + (uint32_t)iter);
-			const int nR = c.nRandomIters;
-			enum { PH_PROP, PH_PICK, PH_RAND, PH_REFINE, PH_DONE };
-			int phase = !act ? PH_DONE : (nc > 0 ? PH_PROP : PH_PICK);
-			int t0 = 0;
-			unsigned idxScaleRange = 0;
-			float scaleRange = 1.f, depthRange = 0.f, p0 = 0.f, p1 = 0.f;
-			unsigned evals = 0;
-			for (;;) {
-				if (phase == PH_PICK) { // the RefineIters label, DepthMap.cpp:1443-1448
-					if (conf <= c.thConfSmall) idxScaleRange = 2;
-					else if (conf <= c.thConfBig) idxScaleRange = 1;
-					if (conf > c.thConfBig && conf >= c.thConfRand) phase = PH_RAND;
-					else {
-						phase = PH_REFINE;
-						scaleRange = 1.f / (float)(1u << idxScaleRange);
-						depthRange = depth * c.depthRatio;
-						p0 = pm_atan2f(n1, n0); p1 = pm_acosf(n2);
-						t0 = 0;
-					}
-				}
-				if (__ballot(phase != PH_DONE) == 0ull) break;
-				// ---- hypotheses of this round: lane (p, h) = hypothesis h of pixel p ----
-				float hd = 0.f, h0 = 0.f, h1 = 0.f, h2 = -1.f, hq0 = 0.f, hq1 = 0.f;
-				int hlimit = 63;
-				bool hv = false, planeOwn = true;
-				if (phase == PH_PROP) {
-					hd = qd; h0 = q0; h1 = q1; h2 = q2; hlimit = candSlot;
-					hv = sub < nc;
-				} else if (phase == PH_RAND) {
-					planeOwn = false;
-					if (sub < nR) {
-						hd = random_depth(c, rand_unit(rk, 3u * sub));
-						random_normal(G, rand_unit(rk, 3u * sub + 1u), rand_unit(rk, 3u * sub + 2u), h0, h1, h2);
-						hv = true;
-					}
-				} else if (phase == PH_REFINE) {
-					if (sub >= t0 && sub < nR) {
-						const uint32_t cbase = 64u + 3u * sub;
-						hd = depth + (depthRange * scaleRange) * (2.f * rand_unit(rk, cbase) - 1.f);
-						if (c.dMin <= hd && hd < c.dMax) {
-							hq0 = p0 + (c.angle1Range * scaleRange) * (2.f * rand_unit(rk, cbase + 1u) - 1.f);
-							hq1 = p1 + (c.angle2Range * scaleRange) * (2.f * rand_unit(rk, cbase + 2u) - 1.f);
-							dir2normal(hq0, hq1, h0, h1, h2);
-							hv = !(dot3(h0, h1, h2, G.v0, G.v1, 1.f) >= 0.f);
-						}
-					}
-				}
-				const unsigned long long vmask = __ballot(hv);
-				// ---- smoothness factors: one pass per pixel that has hypotheses (lane = 8 * hypothesis + slot) ----
-				float F = 1.f;
-				{
-					const float hp0 = planeOwn ? h0 : G.pn0, hp1 = planeOwn ? h1 : G.pn1, hp2 = planeOwn ? h2 : G.pn2;
-					const float hpd = planeOwn ? -hd * dot3(h0, h1, h2, G.v0, G.v1, 1.f) : G.pd;
-#pragma unroll 1
-					for (int p = 0; p < kBandRows; ++p) {
-						if (((vmask >> (8 * p)) & 0xffull) == 0ull) continue;
-						const int src = 8 * p + (lane >> 3);
-						const float gd = __shfl(hd, src, 64), g0 = __shfl(h0, src, 64), g1 = __shfl(h1, src, 64), g2 = __shfl(h2, src, 64);
-						const float gp0 = __shfl(hp0, src, 64), gp1 = __shfl(hp1, src, 64), gp2 = __shfl(hp2, src, 64), gpd = __shfl(hpd, src, 64);
-						const int glimit = __shfl(hlimit, src, 64);
-						const unsigned cb = (unsigned)(closeAll >> (8 * p)) & 0xffu, eb = (unsigned)(eligAll >> (8 * p)) & 0xffu;
-						const float Fg = band_smooth(c, park.cl[p], cb, eb, lane, gd, g0, g1, g2, gp0, gp1, gp2, gpd, glimit);
-						const float Fp = __shfl(Fg, 8 * sub, 64); // hypothesis `sub` of pixel p sits in lanes 8 * sub ...
-						if (pix == p) F = Fp;
-					}
-				}
-				// ---- scoring: chunks of up to eight (pixel, hypothesis) pairs in lane order ----
-				float mine = __builtin_huge_valf();
-				for (unsigned long long rest = vmask; rest;) {
-					// the chunk's pairs: the next (up to) eight set bits; lane j < 8 learns the lane of pair j
-					unsigned long long chunk = 0ull, tmp = rest;
-					int nPairs = 0, pairLane = 0;
-					for (; tmp && nPairs < 8; ++nPairs) {
-						const int b = __builtin_ctzll(tmp);
-						if (lane == nPairs) pairLane = b;
-						chunk |= 1ull << b;
-						tmp &= tmp - 1ull;
-					}
-					rest &= ~chunk;
-					chunk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(chunk >> 32)) << 32) |
-					        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)chunk); // the same in every lane: keep it scalar
-					nPairs = __builtin_amdgcn_readfirstlane(nPairs);
-					const int pg = lane >> 3, pv = lane & 7;             // pair-pass layout: lane = 8 * pair + view
-					const int src = __shfl(pairLane, pg < nPairs ? pg : 0, 64);
-					{ // (1) homographies of all (pair, view) of the chunk
-						const float gd = __shfl(hd, src, 64), g0 = __shfl(h0, src, 64), g1 = __shfl(h1, src, 64), g2 = __shfl(h2, src, 64);
-						const float gv0 = __shfl(G.v0, src, 64), gv1 = __shfl(G.v1, src, 64);
-						if (pg < nPairs) {
-							float vA[9], vHm[3], Hh[9];
-							const float4 a_ = park.vh[pv][0], b_ = park.vh[pv][1], cc = park.vh[pv][2];
-							vA[0] = a_.x; vA[1] = a_.y; vA[2] = a_.z; vA[3] = a_.w; vA[4] = b_.x; vA[5] = b_.y; vA[6] = b_.z; vA[7] = b_.w; vA[8] = cc.x;
-							vHm[0] = cc.y; vHm[1] = cc.z; vHm[2] = cc.w;
-							make_homography(c, vA, vHm, gv0, gv1, gd, g0, g1, g2, Hh);
-							park.hl[pg][pv][0] = make_float4(Hh[0], Hh[1], Hh[2], Hh[3]);
-							park.hl[pg][pv][1] = make_float4(Hh[4], Hh[5], Hh[6], Hh[7]);
-							park.hl[pg][pv][2] = make_float4(Hh[8], 0.f, 0.f, 0.f);
-						}
-					}
-					// (2) the tap sums of every pair: all 64 lanes = 8 views x 8 patch columns
-					{
-						int g = 0;
-						for (unsigned long long td = chunk; td; td &= td - 1ull, ++g) {
-							const int pl = __builtin_ctzll(td), pp_ = pl >> 3;
-							const int xp = rli(x, 8 * pp_), yp = rli(y, 8 * pp_), ap = rli(a, 8 * pp_);
-							Patch<8> Pp;
-							Pp.a = ap; Pp.x = xp; Pp.y = 0; Pp.sumW = Pp.invSumW = Pp.normSq0 = 0.f;
-							Pp.px0 = (float)(xp - ap + 2 * (L.seg < ap ? L.seg : ap));
-							BandStore bs; bs.pk = &park; bs.pix = pp_; bs.y = yp; bs.a = ap;
-							float Hh[9];
-							{
-								const float4 a_ = park.hl[g][L.view][0], b_ = park.hl[g][L.view][1], cc = park.hl[g][L.view][2];
-								Hh[0] = a_.x; Hh[1] = a_.y; Hh[2] = a_.z; Hh[3] = a_.w; Hh[4] = b_.x; Hh[5] = b_.y; Hh[6] = b_.z; Hh[7] = b_.w; Hh[8] = cc.x;
-							}
-							float sum, sumSq, num;
-							bool viewBad;
-							if (ap == 6) score_taps<8, 7>(c, L, Pp, bs, Hh, sum, sumSq, num, viewBad);
-							else if (ap == 5) score_taps<8, 6>(c, L, Pp, bs, Hh, sum, sumSq, num, viewBad);
-							else score_taps<8, 8>(c, L, Pp, bs, Hh, sum, sumSq, num, viewBad);
-							++issued;
-							if (L.seg == 0) park.acc[g][L.view] = make_float4(sum, sumSq, num, viewBad ? 1.f : 0.f);
-						}
-					}
-					{ // (3) per-view scores and the two-best-views means of the chunk, lane = 8 * pair + view
-						const float4 rr = park.acc[pg < nPairs ? pg : 0][pv];
-						const float gInv = __shfl(invSumW, src, 64), gNorm = __shfl(normSq0, src, 64), gF = __shfl(F, src, 64);
-						const float s_ = view_score(c, rr.x, rr.y, rr.z, rr.w != 0.f, gInv, gNorm, gF);
-						float m1 = pv < c.V ? s_ : __builtin_huge_valf(), m2 = __builtin_huge_valf();
-						min2_group<8>(m1, m2);
-						const float sc = two_best(c, m1, m2);
-						const int rank = __builtin_popcountll(chunk & ((1ull << lane) - 1ull));
-						const float got = __shfl(sc, rank * 8, 64);
-						if ((chunk >> lane) & 1ull) mine = got;
-					}
-				}
-				// ---- accept logic of every pixel, inside its lane group ----
-				if (__ballot(phase == PH_PROP)) { // candidates in slot order: the first smallest score wins if it beats the estimate
-					float bv = (phase == PH_PROP && hv) ? mine : __builtin_huge_valf();
-					int bi = sub;
-					group_argmin(bv, bi);
-					const int srcB = (lane & ~7) + bi, srcL = (lane & ~7) + (nc > 0 ? nc - 1 : 0);
-					const float bd_ = __shfl(hd, srcB, 64), b0 = __shfl(h0, srcB, 64), b1 = __shfl(h1, srcB, 64), b2 = __shfl(h2, srcB, 64);
-					const float ld = __shfl(hd, srcL, 64), l0 = __shfl(h0, srcL, 64), l1 = __shfl(h1, srcL, 64), l2 = __shfl(h2, srcL, 64);
-					if (phase == PH_PROP) {
-						evals += (unsigned)nc;
-						if (conf > bv) { conf = bv; depth = bd_; n0 = b0; n1 = b1; n2 = b2; }
-						init_plane(G, ld, l0, l1, l2); // the last candidate's plane stays (DepthMap.cpp:1421)
-						phase = PH_PICK;
-					}
-				}
-				if (__ballot(phase == PH_RAND)) { // rare: replay the sequential scan with its early exit (DepthMap.cpp:1448-1465)
-					bool again = false, stop = false;
-					for (int tt = 0; tt < nR; ++tt) {
-						const int srcT = (lane & ~7) + tt;
-						const float sv = __shfl(mine, srcT, 64), sd = __shfl(hd, srcT, 64), s0 = __shfl(h0, srcT, 64), s1 = __shfl(h1, srcT, 64), s2 = __shfl(h2, srcT, 64);
-						if (phase == PH_RAND && !stop) {
-							++evals;
-							if (conf > sv) {
-								conf = sv; depth = sd; n0 = s0; n1 = s1; n2 = s2;
-								if (conf < c.thConfRand) { again = true; stop = true; }
-							}
-						}
-					}
-					if (phase == PH_RAND) phase = again ? PH_PICK : PH_DONE;
-				}
-				if (__ballot(phase == PH_REFINE)) {
-					// the sequential scan stops at the first valid trial that beats the estimate (DepthMap.cpp:1484)
-					const unsigned range = ((1u << nR) - 1u) & ~((1u << t0) - 1u);
-					const unsigned live = ((unsigned)(vmask >> (8 * pix)) & 0xffu) & range;
-					const unsigned long long betterAll = __ballot(phase == PH_REFINE && hv && conf > mine);
-					const unsigned better = ((unsigned)(betterAll >> (8 * pix)) & 0xffu) & live;
-					const int tb = better ? __builtin_ctz(better) : 0;
-					const int srcT = (lane & ~7) + tb;
-					const float sv = __shfl(mine, srcT, 64), sd = __shfl(hd, srcT, 64), s0 = __shfl(h0, srcT, 64), s1 = __shfl(h1, srcT, 64), s2 = __shfl(h2, srcT, 64);
-					const float sq0 = __shfl(hq0, srcT, 64), sq1 = __shfl(hq1, srcT, 64);
-					if (phase == PH_REFINE) {
-						if (better) {
-							evals += (unsigned)__builtin_popcount(live & ((2u << tb) - 1u));
-							conf = sv; depth = sd; n0 = s0; n1 = s1; n2 = s2; p0 = sq0; p1 = sq1;
-							++idxScaleRange;
-							scaleRange = 1.f / (float)(1u << idxScaleRange);
-							t0 = tb + 1;
-						} else {
-							evals += (unsigned)__builtin_popcount(live);
-							t0 = nR;
-						}
-						if (t0 >= nR) phase = PH_DONE;
-					}
-				}
-			}
-			// ---- results: ring of the row, global state (read by the band below and by the next sweep) ----
-			if (act && sub == 0) {
-				float* hrec = park.hist[pix][q & (kHist - 1)];
-				hrec[0] = depth; hrec[1] = n0; hrec[2] = n1; hrec[3] = n2; hrec[4] = conf;
-				store_dn(&c.dn[idx], depth, n0, n1, n2);
-				store_f(&c.conf[idx], conf);
-				myEvals += evals;
-				myTaps += (unsigned long long)evals * (unsigned)((a + 1) * (a + 1));
-			}
-			// publish the columns the band's last row has finished (the band below waits on them)
-			const int lastRow = (nrows - band * kBandRows) < kBandRows ? (nrows - band * kBandRows) - 1 : kBandRows - 1;
-			const int donecols = t - lastRow + 1;
-			if (donecols >= 1) {
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				if (lane == 0) __hip_atomic_store(myWord, donecols < ncols ? donecols : ncols, __ATOMIC_RELAXED, HC_SCOPE);
-			}
-		}
-		if (fail) break;
-	}
-	if (sub == 0 && myEvals) { atomicAdd(sy.evals, (unsigned long long)myEvals); atomicAdd(sy.evals + 2, myTaps); }
-	if (lane == 0 && issued) atomicAdd(sy.evals + 1, (unsigned long long)issued);
-}
-
-void launch_band_sweep(const EstConst* dItems, int nItems, int totalBands, const SweepSync& sync, int iter, int affinity, hipStream_t s) {
-	int grid = totalBands < 8192 ? totalBands : 8192;
-	if (grid < 1) return;
-	hipLaunchKernelGGL(band_kernel, dim3(grid), dim3(64), 0, s, dItems, nItems, sync, iter, affinity);
-}
-
-// ------------------------------------------------------------------------------------------------------
 // init-score pass (SceneDensify.cpp:649-675 ScoreDepthMapTmp): no inter-pixel dependence
 
 __global__ void import_kernel(EstConst c, const float* depthIn, const float* normalIn) {
@@ -2033,6 +1595,16 @@ __global__ void gradient_kernel(const uint8_t* g, uint8_t* gra, int W, int H) {
 	if ((s2 & 1) && (r & 1)) r += 1;
 	gra[y * W + x] = (uint8_t)(r > 255 ? 255 : r);
 }
+// The layout the scorer gathers from: per pixel the 2 x 2 footprint of a bilinear sample, (I(x,y), I(x+1,y), I(x,y+1), I(x+1,y+1))
+// (Types.inl:2250-2258 reads exactly these four), so that one 16-byte load serves a sample; the last column / row repeat
+// (never sampled: positions are inside the image with a border of 1, Types.h:1633-1635).  Four times the bytes of the image --
+// HBM is sized for it -- and the same number of cache lines per wave-instruction as two 8-byte gathers from two rows.
+__global__ void quad_kernel(const float* g, float4* out, int W, int H) {
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+	if (x >= W || y >= H) return;
+	const int x1 = x + 1 < W ? x + 1 : W - 1, y1 = y + 1 < H ? y + 1 : H - 1;
+	out[(size_t)y * W + x] = make_float4(g[(size_t)y * W + x], g[(size_t)y * W + x1], g[(size_t)y1 * W + x], g[(size_t)y1 * W + x1]);
+}
 __global__ void median3_kernel(const float* in, float* out, int W, int H) {
 	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
 	if (x >= W || y >= H) return;
@@ -2061,8 +1633,8 @@ __global__ void median3_kernel(const float* in, float* out, int W, int H) {
 
 #ifdef HCMVS_STAMPS
 void debug_read_stamps(unsigned long long* out, int reset) {
-	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
-	if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z); }
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32);
+	if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z); }
 }
 #endif
 
@@ -2079,6 +1651,9 @@ void launch_bgr_to_u8(const uint8_t* bgr, uint8_t* out, int n, hipStream_t s) {
 }
 void launch_gradient_map(const uint8_t* g8, uint8_t* gra, int W, int H, hipStream_t s) {
 	hipLaunchKernelGGL(gradient_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(64, 4), 0, s, g8, gra, W, H);
+}
+void launch_quads(const float* gray, float4* out, int W, int H, hipStream_t s) {
+	hipLaunchKernelGGL(quad_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(64, 4), 0, s, gray, out, W, H);
 }
 void launch_median3(const float* in, float* out, int W, int H, hipStream_t s) {
 	hipLaunchKernelGGL(median3_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(64, 4), 0, s, in, out, W, H);

@@ -9,28 +9,44 @@
  * (DensifyPointCloud.cpp:447-449).
  *
  * Deliberately narrower than the reference ("defined subset"): images are read from binary
- * PPM/PGM files (no PNG/JPEG codecs here); resolution levels halve the image with a box filter (== cv::resize
- * INTER_AREA for integer factors); the initial maps come from the Delaunay triangulation of the sparse points
- * (--n-initTriangulate 1, the default), from the previous level's depth maps in the working folder
- * (--n-initTriangulate 0, the fork's coarse-to-fine hand-off) or from a splat (--min-views-trust-point 1); optical flow, semantic priors, view spread, gap interpolation and SGM modes are not available and the
- * corresponding flags are accepted and ignored with a note.
+ * PPM/PGM files (no PNG/JPEG codecs here); the initial maps come from the Delaunay triangulation of the sparse points
+ * (--n-initTriangulate 1, the default), from the previous run's maps under <working-folder>/depthmap + normalmap
+ * (--n-initTriangulate 0, the fork's hand-off, SceneDensify.cpp:527-553) or from a splat (--min-views-trust-point 1); --n-nOptimize
+ * gates the fork's post-filters (RemoveSmallSegments + GapInterpolation) as in the reference; optical flow, semantic priors, view
+ * spread and SGM modes are not available and the corresponding flags are accepted and ignored with a note.
+ *
+ * How the run is laid out in time (the reference overlaps image k + 1's InitViews with image k's estimate, SceneDensify.cpp:3699-3703;
+ * here the unit is a batch of reference images):
+ *   load     all cores decode / resize the images and select the source views at the same time; uploads go out as images arrive
+ *   estimate a loader thread prepares the initial maps of batch k + 1 (triangulation on all cores, upload) while the device
+ *            estimates batch k; after the last outer iteration a copier thread brings finished batches back and a pool of writer
+ *            threads saves the depth maps while the next batch is estimated and while the fusion runs
+ *   resume   an image whose final depth map is already in the working folder is not estimated again (SceneDensify.cpp:3865-3880)
  */
 #include "../../include/hcmvs_hip.h"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <sys/stat.h>
 
 namespace {
 
@@ -45,10 +61,13 @@ struct Options { // DensifyPointCloud.cpp:139-198 (defaults from there)
 	                              // (shorter dependence chains; point count within 1 % of the reference's)
 	int estimateColors = 2, estimateNormals = 2;   // 2: during fusion, 1: after it (DepthMap.cpp:2125-2269), 0: none
 	int maxResolution = 3200, minResolution = 640;  // DensifyPointCloud.cpp:144-145
-	int postFilter = 1;           // the fork's RemoveSmallSegments + GapInterpolation after outer iterations 1 and 2 (SceneDensify.cpp:3939-3958)
+	int nOptimize = 2;            // --n-nOptimize (DensifyPointCloud.cpp:164, 268): bits REMOVE_SPECKLES 1 | FILL_GAPS 2 (DepthMap.h:113-118) gate the fork's
+	                              // RemoveSmallSegments + GapInterpolation after outer iterations 1 and 2 (SceneDensify.cpp:3916, 3939-3958)
+	int postFilter = -1;          // --n-postfilter 0|1: override of that gate (-1: follow --n-nOptimize)
+	int resume = 1;               // skip-if-exists (SceneDensify.cpp:3865-3880): an image whose final depth map is already in the working folder is not estimated again
 	int restoreHypothesis = 0;    // 1: the `restore` binary's extra last-sweep hypothesis from the previous level's maps
 	                              // (restore/libs/MVS/DepthMap.cpp:1527-1549); needs the previous level's maps in the working folder
-	int device = 0, batch = 8;
+	int device = 0, batch = 32;   // reference images per launch: 32 is the measured optimum (profiles/r02_knobs.txt); lowered when HBM is short
 	uint32_t seed = 1234;
 };
 
@@ -195,9 +214,8 @@ bool save_mvs(const std::string& path, const std::vector<MvsPlatform>& platforms
 }
 
 // ---- images --------------------------------------------------------------------------------------------------------
-bool load_pnm(const std::string& path, int& w, int& h, std::vector<uint8_t>& bgr) {
-	std::ifstream f(path, std::ios::binary);
-	if (!f) return false;
+// header of a binary PPM / PGM: size and channel count; the stream is left at the first pixel
+bool pnm_header(std::ifstream& f, int& w, int& h, int& ch) {
 	std::string magic;
 	f >> magic;
 	if (magic != "P5" && magic != "P6") return false;
@@ -205,8 +223,19 @@ bool load_pnm(const std::string& path, int& w, int& h, std::vector<uint8_t>& bgr
 	w = next(); h = next();
 	const int maxv = next();
 	f.get();
-	if (w <= 0 || h <= 0 || maxv != 255) return false;
-	const int ch = magic == "P6" ? 3 : 1;
+	ch = magic == "P6" ? 3 : 1;
+	return w > 0 && h > 0 && maxv == 255 && (bool)f;
+}
+bool pnm_size(const std::string& path, int& w, int& h) {
+	std::ifstream f(path, std::ios::binary);
+	int ch;
+	return f && pnm_header(f, w, h, ch);
+}
+bool load_pnm(const std::string& path, int& w, int& h, std::vector<uint8_t>& bgr) {
+	std::ifstream f(path, std::ios::binary);
+	if (!f) return false;
+	int ch;
+	if (!pnm_header(f, w, h, ch)) return false;
 	std::vector<uint8_t> raw((size_t)w * h * ch);
 	f.read((char*)raw.data(), (std::streamsize)raw.size());
 	if (!f) return false;
@@ -375,11 +404,13 @@ bool select_views(std::vector<ImageData>& images, const std::vector<Vertex>& ver
 	return !A.srcs.empty();
 }
 
-bool save_dmap(const std::string& path, const ImageData& im, const std::vector<float>& d, const std::vector<float>& n, const std::vector<float>& c) {
+// raw 'DR' file (Interface.h:634-652): any of depth (flag 1), normal (2), confidence (4); null = not stored
+bool save_dmap(const std::string& path, const ImageData& im, const float* d, const float* n, const float* c) {
 	std::ofstream f(path + ".tmp", std::ios::binary); // atomic like DepthData::Save (DepthMap.cpp:253-286)
 	if (!f) return false;
 	struct __attribute__((packed)) Hdr { uint16_t name; uint8_t type, pad; uint32_t iw, ih, dw, dh; float dMin, dMax; } h;
-	h.name = 0x5244; h.type = 7; h.pad = 0; h.iw = h.dw = (uint32_t)im.w; h.ih = h.dh = (uint32_t)im.h; h.dMin = im.dMin; h.dMax = im.dMax;
+	const size_t px = (size_t)im.w * im.h;
+	h.name = 0x5244; h.type = (uint8_t)((d ? 1 : 0) | (n ? 2 : 0) | (c ? 4 : 0)); h.pad = 0; h.iw = h.dw = (uint32_t)im.w; h.ih = h.dh = (uint32_t)im.h; h.dMin = im.dMin; h.dMax = im.dMax;
 	f.write((const char*)&h, 28);
 	const uint16_t nl = (uint16_t)im.name.size();
 	f.write((const char*)&nl, 2); f.write(im.name.data(), nl);
@@ -387,10 +418,11 @@ bool save_dmap(const std::string& path, const ImageData& im, const std::vector<f
 	const uint32_t nids = 1 + (uint32_t)ids.size();
 	f.write((const char*)&nids, 4); f.write((const char*)&im.id, 4); f.write((const char*)ids.data(), (std::streamsize)ids.size() * 4);
 	f.write((const char*)im.cam.K, 72); f.write((const char*)im.cam.R, 72); f.write((const char*)im.cam.C, 24);
-	f.write((const char*)d.data(), (std::streamsize)d.size() * 4); f.write((const char*)n.data(), (std::streamsize)n.size() * 4);
-	f.write((const char*)c.data(), (std::streamsize)c.size() * 4);
+	if (d) f.write((const char*)d, (std::streamsize)px * 4);
+	if (n) f.write((const char*)n, (std::streamsize)px * 12);
+	if (c) f.write((const char*)c, (std::streamsize)px * 4);
 	f.close();
-	return std::rename((path + ".tmp").c_str(), path.c_str()) == 0;
+	return (bool)f && std::rename((path + ".tmp").c_str(), path.c_str()) == 0;
 }
 bool save_ply(const std::string& path, const RawArray<float>& xyz, const RawArray<float>& nrm, const RawArray<uint8_t>& bgr) {
 	Writer w;
@@ -414,19 +446,27 @@ bool save_ply(const std::string& path, const RawArray<float>& xyz, const RawArra
 }
 
 // raw 'DR' depth map written by save_dmap / the reference (Interface.h:634-652); returns false when absent or malformed
-bool load_dmap(const std::string& path, int& w, int& h, std::vector<float>& d, std::vector<float>& n) {
+struct DmapFile { int w = 0, h = 0; float dMin = 0, dMax = 0; std::vector<float> d, n, c; };
+// what: bit 1 depth, 2 normal, 4 confidence -- the maps wanted; a wanted map the file does not hold fails the load.
+// headerOnly: size and range only
+bool load_dmap(const std::string& path, DmapFile& m, int what, bool headerOnly = false) {
 	std::ifstream f(path, std::ios::binary);
 	if (!f) return false;
 	struct __attribute__((packed)) Hdr { uint16_t name; uint8_t type, pad; uint32_t iw, ih, dw, dh; float dMin, dMax; } hd;
 	f.read((char*)&hd, 28);
-	if (!f || hd.name != 0x5244 || !(hd.type & 1)) return false;
+	if (!f || hd.name != 0x5244 || (hd.type & what) != what) return false;
+	m.w = (int)hd.dw; m.h = (int)hd.dh; m.dMin = hd.dMin; m.dMax = hd.dMax;
+	if (m.w <= 0 || m.h <= 0 || m.w > 65536 || m.h > 65536) return false;
+	if (headerOnly) return true;
 	uint16_t nl = 0; f.read((char*)&nl, 2); f.seekg(nl, std::ios::cur);
 	uint32_t nids = 0; f.read((char*)&nids, 4); f.seekg((std::streamoff)nids * 4 + 72 + 72 + 24, std::ios::cur);
-	w = (int)hd.dw; h = (int)hd.dh;
-	d.resize((size_t)w * h);
-	f.read((char*)d.data(), (std::streamsize)d.size() * 4);
-	n.assign((size_t)w * h * 3, 0.f);
-	if (hd.type & 2) f.read((char*)n.data(), (std::streamsize)n.size() * 4);
+	const size_t px = (size_t)m.w * m.h;
+	auto part = [&](int bit, size_t floats, std::vector<float>& v) {
+		if (!(hd.type & bit)) return;
+		if (what & bit) { v.resize(floats); f.read((char*)v.data(), (std::streamsize)floats * 4); }
+		else f.seekg((std::streamoff)floats * 4, std::ios::cur);
+	};
+	part(1, px, m.d); part(2, px * 3, m.n); part(4, px, m.c);
 	return (bool)f;
 }
 // cv::resize(..., INTER_CUBIC) as the hand-off uses it (SceneDensify.cpp:541-542): Keys kernel a = -0.75, pixel centres
@@ -474,6 +514,31 @@ std::string dirname_of(const std::string& p) { const size_t k = p.find_last_of('
 #define HIPOK(call) do { if ((call) != hipSuccess) { fprintf(stderr, "error: %s failed\n", #call); return EXIT_FAILURE; } } while (0)
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+static std::string map_path(const std::string& dir, const char* fmt, uint32_t id) { char nm[96]; snprintf(nm, sizeof nm, fmt, id); return dir + nm; }
+
+namespace {
+
+// One batch of reference images whose initial maps the loader thread prepares while the device works on the batch before it
+// (the reference requests "next image initialization to be performed while computing this depth-map", SceneDensify.cpp:3699-3703)
+struct Prepared { bool ready = false; int failed = 0; uint32_t failedId = 0; };
+
+// the initial maps of one image (SceneDensify.cpp:772-812) and, for the `restore` variant, its hint maps: host part
+struct InitMaps { std::vector<float> d, n, hd, hn; int failed = 0; };
+
+// Saving the final maps: a copier thread brings the maps of finished batches to the host (its own stream; the device keeps
+// estimating), writer threads put them on disk.  The fusion mutates the depth maps (SceneDensify.cpp:3447-3449), so it waits for
+// the copies -- not for the files.
+struct SaveJob { uint32_t id; std::vector<float> d, n, c; };
+struct Saver {
+	std::mutex mu; std::condition_variable cv;
+	std::deque<uint32_t> toCopy; std::deque<std::unique_ptr<SaveJob>> toWrite;
+	size_t bytesQueued = 0, copied = 0, written = 0, submitted = 0;
+	bool closing = false; std::string error;
+	static constexpr size_t kMaxQueuedBytes = (size_t)12 << 30; // host memory the copier may run ahead of the writers
+};
+
+} // namespace
 
 int main(int argc, char** argv) {
 	const double tStart = now_s();
@@ -493,7 +558,7 @@ int main(int argc, char** argv) {
 		"--n-usegeoconsistency", "--n-initTriangulate", "--n-viewspread", "--n-opticalflow", "--n-adapthalfwin",
 		"--n-propagatehalfwin", "--n-propagatestep",
 		// this driver's own
-		"--min-views-trust-point", "--fuse-order", "--device", "--batch", "--seed", "--restore-hypothesis", "--n-postfilter"};
+		"--min-views-trust-point", "--fuse-order", "--device", "--batch", "--seed", "--restore-hypothesis", "--n-postfilter", "--resume"};
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i], val;
 		if (a == "-h" || a == "--help") { kv["--help"] = "1"; continue; }
@@ -521,12 +586,13 @@ int main(int argc, char** argv) {
 	geti("--n-propagatehalfwin", o.propagateHalfWin); geti("--n-propagatestep", o.propagateStep);
 	getf("--n-photometric_flow", o.photometricFlow); getf("--depthweight", o.depthweight); getf("--normalweight", o.normalweight);
 	geti("--n-initTriangulate", o.initTriangulate); geti("--min-views-trust-point", o.minViewsTrustPoint);
-	geti("--fuse-order", o.fuseOrder); geti("--restore-hypothesis", o.restoreHypothesis); geti("--n-postfilter", o.postFilter);
+	geti("--fuse-order", o.fuseOrder); geti("--restore-hypothesis", o.restoreHypothesis); geti("--n-postfilter", o.postFilter); geti("--n-nOptimize", o.nOptimize); geti("--resume", o.resume);
 	geti("--device", o.device); geti("--batch", o.batch);
 	if (kv.count("--seed")) o.seed = (uint32_t)strtoul(kv["--seed"].c_str(), nullptr, 10);
 	geti("--estimate-colors", o.estimateColors); geti("--estimate-normals", o.estimateNormals);
 	geti("--max-resolution", o.maxResolution); geti("--min-resolution", o.minResolution);
-	for (const char* k : {"--n-opticalflow", "--n-viewspread", "--use-semantic", "--n-nOptimize", "--n-usegeoconsistency", "--n-usepartconsistency"})
+	if (o.postFilter < 0) o.postFilter = (o.nOptimize & 3) != 0 ? 1 : 0; // OPTDENSE::OPTIMIZE = REMOVE_SPECKLES | FILL_GAPS (DepthMap.h:113-118)
+	for (const char* k : {"--n-opticalflow", "--n-viewspread", "--use-semantic", "--n-usegeoconsistency", "--n-usepartconsistency"})
 		if (kv.count(k) && atoi(kv[k].c_str()) != 0 && o.verbosity > 1)
 			fprintf(stderr, "note: %s is not available in this build (defined subset); treated as 0\n", k);
 	if (kv.count("--filter-point-cloud") && atoi(kv["--filter-point-cloud"].c_str()) < 0) {
@@ -544,11 +610,15 @@ int main(int argc, char** argv) {
 	if (o.output.empty()) o.output = o.input.substr(0, o.input.rfind('.')) + "_dense.mvs";
 	if (o.batch < 1) o.batch = 1;
 	if (o.batch > HCMVS_MAX_BATCH) o.batch = HCMVS_MAX_BATCH;
+	if (o.estimationItersExternal < 1) o.estimationItersExternal = 1;
 
 	std::vector<MvsPlatform> platforms; std::vector<MvsImage> mimages; std::vector<Vertex> verts;
 	if (!load_mvs(o.input, platforms, mimages, verts)) { fprintf(stderr, "error: can not load '%s'\n", o.input.c_str()); return EXIT_FAILURE; }
 	std::vector<ImageData> images(mimages.size());
+	std::vector<std::string> paths(mimages.size());
 	unsigned nValid = 0;
+	// headers first: the working size and the camera of every image are known before a pixel is decoded, which is all the view
+	// selection needs
 	for (size_t i = 0; i < mimages.size(); ++i) {
 		ImageData& im = images[i];
 		im.name = mimages[i].name; im.id = (uint32_t)i;
@@ -556,13 +626,11 @@ int main(int argc, char** argv) {
 		const MvsPlatform& p = platforms[mimages[i].platformID];
 		const MvsCamera& c = p.cams[mimages[i].cameraID];
 		const MvsPose& q = p.poses[mimages[i].poseID];
-		std::string path = im.name[0] == '/' ? im.name : dirname_of(o.input) + "/" + im.name;
-		if (!load_pnm(path, im.w, im.h, im.bgr)) { fprintf(stderr, "error: failed loading image '%s' (binary PPM/PGM expected)\n", path.c_str()); return EXIT_FAILURE; }
-		{ // SceneDensify.cpp:3612-3615: one INTER_AREA resize to the resolution level's size, within [min-resolution, max-resolution]
-			int nw, nh;
-			working_size(im.w, im.h, (unsigned)std::max(0, o.resolutionLevel), (unsigned)std::max(1, o.minResolution), (unsigned)std::max(1, o.maxResolution), nw, nh);
-			if (nw != im.w || nh != im.h) resize_area_bgr(im.w, im.h, im.bgr, nw, nh);
-		}
+		paths[i] = im.name[0] == '/' ? im.name : dirname_of(o.input) + "/" + im.name;
+		int fw = 0, fh = 0;
+		if (!pnm_size(paths[i], fw, fh)) { fprintf(stderr, "error: failed loading image '%s' (binary PPM/PGM expected)\n", paths[i].c_str()); return EXIT_FAILURE; }
+		// SceneDensify.cpp:3612-3615: one INTER_AREA resize to the resolution level's size, within [min-resolution, max-resolution]
+		working_size(fw, fh, (unsigned)std::max(0, o.resolutionLevel), (unsigned)std::max(1, o.minResolution), (unsigned)std::max(1, o.maxResolution), im.w, im.h);
 		// Interface.h:451-459 pose composition; K rescaled to the working resolution (Scene.cpp:83-91, Camera.h:167-180)
 		mat3mul(c.R, q.R, im.cam.R);
 		for (int k = 0; k < 3; ++k) im.cam.C[k] = q.R[0 * 3 + k] * c.C[0] + q.R[1 * 3 + k] * c.C[1] + q.R[2 * 3 + k] * c.C[2] + q.C[k];
@@ -573,24 +641,44 @@ int main(int argc, char** argv) {
 		im.cam.K[0] *= s; im.cam.K[4] *= s;
 		if (c.K[2] == 0 && c.K[5] == 0) { im.cam.K[2] = 0.5 * (im.w - 1); im.cam.K[5] = 0.5 * (im.h - 1); }
 		else { im.cam.K[2] *= s; im.cam.K[5] *= s; }
-		im.gray.resize((size_t)im.w * im.h);
-		for (size_t k = 0; k < im.gray.size(); ++k)
-			im.gray[k] = (0.114f * im.bgr[3 * k] + 0.587f * im.bgr[3 * k + 1] + 0.299f * im.bgr[3 * k + 2]) / 255.f;
 		im.valid = true;
 		++nValid;
 	}
-	if (o.verbosity > 1) printf("Scene loaded: %zu images (%u calibrated), %zu sparse points\n", images.size(), nValid, verts.size());
-
-	const double tLoaded = now_s();
 	hcmvs_ctx* ctx = nullptr;
 	if (hcmvs_create(o.device, &ctx) != HCMVS_OK) { fprintf(stderr, "error: no usable MI355X device (there is no CPU path)\n"); return EXIT_FAILURE; }
-	std::vector<uint32_t> todo;
-	for (auto& im : images)
-		if (im.valid) CHK(hcmvs_upload_view(ctx, im.id, im.w, im.h, im.gray.data(), im.bgr.data(), im.cam.K, im.cam.R, im.cam.C));
+	// decode + resize + gray conversion of the images and the view selection of every image, all cores, one work list: image i is
+	// item i, its view selection item N + i (every item writes only its own image; the selection reads cameras and sizes only,
+	// SceneDensify.cpp:3590-3634 is an OpenMP loop too).  An image goes to the device as soon as it is decoded.
 	std::vector<char> selected(images.size(), 0);
+	std::string loadError;
+	{
+		std::mutex upMu;
+		const long N = (long)images.size();
 #pragma omp parallel for schedule(dynamic, 1)
-	for (long i = 0; i < (long)images.size(); ++i) // every image writes only its own lists (SceneDensify.cpp:3590-3634 is an OpenMP loop too)
-		if (images[i].valid) selected[i] = select_views(images, verts, (uint32_t)i, 12, o.numberViews) ? 1 : 0;
+		for (long t = 0; t < 2 * N; ++t) {
+			if (t >= N) {
+				const long i = t - N;
+				if (images[i].valid) selected[i] = select_views(images, verts, (uint32_t)i, 12, o.numberViews) ? 1 : 0;
+				continue;
+			}
+			ImageData& im = images[t];
+			if (!im.valid) continue;
+			int fw = 0, fh = 0;
+			std::vector<uint8_t> bgr;
+			if (!load_pnm(paths[t], fw, fh, bgr)) { std::lock_guard<std::mutex> g(upMu); loadError = "failed loading image '" + paths[t] + "'"; continue; }
+			if (fw != im.w || fh != im.h) resize_area_bgr(fw, fh, bgr, im.w, im.h);
+			std::vector<float> gray((size_t)im.w * im.h);
+			for (size_t k = 0; k < gray.size(); ++k) // Types.inl:2354-2400 toGray, normalised
+				gray[k] = (0.114f * bgr[3 * k] + 0.587f * bgr[3 * k + 1] + 0.299f * bgr[3 * k + 2]) / 255.f;
+			std::lock_guard<std::mutex> g(upMu); // one HIP stream: uploads one after the other, while the other cores decode
+			if (hcmvs_upload_view(ctx, im.id, im.w, im.h, gray.data(), bgr.data(), im.cam.K, im.cam.R, im.cam.C) != HCMVS_OK && loadError.empty())
+				loadError = std::string("upload of image '") + paths[t] + "' failed: " + hcmvs_last_error(ctx);
+		}
+	}
+	if (!loadError.empty()) { fprintf(stderr, "error: %s\n", loadError.c_str()); return EXIT_FAILURE; }
+	if (o.verbosity > 1) printf("Scene loaded: %zu images (%u calibrated), %zu sparse points\n", images.size(), nValid, verts.size());
+	const double tLoaded = now_s();
+	std::vector<uint32_t> todo;
 	for (auto& im : images) {
 		if (!im.valid) continue;
 		if (!selected[im.id]) {
@@ -637,116 +725,267 @@ int main(int argc, char** argv) {
 	prm.adapthalfwin = o.adaptHalfWin; prm.n_estimation_iters = o.estimationIters; prm.n_external_iters = o.estimationItersExternal;
 	prm.propagate_halfwin = o.propagateHalfWin; prm.propagate_step = o.propagateStep; prm.photometric_flow = o.photometricFlow; prm.seed = o.seed;
 
-	// initial maps (SceneDensify.cpp:772-812), kept on the device between outer iterations:
+	// the batch size the device memory allows: per image of a batch the working state (24 B/px) on top of what stays resident per
+	// image (maps 20 B/px, hint maps 16 B/px, gray + colour + gradient 8 B/px, source footprints 16 B/px)
+	{
+		size_t freeB = 0, totalB = 0, maxPx = 0, allPx = 0;
+		HIPOK(hipMemGetInfo(&freeB, &totalB));
+		for (uint32_t id : todo) { const size_t px = (size_t)images[id].w * images[id].h; maxPx = std::max(maxPx, px); allPx += px; }
+		const size_t resident = allPx * (size_t)(20 + 16 + (o.restoreHypothesis ? 16 : 0)) + ((size_t)2 << 30);
+		while (o.batch > 1 && resident + (size_t)o.batch * maxPx * 24 > freeB) o.batch /= 2;
+		if (o.verbosity > 2) printf("Batch of %d reference images per launch (%.1f GiB of device memory free)\n", o.batch, freeB / 1073741824.0);
+	}
+
+	// skip-if-exists resume (SceneDensify.cpp:3865-3880: "try to load already compute depth-map for this image"): an image whose
+	// final depth map of this size is in the working folder is loaded instead of estimated
+	std::vector<char> resumed(images.size(), 0);
+	std::vector<uint32_t> work; // the images to estimate, in todo order
+	for (uint32_t id : todo) {
+		DmapFile hdr;
+		if (o.resume && load_dmap(map_path(o.workdir, "/depth%04u.dmap", id), hdr, 7, true) && hdr.w == images[id].w && hdr.h == images[id].h) resumed[id] = 1;
+		else work.push_back(id);
+	}
+	for (uint32_t id : todo) {
+		if (!resumed[id]) continue;
+		ImageData& im = images[id];
+		DmapFile m;
+		if (!load_dmap(map_path(o.workdir, "/depth%04u.dmap", id), m, 7)) { fprintf(stderr, "error: invalid depth-map '%s'\n", map_path(o.workdir, "/depth%04u.dmap", id).c_str()); return EXIT_FAILURE; }
+		const size_t n = (size_t)im.w * im.h;
+		im.dMin = m.dMin; im.dMax = m.dMax;
+		HIPOK(hipMalloc(&im.dDepth, n * 4)); HIPOK(hipMalloc(&im.dNormal, n * 12)); HIPOK(hipMalloc(&im.dConf, n * 4));
+		HIPOK(hipMemcpy(im.dDepth, m.d.data(), n * 4, hipMemcpyHostToDevice)); HIPOK(hipMemcpy(im.dNormal, m.n.data(), n * 12, hipMemcpyHostToDevice));
+		HIPOK(hipMemcpy(im.dConf, m.c.data(), n * 4, hipMemcpyHostToDevice));
+		if (o.verbosity > 1) printf("Depth-map for image %3u loaded from '%s' (not estimated again)\n", id, map_path(o.workdir, "/depth%04u.dmap", id).c_str());
+	}
+
+	// batches: images of one lane layout class (up to 8 source views, or 9..16) share a launch
+	std::vector<std::vector<uint32_t>> batches;
+	{
+		std::map<int, std::vector<uint32_t>> byClass;
+		for (uint32_t id : work) byClass[images[id].srcs.size() <= 8 ? 8 : 16].push_back(id);
+		for (auto& g : byClass)
+			for (size_t b0 = 0; b0 < g.second.size(); b0 += (size_t)o.batch)
+				batches.emplace_back(g.second.begin() + (long)b0, g.second.begin() + (long)std::min(g.second.size(), b0 + (size_t)o.batch));
+	}
+
+	// ---- the loader: initial maps of batch k + 1 while batch k is estimated (outer iteration 0) ----
 	//   nMinViewsTrustPoint < 2      splat of the sparse points (SceneDensify.cpp:783-808)
 	//   initTriangulate != 0         Delaunay triangulation of the sparse points (DepthMapsData::InitDepthMap, DepthMap.cpp:1796-1936)
-	//   initTriangulate == 0         the previous (coarser) level's maps from the working folder, resized (SceneDensify.cpp:527-553)
-	// the host part (triangulation / resize) of up to 16 images at a time runs on all cores, like the reference's OpenMP
-	// loop over the images (SceneDensify.cpp:3651-3667); the uploads follow in order
-	for (size_t c0 = 0; c0 < todo.size(); c0 += 16) {
-		const size_t c1 = std::min(todo.size(), c0 + 16);
-		std::vector<std::vector<float>> dAll(c1 - c0), nAll(c1 - c0), hdAll(c1 - c0), hnAll(c1 - c0);
-		std::vector<int> failed(c1 - c0, 0);
+	//   initTriangulate == 0         the previous run's maps, <working-folder>/depthmap/depth%04u.dmap + normalmap/normal%04u.dmap
+	//                                (what run.sh moves between the stages; SceneDensify.cpp:527-553), else <working-folder>/depth%04u.dmap
+	// restore-hypothesis: the previous level's maps, enlarged with INTER_AREA, are the extra last-sweep hypothesis and widen the
+	// depth range (restore/libs/MVS/SceneDensify.cpp:508-532)
+	std::vector<Prepared> prepared(batches.size());
+	std::mutex prepMu; std::condition_variable prepCv;
+	std::string prepError;
+	auto previous_maps = [&](uint32_t id, DmapFile& out) -> bool {
+		DmapFile dm, nm;
+		if (load_dmap(map_path(o.workdir, "/depthmap/depth%04u.dmap", id), dm, 1) && load_dmap(map_path(o.workdir, "/normalmap/normal%04u.dmap", id), nm, 2) &&
+		    dm.w == nm.w && dm.h == nm.h) {
+			out.w = dm.w; out.h = dm.h; out.d.swap(dm.d); out.n.swap(nm.n);
+			return true;
+		}
+		return load_dmap(map_path(o.workdir, "/depth%04u.dmap", id), out, 3);
+	};
+	auto loader = [&]() {
+		if (hipSetDevice(o.device) != hipSuccess) { std::lock_guard<std::mutex> g(prepMu); prepError = "hipSetDevice failed in the loader"; prepCv.notify_all(); return; }
+		for (size_t b = 0; b < batches.size(); ++b) {
+			const std::vector<uint32_t>& ids = batches[b];
+			std::vector<InitMaps> maps(ids.size());
 #pragma omp parallel for schedule(dynamic, 1)
-		for (long k = (long)c0; k < (long)c1; ++k) {
-			ImageData& im = images[todo[k]];
-			const uint32_t id = im.id;
-			std::vector<float> pts;
-			for (uint32_t idx : im.points) { pts.push_back(verts[idx].X[0]); pts.push_back(verts[idx].X[1]); pts.push_back(verts[idx].X[2]); }
-			const size_t n = (size_t)im.w * im.h;
-			std::vector<float>& d = dAll[k - c0];
-			std::vector<float>& nn = nAll[k - c0];
-			d.assign(n, 0.f); nn.assign(3 * n, 0.f);
-			if (o.minViewsTrustPoint < 2) {
-				if (hcmvs_splat_init(ctx, id, pts.data(), (int32_t)im.points.size(), d.data(), nn.data(), &im.dMin, &im.dMax) != HCMVS_OK) failed[k - c0] = 1;
-			} else if (o.initTriangulate) {
-				if (hcmvs_triangulate_points(im.w, im.h, im.cam.K, im.cam.R, im.cam.C, pts.data(), (int32_t)im.points.size(), 0.f, 1, d.data(), nn.data(),
-				                             &im.dMin, &im.dMax) != HCMVS_OK) failed[k - c0] = 1;
-			} else {
-				char nm[64];
-				snprintf(nm, sizeof nm, "/depth%04u.dmap", id);
-				int pw = 0, ph = 0;
-				std::vector<float> pd, pn;
-				if (!load_dmap(o.workdir + nm, pw, ph, pd, pn)) { failed[k - c0] = 2; continue; }
-				if (o.verbosity > 2) printf("read  :  %s%s (%dx%d -> %dx%d)\n", o.workdir.c_str(), nm, pw, ph, im.w, im.h);
-				resize_cubic(pd, pw, ph, 1, d, im.w, im.h);
-				resize_cubic(pn, pw, ph, 3, nn, im.w, im.h);
-				// depth range of the resized map (SceneDensify.cpp:544-553; taken over the valid depths only, the cubic
-				// kernel overshoots next to holes and a non-positive bound would poison the random-depth range)
-				float lo = 3.402823466e+38f, hi = 0.f;
-				for (size_t q_ = 0; q_ < n; ++q_) {
-					if (!(d[q_] > 0.f)) { d[q_] = 0.f; continue; }
-					lo = std::min(lo, d[q_]); hi = std::max(hi, d[q_]);
-					float* q = &nn[3 * q_];
-					const float len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
-					if (len > 0.f) { q[0] /= len; q[1] /= len; q[2] /= len; }
+			for (long k = 0; k < (long)ids.size(); ++k) {
+				ImageData& im = images[ids[k]];
+				InitMaps& M = maps[k];
+				const size_t n = (size_t)im.w * im.h;
+				std::vector<float> pts;
+				for (uint32_t idx : im.points) { pts.push_back(verts[idx].X[0]); pts.push_back(verts[idx].X[1]); pts.push_back(verts[idx].X[2]); }
+				M.d.assign(n, 0.f); M.n.assign(3 * n, 0.f);
+				if (o.minViewsTrustPoint < 2) {
+					if (hcmvs_splat_init(ctx, im.id, pts.data(), (int32_t)im.points.size(), M.d.data(), M.n.data(), &im.dMin, &im.dMax) != HCMVS_OK) M.failed = 1;
+				} else if (o.initTriangulate || o.restoreHypothesis) { // the `restore` binary always triangulates (restore/libs/MVS/SceneDensify.cpp:508-511)
+					if (hcmvs_triangulate_points(im.w, im.h, im.cam.K, im.cam.R, im.cam.C, pts.data(), (int32_t)im.points.size(), 0.f, 1, M.d.data(), M.n.data(),
+					                             &im.dMin, &im.dMax) != HCMVS_OK) M.failed = 1;
+				} else {
+					DmapFile pm;
+					if (!previous_maps(im.id, pm)) { M.failed = 2; continue; }
+					if (o.verbosity > 2) printf("read  :  %s (%dx%d -> %dx%d)\n", map_path(o.workdir, "/depthmap/depth%04u.dmap", im.id).c_str(), pm.w, pm.h, im.w, im.h);
+					// the reference hands maps over between runs of the SAME level (run.sh: restore at level l, then frame_main at level l)
+					// and uses them as they are (its INTER_CUBIC resize is to the map's own size, SceneDensify.cpp:541-542); maps of
+					// another size are brought to this one with that cubic kernel
+					if (pm.w == im.w && pm.h == im.h) { M.d.swap(pm.d); M.n.swap(pm.n); }
+					else { resize_cubic(pm.d, pm.w, pm.h, 1, M.d, im.w, im.h); resize_cubic(pm.n, pm.w, pm.h, 3, M.n, im.w, im.h); }
+					// depth range of the map (SceneDensify.cpp:544-553; over the valid depths only: the cubic kernel overshoots next to
+					// holes and a non-positive bound would poison the random-depth range)
+					float lo = 3.402823466e+38f, hi = 0.f;
+					for (size_t q_ = 0; q_ < n; ++q_) {
+						if (!(M.d[q_] > 0.f)) { M.d[q_] = 0.f; continue; }
+						lo = std::min(lo, M.d[q_]); hi = std::max(hi, M.d[q_]);
+						float* q = &M.n[3 * q_];
+						const float len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+						if (len > 0.f) { q[0] /= len; q[1] /= len; q[2] /= len; }
+					}
+					if (!(hi > 0.f)) { M.failed = 3; continue; }
+					im.dMin = lo * 0.9f; im.dMax = hi * 1.1f;
 				}
-				if (!(hi > 0.f)) { failed[k - c0] = 3; continue; }
-				im.dMin = lo * 0.9f; im.dMax = hi * 1.1f;
-			}
-			if (o.restoreHypothesis) { // restore/libs/MVS/SceneDensify.cpp:508-532: the previous level's maps, resized, feed the extra hypothesis
-				char nm[64];
-				snprintf(nm, sizeof nm, "/depth%04u.dmap", id);
-				int pw = 0, ph = 0;
-				std::vector<float> pd, pn;
-				if (!load_dmap(o.workdir + nm, pw, ph, pd, pn)) { failed[k - c0] = 2; continue; }
-				resize_cubic(pd, pw, ph, 1, hdAll[k - c0], im.w, im.h);
-				resize_cubic(pn, pw, ph, 3, hnAll[k - c0], im.w, im.h);
-				for (size_t q_ = 0; q_ < n; ++q_) {
-					float& hd = hdAll[k - c0][q_];
-					float* q = &hnAll[k - c0][3 * q_];
-					const float len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
-					if (!(hd > 0.f) || !(len > 0.f)) { hd = 0.f; continue; } // no estimate at the coarser level: no extra hypothesis here
-					q[0] /= len; q[1] /= len; q[2] /= len;
+				if (o.restoreHypothesis && !M.failed) {
+					DmapFile pm;
+					if (!previous_maps(im.id, pm) || pm.w > im.w || pm.h > im.h) { M.failed = 2; continue; }
+					M.hd.resize(n); M.hn.resize(3 * n);
+					// cv::resize(..., INTER_AREA) to the current size (restore/libs/MVS/SceneDensify.cpp:523-524)
+					if (hcmvs_resize_area_up(pm.d.data(), pm.w, pm.h, 1, M.hd.data(), im.w, im.h) != HCMVS_OK ||
+					    hcmvs_resize_area_up(pm.n.data(), pm.w, pm.h, 3, M.hn.data(), im.w, im.h) != HCMVS_OK) { M.failed = 2; continue; }
+					// ... and the depth range takes the enlarged map in, every pixel of it (restore/libs/MVS/SceneDensify.cpp:526-532).  The
+					// border rows and columns of an estimated map hold no depth, so the lower bound becomes 0 there as it does in the
+					// reference; where the coarser level has no estimate there is no extra hypothesis
+					float lo = im.dMin, hi = im.dMax;
+					for (size_t q_ = 0; q_ < n; ++q_) {
+						float& hd = M.hd[q_];
+						lo = lo > hd ? hd : lo; hi = hi > hd ? hi : hd;
+						float* q = &M.hn[3 * q_];
+						const float len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+						if (!(hd > 0.f) || !(len > 0.f)) { hd = 0.f; continue; }
+						q[0] /= len; q[1] /= len; q[2] /= len; // the mix of two unit normals is shorter than 1
+					}
+					im.dMin = std::max(lo, 0.f); im.dMax = hi;
 				}
 			}
-		}
-		for (size_t k = c0; k < c1; ++k) {
-			ImageData& im = images[todo[k]];
-			if (failed[k - c0] == 2) { fprintf(stderr, "error: can not read the previous level's '%s/depth%04u.dmap'\n", o.workdir.c_str(), im.id); return EXIT_FAILURE; }
-			if (failed[k - c0] == 3) { fprintf(stderr, "error: '%s/depth%04u.dmap' holds no valid depth\n", o.workdir.c_str(), im.id); return EXIT_FAILURE; }
-			if (failed[k - c0]) { fprintf(stderr, "error: initialisation of image %u failed (%s)\n", im.id, hcmvs_last_error(ctx)); return EXIT_FAILURE; }
-			const size_t n = (size_t)im.w * im.h;
-			HIPOK(hipMalloc(&im.dDepth, n * 4)); HIPOK(hipMalloc(&im.dNormal, n * 12)); HIPOK(hipMalloc(&im.dConf, n * 4));
-			HIPOK(hipMemcpy(im.dDepth, dAll[k - c0].data(), n * 4, hipMemcpyHostToDevice));
-			HIPOK(hipMemcpy(im.dNormal, nAll[k - c0].data(), n * 12, hipMemcpyHostToDevice));
-			HIPOK(hipMemset(im.dConf, 0, n * 4));
-			if (o.restoreHypothesis) {
-				HIPOK(hipMalloc(&im.dHintDepth, n * 4)); HIPOK(hipMalloc(&im.dHintNormal, n * 12));
-				HIPOK(hipMemcpy(im.dHintDepth, hdAll[k - c0].data(), n * 4, hipMemcpyHostToDevice));
-				HIPOK(hipMemcpy(im.dHintNormal, hnAll[k - c0].data(), n * 12, hipMemcpyHostToDevice));
+			Prepared res;
+			for (size_t k = 0; k < ids.size() && !res.failed; ++k) if (maps[k].failed) { res.failed = maps[k].failed; res.failedId = ids[k]; }
+			for (size_t k = 0; k < ids.size() && !res.failed; ++k) {
+				ImageData& im = images[ids[k]];
+				const size_t n = (size_t)im.w * im.h;
+				bool ok = hipMalloc(&im.dDepth, n * 4) == hipSuccess && hipMalloc(&im.dNormal, n * 12) == hipSuccess && hipMalloc(&im.dConf, n * 4) == hipSuccess &&
+				          hipMemcpy(im.dDepth, maps[k].d.data(), n * 4, hipMemcpyHostToDevice) == hipSuccess &&
+				          hipMemcpy(im.dNormal, maps[k].n.data(), n * 12, hipMemcpyHostToDevice) == hipSuccess && hipMemset(im.dConf, 0, n * 4) == hipSuccess;
+				if (ok && o.restoreHypothesis)
+					ok = hipMalloc(&im.dHintDepth, n * 4) == hipSuccess && hipMalloc(&im.dHintNormal, n * 12) == hipSuccess &&
+					     hipMemcpy(im.dHintDepth, maps[k].hd.data(), n * 4, hipMemcpyHostToDevice) == hipSuccess &&
+					     hipMemcpy(im.dHintNormal, maps[k].hn.data(), n * 12, hipMemcpyHostToDevice) == hipSuccess;
+				if (!ok) { res.failed = 4; res.failedId = ids[k]; }
 			}
+			res.ready = true;
+			{
+				std::lock_guard<std::mutex> g(prepMu);
+				prepared[b] = res;
+			}
+			prepCv.notify_all();
+			if (res.failed) return;
 		}
-	}
+	};
+	std::thread loaderThread(loader);
+	struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } loaderJoin{loaderThread};
+
+	// ---- the saver: copies + files of the final maps, behind the estimation ----
+	Saver sv;
+	auto save_files = [&](const SaveJob& j) -> bool {
+		const ImageData& im = images[j.id];
+		// depth%04u.dmap: the complete DepthData (what the fusion stage of the reference loads, SceneDensify.cpp:3292); depthmap/ +
+		// normalmap/: the hand-off pair the next stage of run.sh picks up (DepthMap.h:76-80, SceneDensify.cpp:3984-3988; raw 'DR'
+		// content instead of the reference's boost archive)
+		return save_dmap(map_path(o.workdir, "/depth%04u.dmap", j.id), im, j.d.data(), j.n.data(), j.c.data()) &&
+		       save_dmap(map_path(o.workdir, "/depthmap/depth%04u.dmap", j.id), im, j.d.data(), nullptr, nullptr) &&
+		       save_dmap(map_path(o.workdir, "/normalmap/normal%04u.dmap", j.id), im, nullptr, j.n.data(), nullptr);
+	};
+	auto copier = [&]() {
+		hipStream_t cs = nullptr;
+		if (hipSetDevice(o.device) != hipSuccess || hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) {
+			std::lock_guard<std::mutex> g(sv.mu); sv.error = "no copy stream"; sv.cv.notify_all(); return;
+		}
+		for (;;) {
+			uint32_t id;
+			{
+				std::unique_lock<std::mutex> g(sv.mu);
+				sv.cv.wait(g, [&] { return !sv.toCopy.empty() || sv.closing || !sv.error.empty(); });
+				if (!sv.error.empty() || (sv.toCopy.empty() && sv.closing)) break;
+				id = sv.toCopy.front(); sv.toCopy.pop_front();
+				const size_t need = (size_t)images[id].w * images[id].h * 20;
+				sv.cv.wait(g, [&] { return sv.bytesQueued + need <= Saver::kMaxQueuedBytes || sv.toWrite.empty() || !sv.error.empty(); });
+				if (!sv.error.empty()) break;
+				sv.bytesQueued += need;
+			}
+			const ImageData& im = images[id];
+			const size_t n = (size_t)im.w * im.h;
+			std::unique_ptr<SaveJob> j(new SaveJob);
+			j->id = id; j->d.resize(n); j->n.resize(3 * n); j->c.resize(n);
+			const bool ok = hipMemcpyAsync(j->d.data(), im.dDepth, n * 4, hipMemcpyDeviceToHost, cs) == hipSuccess &&
+			                hipMemcpyAsync(j->n.data(), im.dNormal, n * 12, hipMemcpyDeviceToHost, cs) == hipSuccess &&
+			                hipMemcpyAsync(j->c.data(), im.dConf, n * 4, hipMemcpyDeviceToHost, cs) == hipSuccess && hipStreamSynchronize(cs) == hipSuccess;
+			std::lock_guard<std::mutex> g(sv.mu);
+			if (!ok) sv.error = "copy of a depth map to the host failed";
+			else { sv.toWrite.push_back(std::move(j)); ++sv.copied; }
+			sv.cv.notify_all();
+		}
+		(void)hipStreamDestroy(cs);
+	};
+	auto writer = [&]() {
+		for (;;) {
+			std::unique_ptr<SaveJob> j;
+			{
+				std::unique_lock<std::mutex> g(sv.mu);
+				sv.cv.wait(g, [&] { return !sv.toWrite.empty() || (sv.closing && sv.copied == sv.submitted) || !sv.error.empty(); });
+				if (sv.toWrite.empty()) break;
+				j = std::move(sv.toWrite.front()); sv.toWrite.pop_front();
+			}
+			const bool ok = save_files(*j);
+			std::lock_guard<std::mutex> g(sv.mu);
+			sv.bytesQueued -= (size_t)images[j->id].w * images[j->id].h * 20;
+			++sv.written;
+			if (!ok && sv.error.empty()) sv.error = "can not write '" + map_path(o.workdir, "/depth%04u.dmap", j->id) + "'";
+			sv.cv.notify_all();
+		}
+	};
+	(void)mkdir((o.workdir + "/depthmap").c_str(), 0777);
+	(void)mkdir((o.workdir + "/normalmap").c_str(), 0777);
+	std::thread copierThread(copier);
+	std::vector<std::thread> writerThreads;
+	for (int k = 0; k < 4; ++k) writerThreads.emplace_back(writer);
+	auto saver_submit = [&](const std::vector<uint32_t>& ids) {
+		std::lock_guard<std::mutex> g(sv.mu);
+		for (uint32_t id : ids) { sv.toCopy.push_back(id); ++sv.submitted; }
+		sv.cv.notify_all();
+	};
+	auto saver_close = [&]() { { std::lock_guard<std::mutex> g(sv.mu); sv.closing = true; } sv.cv.notify_all(); };
+	struct SaverJoin { std::thread& c; std::vector<std::thread>& w; Saver& s; ~SaverJoin() { { std::lock_guard<std::mutex> g(s.mu); s.closing = true; if (s.error.empty() && s.copied != s.submitted) s.error = "aborted"; } s.cv.notify_all(); if (c.joinable()) c.join(); for (auto& t : w) if (t.joinable()) t.join(); } } saverJoin{copierThread, writerThreads, sv};
+
 	const double tInit = now_s();
-	// outer iterations over all images (SceneDensify.cpp:3684), images of equal source count batched per launch
+	double tPostfilter = 0;
+	const bool filterOnLast = o.postFilter && (o.estimationItersExternal - 1 == 1 || o.estimationItersExternal - 1 == 2);
+	// outer iterations over all images (SceneDensify.cpp:3684)
 	for (int it = 0; it < o.estimationItersExternal; ++it) {
 		prm.it_external = it;
-		std::map<size_t, std::vector<uint32_t>> byV;
-		auto viewClass = [](size_t v) { return v <= 1 ? 1 : (v <= 2 ? 2 : (v <= 4 ? 4 : (v <= 8 ? 8 : 16))); }; // one kernel layout per class
-		for (uint32_t id : todo) byV[viewClass(images[id].srcs.size())].push_back(id);
-		for (auto& g : byV)
-			for (size_t b0 = 0; b0 < g.second.size(); b0 += (size_t)o.batch) {
-				std::vector<hcmvs_batch_item> items;
-				for (size_t b = b0; b < std::min(g.second.size(), b0 + (size_t)o.batch); ++b) {
-					ImageData& im = images[g.second[b]];
-					hcmvs_batch_item itx;
-					itx.ref_id = im.id; itx.src_ids = im.srcs.data(); itx.n_src = (int32_t)im.srcs.size(); itx.seed_offset = im.id;
-					itx.d_min = im.dMin; itx.d_max = im.dMax; itx.d_depth = im.dDepth; itx.d_normal = im.dNormal; itx.d_conf = im.dConf;
-					itx.d_hint_depth = im.dHintDepth; itx.d_hint_normal = im.dHintNormal;
-					items.push_back(itx);
-				}
-				CHK(hcmvs_estimate_batch_device(ctx, items.data(), (int32_t)items.size(), &prm));
-				hcmvs_stats st;
-				CHK(hcmvs_get_stats(ctx, &st));
-				if (o.verbosity > 2)
-					for (const auto& itx : items)
-						printf("Depth-map for image %3u estimated using %2d images: %dx%d (outer iteration %d, batch %.0f ms)\n", itx.ref_id,
-						       itx.n_src, images[itx.ref_id].w, images[itx.ref_id].h, it, st.ms_total);
+		const bool last = it == o.estimationItersExternal - 1;
+		for (size_t b = 0; b < batches.size(); ++b) {
+			if (it == 0) { // the batch's initial maps must have arrived
+				std::unique_lock<std::mutex> g(prepMu);
+				prepCv.wait(g, [&] { return prepared[b].ready || !prepError.empty(); });
+				if (!prepError.empty()) { fprintf(stderr, "error: %s\n", prepError.c_str()); return EXIT_FAILURE; }
+				const Prepared& pr = prepared[b];
+				if (pr.failed == 2) { fprintf(stderr, "error: can not read the previous level's maps of image %u ('%s/depthmap/depth%04u.dmap' + normalmap, or '%s/depth%04u.dmap')\n", pr.failedId, o.workdir.c_str(), pr.failedId, o.workdir.c_str(), pr.failedId); return EXIT_FAILURE; }
+				if (pr.failed == 3) { fprintf(stderr, "error: the previous level's depth map of image %u holds no valid depth\n", pr.failedId); return EXIT_FAILURE; }
+				if (pr.failed) { fprintf(stderr, "error: initialisation of image %u failed (%s)\n", pr.failedId, pr.failed == 4 ? "device memory" : hcmvs_last_error(ctx)); return EXIT_FAILURE; }
 			}
-		// SceneDensify.cpp:3939-3958: after outer iterations 1 and 2 every image goes through RemoveSmallSegments (in the fork: a
-		// whole fusion pass over the current maps of all images) and GapInterpolation, one image after the other
-		if (o.postFilter && (it == 1 || it == 2)) {
+			std::vector<hcmvs_batch_item> items;
+			for (uint32_t id : batches[b]) {
+				ImageData& im = images[id];
+				hcmvs_batch_item itx;
+				itx.ref_id = im.id; itx.src_ids = im.srcs.data(); itx.n_src = (int32_t)im.srcs.size(); itx.seed_offset = im.id;
+				itx.d_min = im.dMin; itx.d_max = im.dMax; itx.d_depth = im.dDepth; itx.d_normal = im.dNormal; itx.d_conf = im.dConf;
+				itx.d_hint_depth = im.dHintDepth; itx.d_hint_normal = im.dHintNormal;
+				items.push_back(itx);
+			}
+			CHK(hcmvs_estimate_batch_device(ctx, items.data(), (int32_t)items.size(), &prm));
+			hcmvs_stats st;
+			CHK(hcmvs_get_stats(ctx, &st));
+			if (o.verbosity > 2)
+				for (const auto& itx : items)
+					printf("Depth-map for image %3u estimated using %2d images: %dx%d (outer iteration %d, batch %.0f ms)\n", itx.ref_id,
+					       itx.n_src, images[itx.ref_id].w, images[itx.ref_id].h, it, st.ms_total);
+			if (last && !filterOnLast) saver_submit(batches[b]); // final maps of this batch: off to the host while the next batch runs
+		}
+		// SceneDensify.cpp:3916, 3939-3958: with --n-nOptimize's REMOVE_SPECKLES | FILL_GAPS bits, after outer iterations 1 and 2
+		// every image goes through RemoveSmallSegments (in the fork: a whole fusion pass over the current maps of all images) and
+		// GapInterpolation, one image after the other
+		if (o.postFilter && (it == 1 || it == 2) && !work.empty()) {
 			const double tp = now_s();
 			std::vector<uint32_t> ord(todo);
 			std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return images[a].neighbors.size() > images[b].neighbors.size(); });
@@ -760,35 +999,53 @@ int main(int argc, char** argv) {
 			}
 			CHK(hcmvs_set_fuse_order(ctx, o.fuseOrder));
 			uint64_t filledAll = 0;
-			for (uint32_t id : todo) {
+			for (uint32_t id : work) {
 				uint64_t filled = 0;
-				CHK(hcmvs_postfilter(ctx, id, ord.data(), (int32_t)ord.size(), std::min<int>(o.numberViewsFuse, (int)images.size()), 0.01f, 25.f, o.depthweight,
-				                     o.normalweight, 7, &filled));
+				CHK(hcmvs_postfilter(ctx, id, ord.data(), (int32_t)ord.size(), std::min<int>(o.numberViewsFuse, (int)images.size()), 0.01f, 25.f, 7, &filled));
 				filledAll += filled;
 			}
+			tPostfilter += now_s() - tp;
 			if (o.verbosity > 1) printf("Depth-maps filtered after outer iteration %d: fuse-consistency mask + gap interpolation, %llu pixels filled (%.2f s)\n", it,
 			                            (unsigned long long)filledAll, now_s() - tp);
+			if (last) saver_submit(work);
 		}
 	}
+	loaderThread.join();
 	double pixels = 0;
-	for (uint32_t id : todo) pixels += (double)images[id].w * images[id].h;
+	for (uint32_t id : work) pixels += (double)images[id].w * images[id].h;
 	CHK(hcmvs_synchronize(ctx));
 	const double tEstimated = now_s();
 	if (o.verbosity > 1)
-		printf("Depth-maps estimated: %zu images, %d outer x %d inner sweeps in %.2f s (%.2f Mpix/s per outer iteration); loading %.2f s, view selection + init %.2f s\n",
-		       todo.size(), o.estimationItersExternal, o.estimationIters, tEstimated - tInit,
-		       pixels * o.estimationItersExternal / (tEstimated - tInit) / 1e6, tLoaded - tStart, tInit - tLoaded);
-	// save the depth maps (raw 'DR'), register them for fusion
+		printf("Depth-maps estimated: %zu images (%zu resumed), %d outer x %d inner sweeps in %.2f s (%.2f Mpix/s per outer iteration; post-filters %.2f s of it); "
+		       "loading + view selection %.2f s, set-up %.2f s\n",
+		       work.size(), todo.size() - work.size(), o.estimationItersExternal, o.estimationIters, tEstimated - tInit,
+		       pixels * o.estimationItersExternal / std::max(1e-9, tEstimated - tInit - tPostfilter) / 1e6, tPostfilter, tLoaded - tStart, tInit - tLoaded);
+	// the fusion mutates the depth maps: every final map must be on the host first (the files may still be on their way)
+	saver_close();
+	{
+		std::unique_lock<std::mutex> g(sv.mu);
+		sv.cv.wait(g, [&] { return sv.copied == sv.submitted || !sv.error.empty(); });
+		if (!sv.error.empty()) { fprintf(stderr, "error: %s\n", sv.error.c_str()); return EXIT_FAILURE; }
+	}
+	const double tCopied = now_s();
+	auto wait_files = [&]() -> bool {
+		std::unique_lock<std::mutex> g(sv.mu);
+		sv.cv.wait(g, [&] { return sv.written == sv.submitted || !sv.error.empty(); });
+		if (!sv.error.empty()) { fprintf(stderr, "error: %s\n", sv.error.c_str()); return false; }
+		return true;
+	};
+	if (o.fusionMode == 1 || todo.empty()) {
+		if (!wait_files()) return EXIT_FAILURE;
+		if (o.verbosity > 1) printf("Depth-maps saved (%.2f s after the last estimate)\n", now_s() - tEstimated);
+		for (auto& im : images) for (float* p : {im.dDepth, im.dNormal, im.dConf, im.dHintDepth, im.dHintNormal}) if (p) (void)hipFree(p);
+		hcmvs_destroy(ctx);
+		return EXIT_SUCCESS;
+	}
+	// register the maps for fusion
 	uint64_t capacity = 0;
 	for (uint32_t id : todo) {
 		ImageData& im = images[id];
 		const size_t n = (size_t)im.w * im.h;
-		std::vector<float> d(n), nn(3 * n), c(n);
-		HIPOK(hipMemcpy(d.data(), im.dDepth, n * 4, hipMemcpyDeviceToHost)); HIPOK(hipMemcpy(nn.data(), im.dNormal, n * 12, hipMemcpyDeviceToHost));
-		HIPOK(hipMemcpy(c.data(), im.dConf, n * 4, hipMemcpyDeviceToHost));
-		char nm[64];
-		snprintf(nm, sizeof nm, "/depth%04u.dmap", id);
-		if (!save_dmap(o.workdir + nm, im, d, nn, c)) { fprintf(stderr, "error: can not write '%s%s'\n", o.workdir.c_str(), nm); return EXIT_FAILURE; }
 		CHK(hcmvs_set_depthmap_device(ctx, id, im.dDepth, im.dNormal, im.dConf, im.dMin, im.dMax));
 		std::vector<uint32_t> nb;
 		for (const auto& x : im.neighbors) if (std::find(todo.begin(), todo.end(), x.id) != todo.end()) nb.push_back(x.id);
@@ -796,9 +1053,6 @@ int main(int argc, char** argv) {
 		CHK(hcmvs_set_neighbors(ctx, id, nb.data(), (int32_t)nb.size()));
 		capacity += (uint64_t)(o.numberViewsFuse >= 2 ? n / 2 : n); // a fused point claims at least number-views-fuse pixels
 	}
-	const double tSaved = now_s();
-	if (o.verbosity > 1) printf("Depth-maps saved in %.2f s\n", tSaved - tEstimated);
-	if (o.fusionMode == 1 || todo.empty()) { hcmvs_destroy(ctx); return EXIT_SUCCESS; }
 	// fuse: best connected images first (SceneDensify.cpp:3285-3302)
 	std::vector<uint32_t> order(todo);
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return images[a].neighbors.size() > images[b].neighbors.size(); });
@@ -831,14 +1085,19 @@ int main(int argc, char** argv) {
 	const double tFused = now_s();
 	if (o.verbosity > 1)
 		printf("Depth-maps fused and filtered: %zu depth-maps, %llu depths, %llu points (%d%%) in %.2f s (%.2f Mpoints/s)\n", order.size(),
-		       (unsigned long long)nDepths, (unsigned long long)nPoints, nDepths ? (int)std::lround(100.0 * nPoints / nDepths) : 0, tFused - tSaved,
-		       nPoints / (tFused - tSaved) / 1e6);
+		       (unsigned long long)nDepths, (unsigned long long)nPoints, nDepths ? (int)std::lround(100.0 * nPoints / nDepths) : 0, tFused - tCopied,
+		       nPoints / (tFused - tCopied) / 1e6);
+	// the scene and the point cloud, side by side
 	const std::string base = o.output.substr(0, o.output.rfind('.'));
-	if (!save_mvs(o.output, platforms, mimages, xyz, nrm, bgr, nviews, viewIds, viewWeights) || !save_ply(base + ".ply", xyz, nrm, bgr)) {
-		fprintf(stderr, "error: can not write the output files\n");
-		return EXIT_FAILURE;
+	bool okMvs = false, okPly = false;
+	{
+		std::thread tm([&] { okMvs = save_mvs(o.output, platforms, mimages, xyz, nrm, bgr, nviews, viewIds, viewWeights); });
+		okPly = save_ply(base + ".ply", xyz, nrm, bgr);
+		tm.join();
 	}
-	if (o.verbosity > 1) printf("Scene and point cloud saved in %.2f s\n", now_s() - tFused);
+	if (!okMvs || !okPly) { fprintf(stderr, "error: can not write the output files\n"); return EXIT_FAILURE; }
+	if (!wait_files()) return EXIT_FAILURE;
+	if (o.verbosity > 1) printf("Scene, point cloud and depth-maps saved (%.2f s after the fusion); total %.2f s\n", now_s() - tFused, now_s() - tStart);
 	for (auto& im : images) for (float* p : {im.dDepth, im.dNormal, im.dConf, im.dHintDepth, im.dHintNormal}) if (p) (void)hipFree(p);
 	hcmvs_destroy(ctx);
 	return EXIT_SUCCESS;

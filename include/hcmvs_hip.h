@@ -166,6 +166,14 @@ int hcmvs_triangulate_points(int32_t width, int32_t height, const double K[9], c
                              const float* points_xyz, int32_t n_points, float avg_depth, int32_t add_corners, float* depth,
                              float* normal, float* d_min, float* d_max);
 
+/* cv::resize(src, dst, Size(dst_w, dst_h), 0, 0, INTER_AREA) for an ENLARGING resize of an f32 image with `channels` interleaved
+ * channels -- how the fork's `restore` variant brings the previous pyramid level's depth and normal maps to the current size before
+ * offering them as the extra hypothesis (restore/libs/MVS/SceneDensify.cpp:523-524; d_hint_depth / d_hint_normal above).  OpenCV's
+ * INTER_AREA enlarges with the bilinear kernel and "area mode" coefficients (a destination pixel inside one source pixel copies it,
+ * one that straddles two mixes them by the overlap).  Host buffers, host code, no context (once per image and level).  dst_w >= src_w
+ * and dst_h >= src_h, else HCMVS_ERR_INVALID. */
+int hcmvs_resize_area_up(const float* src, int32_t src_w, int32_t src_h, int32_t channels, float* dst, int32_t dst_w, int32_t dst_h);
+
 /* ---- filter and fuse: work on the estimated maps registered per view ------------------------------------ */
 
 /* register the maps of view `id` (host buffers are copied).  normal may be NULL.  d_min/d_max: the depth range
@@ -215,10 +223,12 @@ int hcmvs_fuse(hcmvs_ctx* ctx, const uint32_t* order, int32_t n_order, int32_t n
  *   columns, whose ends agree within 2.5 x depth_diff_threshold -- or longer ones whose ends agree or whose gradient-map values
  *   differ by at most 10 % -- are filled by linear interpolation of depth and normal direction; finally the maps take the
  *   fused-and-filled values where those are valid.
- * The reference's third, per-pixel pass (SceneDensify.cpp:2717-2983) reads uninitialised variables and is not reproduced.
+ * RemoveSmallSegments compares with the plain thresholds (SceneDensify.cpp:2083, 2177): --depthweight / --normalweight only scale the
+ * thresholds of FuseDepthMaps (SceneDensify.cpp:3310, 3400), so this entry takes no weights.
+ * The reference's third, per-pixel pass (SceneDensify.cpp:2790-2983) reads uninitialised variables and is not reproduced.
  * n_filled: pixels the two interpolation passes wrote. */
 int hcmvs_postfilter(hcmvs_ctx* ctx, uint32_t id, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
-                     float normal_diff_deg, float depthweight, float normalweight, int32_t gap_size, uint64_t* n_filled);
+                     float normal_diff_deg, int32_t gap_size, uint64_t* n_filled);
 
 /* The fused cloud with everything PointCloud holds (PointCloud.h: points, pointViews, pointWeights, colors, normals).
  * Host buffers owned by the caller; any optional pointer may be NULL.  The view lists are stored back to back (CSR): point p's

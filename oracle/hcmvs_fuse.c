@@ -395,7 +395,7 @@ static uint64_t gap_line(float* dF, float* nF, float* conf, const uint8_t* gra, 
 }
 
 int hcor_postfilter(hcor_depthmap* maps, int n_maps, uint32_t id, const uint8_t* gra, const uint32_t* order, int n_order, int nMinViewsFuse,
-                    float fDepthDiffThreshold, float fNormalDiffDeg, float depthweight, float normalweight, int gap, int mode, uint64_t* n_filled) {
+                    float fDepthDiffThreshold, float fNormalDiffDeg, int gap, int mode, uint64_t* n_filled) {
 	if ((int)id >= n_maps || !maps[id].depth || !maps[id].normal) return 1;
 	hcor_depthmap* A = &maps[id];
 	const int W = A->width, H = A->height;
@@ -407,7 +407,7 @@ int hcor_postfilter(hcor_depthmap* maps, int n_maps, uint32_t id, const uint8_t*
 	memset(&cl, 0, sizeof cl);
 	cl.claim_image = id;
 	cl.claim_mask = (uint8_t*)calloc(area, 1);
-	hcor_fuse_depthmaps(maps, n_maps, order, n_order, nMinViewsFuse, fDepthDiffThreshold, fNormalDiffDeg, depthweight, normalweight, &cl);
+	hcor_fuse_depthmaps(maps, n_maps, order, n_order, nMinViewsFuse, fDepthDiffThreshold, fNormalDiffDeg, 1.f, 1.f, &cl); /* SD.cpp:2083, 2177: unweighted */
 	float* dF = (float*)malloc(area * sizeof(float));
 	float* nF = (float*)malloc(area * 3 * sizeof(float));
 	for (size_t i = 0; i < area; ++i) {

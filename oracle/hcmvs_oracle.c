@@ -260,6 +260,47 @@ static void cubic_w(float x, float* c) {
 	c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
 	c[3] = 1.f - c[0] - c[1] - c[2];
 }
+/* cv::resize(src, dst, Size(dw, dh), 0, 0, INTER_AREA) when the destination is LARGER than the source, as the fork's `restore`
+ * variant up-samples the previous level's depth and normal maps (restore/libs/MVS/SceneDensify.cpp:523-524).  OpenCV 4.2
+ * (imgproc/src/resize.cpp, cv::resize): INTER_AREA with scale < 1 runs the bilinear kernel with "area mode" coefficients --
+ *   sx = floor(dx * scale), fx = (dx + 1) - (sx + 1) / scale, fx = fx <= 0 ? 0 : fx - floor(fx)
+ * (a destination pixel that lies inside one source pixel copies it; one that straddles two mixes them by the overlap), the last
+ * source column / row has no right / lower partner; horizontal pass first (HResizeLinear: S[sx] * (1 - fx) + S[sx + 1] * fx), then
+ * the vertical one (VResizeLinear: R0 * (1 - fy) + R1 * fy).  Multiplies and adds are not fused (the C source's expression).
+ * ch interleaved channels.  OpenCV itself is absent: restated from its published source (parity unpinned). */
+static void area_up_coef(int d, int ssize, int dsize, int columns, int* s0, float* f) {
+	const double scale = (double)ssize / (double)dsize, inv_scale = (double)dsize / (double)ssize;
+	int sx = (int)floor(d * scale);
+	float fx = (float)((d + 1) - (sx + 1) * inv_scale);
+	fx = fx <= 0 ? 0.f : fx - floorf(fx);
+	if (columns) { /* the x table resets the weight at the borders; the y table does not, its rows are clipped where they are used */
+		if (sx < 0) { fx = 0; sx = 0; }
+		if (sx >= ssize - 1) { fx = 0; sx = ssize - 1; }
+	}
+	*s0 = sx; *f = fx;
+}
+void hcor_resize_area_up(const float* src, int sw, int sh, int ch, float* dst, int dw, int dh) {
+	for (int y = 0; y < dh; ++y) {
+		int sy; float fy;
+		area_up_coef(y, sh, dh, 0, &sy, &fy);
+		const int sy1 = sy + 1 < sh ? (sy + 1 > 0 ? sy + 1 : 0) : sh - 1;
+		sy = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+		const float b0 = 1.f - fy, b1 = fy;
+		for (int x = 0; x < dw; ++x) {
+			int sx; float fx;
+			area_up_coef(x, sw, dw, 1, &sx, &fx);
+			const int last = sx + 1 >= sw; /* dx >= xmax: the left sample alone, times ONE */
+			const float a0 = 1.f - fx, a1 = fx;
+			for (int c = 0; c < ch; ++c) {
+				const float* r0 = src + ((size_t)sy * sw) * ch + c;
+				const float* r1 = src + ((size_t)sy1 * sw) * ch + c;
+				const float h0 = last ? r0[(size_t)sx * ch] : r0[(size_t)sx * ch] * a0 + r0[(size_t)(sx + 1) * ch] * a1;
+				const float h1 = last ? r1[(size_t)sx * ch] : r1[(size_t)sx * ch] * a0 + r1[(size_t)(sx + 1) * ch] * a1;
+				dst[((size_t)y * dw + x) * ch + c] = h0 * b0 + h1 * b1;
+			}
+		}
+	}
+}
 void hcor_resize_gray(const float* src, int sw, int sh, float scale, float* dst, int dw, int dh) {
 	const double sc = 1.0 / (double)scale;
 	if (scale > 1.f) {

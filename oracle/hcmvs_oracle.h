@@ -81,6 +81,10 @@ void hcor_default_params(hcor_params* p);
  * on an f32 image, restated from OpenCV 4.2's published algorithm (OpenCV is absent: parity unpinned) */
 void hcor_resize_size(int w, int h, float scale, int* dw, int* dh);
 void hcor_resize_gray(const float* src, int sw, int sh, float scale, float* dst, int dw, int dh);
+/* cv::resize(src, dst, Size(dw, dh), 0, 0, INTER_AREA) for dw >= sw, dh >= sh (INTER_AREA enlarging = bilinear kernel with area-mode
+ * coefficients), ch interleaved f32 channels: the `restore` variant's up-sampling of the previous level's maps
+ * (restore/libs/MVS/SceneDensify.cpp:523-524).  Restated from OpenCV 4.2's published source (parity unpinned). */
+void hcor_resize_area_up(const float* src, int sw, int sh, int ch, float* dst, int dw, int dh);
 
 /* ---- small pieces, exposed for known-answer tests ------------------------------------------- */
 
@@ -213,10 +217,10 @@ int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, 
  * `(u-count) == 0` can not be true inside the loops).  NOT restated: the third, per-pixel pass (SD.cpp:2717-2983): it reads
  * variables that are never initialised (dir1, dirDiffsum, x1_demin ... at SD.cpp:2745-2760, 2782-2791) and divides by counters
  * that may be zero, so it has no defined result to match.  gra: the image's u8 gradient map.  mode: HCOR_ARITH_*.
- * maps[id]'s depth / normal / conf are updated in place; other images' depths may be zeroed by the fusion. */
+ * maps[id]'s depth / normal / conf are updated in place; other images' depths may be zeroed by the fusion.  The fusion inside
+ * RemoveSmallSegments uses the plain thresholds (SD.cpp:2083, 2177), not the --depthweight / --normalweight ones of FuseDepthMaps. */
 int hcor_postfilter(hcor_depthmap* maps, int n_maps, uint32_t id, const uint8_t* gra, const uint32_t* order, int n_order, int n_min_views_fuse,
-                    float depth_diff_threshold, float normal_diff_deg, float depthweight, float normalweight, int gap_size, int mode,
-                    uint64_t* n_filled);
+                    float depth_diff_threshold, float normal_diff_deg, int gap_size, int mode, uint64_t* n_filled);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,7 @@ def lib():
         L.hcor_median3.argtypes = [fp, C.c_int, C.c_int, fp]
         L.hcor_resize_size.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.hcor_resize_gray.argtypes = [fp, C.c_int, C.c_int, C.c_float, fp, C.c_int, C.c_int]
+        L.hcor_resize_area_up.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int]
         L.hcor_splat_init.argtypes = [C.POINTER(View), fp, C.c_int, fp, fp, fp, fp]
         L.hcor_fill_patch.argtypes = [C.POINTER(View), u8p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, fp, fp, fp, fp]
         L.hcor_fill_patch.restype = C.c_int
@@ -105,7 +106,7 @@ def lib():
         L.hcor_estimate_point_colors.argtypes = [C.POINTER(DepthMap), C.c_int, C.c_uint64, fp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p]
         L.hcor_estimate_point_colors.restype = None
         L.hcor_postfilter.argtypes = [C.POINTER(DepthMap), C.c_int, C.c_uint32, u8p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_float, C.c_float,
-                                      C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+                                      C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.hcor_postfilter.restype = C.c_int
     return _lib
 
@@ -173,6 +174,15 @@ def resize_gray(gray, scale):
     L.hcor_resize_size(w, h, C.c_float(scale), C.byref(dw), C.byref(dh))
     out = np.empty((dh.value, dw.value), np.float32)
     L.hcor_resize_gray(fptr(g), w, h, C.c_float(scale), fptr(out), dw.value, dh.value)
+    return out
+
+
+def resize_area_up(src, dw, dh):
+    """cv::resize INTER_AREA, enlarging, on an f32 map (h, w) or (h, w, ch)"""
+    s = np.ascontiguousarray(src, np.float32)
+    ch = 1 if s.ndim == 2 else s.shape[2]
+    out = np.empty((dh, dw) if s.ndim == 2 else (dh, dw, ch), np.float32)
+    lib().hcor_resize_area_up(fptr(s), s.shape[1], s.shape[0], ch, fptr(out), dw, dh)
     return out
 
 
@@ -255,7 +265,7 @@ def estimate_point_colors(maps, xyz, n_views, view_ids):
     return out
 
 
-def postfilter(maps, vid, gra, order, mode=ARITH_DEVICE, n_min_views_fuse=2, thr=0.01, normal_deg=25.0, depthweight=1.0, normalweight=1.0, gap=7):
+def postfilter(maps, vid, gra, order, mode=ARITH_DEVICE, n_min_views_fuse=2, thr=0.01, normal_deg=25.0, gap=7):
     """RemoveSmallSegments (fork) + GapInterpolation on image vid; maps are copied.  Returns (maps' depth copies, normal, conf of vid, n_filled)"""
     maps = [dict(m) for m in maps]
     maps[vid]["normal"] = np.ascontiguousarray(maps[vid]["normal"], np.float32).copy()
@@ -265,7 +275,7 @@ def postfilter(maps, vid, gra, order, mode=ARITH_DEVICE, n_min_views_fuse=2, thr
     ids = (C.c_uint32 * len(order))(*order)
     nf = C.c_uint64()
     g = np.ascontiguousarray(gra, np.uint8)
-    rc = lib().hcor_postfilter(arr, len(maps), vid, u8ptr(g), ids, len(order), n_min_views_fuse, thr, normal_deg, depthweight, normalweight, gap, mode,
+    rc = lib().hcor_postfilter(arr, len(maps), vid, u8ptr(g), ids, len(order), n_min_views_fuse, thr, normal_deg, gap, mode,
                                C.byref(nf))
     assert rc == 0
     return depths, maps[vid]["normal"], maps[vid]["conf"], nf.value

@@ -214,3 +214,27 @@ def test_postfilter_bit_exact(ctx, vid):
     gt = maps[vid]["gt"]
     newly = (d > 0) & (maps[vid]["depth"] == 0)
     assert (np.abs(d - gt)[newly] / gt[newly] < 0.02).mean() > 0.8   # and the filled values lie on the surface
+
+
+@pytest.mark.parametrize("pairs", [[(10, 11), (20, 22), (90, 99)], [(20, 21)]])
+def test_postfilter_gradient_ratio_literal(ctx, pairs):
+    """GapInterpolation's long-gap rule compares the float ratio of the gradient-map values at the gap's ends with the DOUBLE
+    literal 0.1 (SceneDensify.cpp:2383-2390 rows, :2713-2720 columns): pairs whose ratio rounds to 0.1f -- (10, 11), (20, 22),
+    (90, 99) -- stay open, (20, 21) fills.  The device computes the gradient map itself from the uploaded image."""
+    from test_oracle_postfilter import gap_scene
+    maps, rows, (x0, x1), img = gap_scene(pairs)
+    for i, m in enumerate(maps):
+        g8 = img if i == 0 else np.full_like(img, 50)
+        m["gray"] = g8.astype(np.float32) / 255.0
+        m["bgr"] = np.repeat(g8[..., None], 3, -1).copy()
+        m["conf"] = np.where(m["depth"] > 0, 0.4, 0).astype(np.float32)
+    upload(ctx, maps)
+    gra = ctx.gradient_map(0)
+    for y, (g0, g1) in zip(rows, pairs):
+        assert (int(gra[y, x0]), int(gra[y, x1])) == (g0, g1)
+    dd, nd, cd, filled = O.postfilter(maps, 0, gra, [0, 1], mode=O.ARITH_DEVICE)
+    assert ctx.postfilter(0, [0, 1]) == filled
+    d, n, c = ctx.get_depthmap(0, with_normal=True)
+    assert np.array_equal(d, dd[0]) and np.array_equal(n, nd) and np.array_equal(c, cd)
+    for y in rows:
+        assert ((d[y, x0 + 1:x1] > 0).all() if pairs == [(20, 21)] else (d[y, x0 + 1:x1] == 0).all())

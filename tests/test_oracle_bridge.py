@@ -6,8 +6,8 @@ operation by operation (libm, sequential tap sums, incremental warp, double homo
 DepthMap.h:565-574).  Two different floating-point evaluations of the same algorithm cannot agree bit for bit -- PatchMatch
 amplifies an ulp into a different accepted hypothesis -- so the comparison is in the terms the north star states: per-pixel
 depth L1, valid-pixel count, fused point count (and the reference authors' own 1 % criterion, CompareDepthMaps,
-DepthMap.cpp:2958).  Six scenes: 1..8 source views, half windows 5/6/7/10, outer iterations 0..2 with the cross pattern,
-photometric_flow on.  The bars below are the tolerance BASELINE.md section 3 claims."""
+DepthMap.cpp:2958).  Nine scenes: 1..12 source views (incl. 7, 10 = the authors' --number-views, 12), half windows 5/6/7/10, outer iterations 0..3
+with the cross pattern, photometric_flow on.  The bars below are the tolerance BASELINE.md section 3 claims."""
 import ctypes as C
 import importlib
 
@@ -64,6 +64,13 @@ SCENES = [
     dict(name="V1 a6", n_src=1, seed=7, outer=1, kw=dict(adapthalfwin=6, n_estimation_iters=4)),
     dict(name="V5 a10 (11x11)", n_src=5, seed=8, outer=1, kw=dict(adapthalfwin=10, n_estimation_iters=3)),
     dict(name="V2 a6 pf0.26 outer 0-1", n_src=2, seed=9, outer=2, kw=dict(adapthalfwin=6, n_estimation_iters=3, photometric_flow=0.26, propagate_halfwin=5, propagate_step=4)),
+    # the lane paths added in round 2 (two sets of eight view groups for 9..16 views; pair packing in partly filled sets; the plain
+    # partial set of 7 views).  V10 = the authors' own settings (data/frame_main/resize3/run.py:45-76: --number-views 10, 4 outer x 3
+    # inner sweeps, --n-adapthalfwin 7, --n-propagatehalfwin 5, --n-propagatestep 4, --n-photometric_flow 0.26)
+    dict(name="V10 a7 pf0.26 outer 0-3 cross (authors)", n_src=10, seed=10, outer=4,
+         kw=dict(adapthalfwin=7, n_estimation_iters=3, photometric_flow=0.26, propagate_halfwin=5, propagate_step=4)),
+    dict(name="V7 a6", n_src=7, seed=11, outer=1, kw=dict(adapthalfwin=6, n_estimation_iters=4)),
+    dict(name="V12 a5 outer 0-1", n_src=12, seed=13, outer=2, kw=dict(adapthalfwin=5, n_estimation_iters=3, propagate_halfwin=5, propagate_step=4)),
 ]
 
 

@@ -77,3 +77,45 @@ def test_fusion_side_effects_and_modes_agree():
         assert np.array_equal(dr[i], f["depths"][i])
     assert (dr[1] > 0).sum() > (f["depths"][1] > 0).sum()          # holes of image 1 were filled
     assert np.abs(dr[1] - dd[1]).max() < 1e-5 and np.abs(nr - nd).max() < 1e-5 and np.array_equal(cr, cd)
+
+
+def gap_scene(pairs):
+    """Two views of a plane with a depth step (10 -> 12 at column 32, seen alike by both views, so both sides fuse) and, in
+    view 0, a hole 20 pixels wide across the step that is open to the lower border (columns have no second end): too long for
+    nIpolGapSize = 7 and with ends 20 % apart, so only the gradient-map rule `texture_ratio <= 0.1` (SD.cpp:2383-2390, columns
+    :2713-2720) can fill a row of it.  Returns (maps, the rows whose hole ends carry the gradient values `pairs`, the end
+    columns, the 8-bit image whose gradient map has exactly those values there and 0 at the ends of every other row)."""
+    maps, w, h = _plane_maps()
+    for mm in maps:
+        mm["depth"][:, 32:] = 12.0
+    rows = [8 + 6 * k for k in range(len(pairs))]
+    x0, x1 = 21, 42
+    maps[0]["depth"][6:, x0 + 1:x1] = 0
+    img = np.full((h, w), 50, np.uint8)
+    for y, (g0, g1) in zip(rows, pairs):
+        # Sobel x on rows y-1..y+1 that are alike: gx = 4 (v[x+1] - v[x-1]), gy = 0, gra = |gx| / 2; an extra +1 at (x+1, y) alone
+        # adds 2 to gx without touching gy, which makes the odd values
+        for x, g in ((x0, g0), (x1, g1)):
+            img[y - 1:y + 2, x + 1:] += g // 2
+            if g % 2:
+                img[y, x + 1] += 1
+    return maps, rows, (x0, x1), img
+
+
+def test_gradient_ratio_is_compared_with_the_double_literal():
+    """SD.cpp:2390 / :2720 test the FLOAT ratio against the DOUBLE literal 0.1: a ratio that rounds to 0.1f (gradient pairs
+    (10, 11), (20, 22), (90, 99)) is > 0.1 and must NOT fill; (20, 21) fills."""
+    pairs = [(10, 11), (20, 22), (90, 99)]
+    for pr, filled in ((pairs, False), ([(20, 21)], True)):
+        maps, rows, (x0, x1), img = gap_scene(pr)
+        gra = O.gradient_map(img.astype(np.float32) / 255.0)     # the GPU test uploads img; the device computes this map itself
+        for y, (g0, g1) in zip(rows, pr):
+            assert (int(gra[y, x0]), int(gra[y, x1])) == (g0, g1)
+            assert (np.float32(g1 - g0) / np.float32(g0) == np.float32(0.1)) == (not filled)
+        for mode in (O.ARITH_REFERENCE, O.ARITH_DEVICE):
+            depths, _, _, _ = O.postfilter(maps, 0, gra, [0, 1], mode=mode)
+            for y in rows:
+                if filled:
+                    assert (depths[0][y, x0 + 1:x1] > 0).all()
+                else:
+                    assert (depths[0][y, x0 + 1:x1] == 0).all(), "a ratio of exactly 0.1f must not fill (mode %d, row %d)" % (mode, y)

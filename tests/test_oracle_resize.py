@@ -49,3 +49,35 @@ def test_cubic_reproduces_linear_ramps_and_interpolates():
     assert out[9, 7] == pytest.approx(0.87890625 * 0.26171875, rel=1e-6)   # destination 7: fx = 3.25 -> taps 2..5, the impulse is tap 2 (w2)
     assert out[9, 5] == pytest.approx(0.87890625 * -0.03515625, rel=1e-5)  # destination 5: fx = 2.25 -> taps 1..4, the impulse is tap 3 (w3)
     assert O.resize_gray(np.full((20, 30), 0.6, np.float32), 1.7).shape == (34, 51)
+
+
+def test_area_enlarging_is_bilinear_with_overlap_weights():
+    """cv::resize INTER_AREA with a destination larger than the source (restore/libs/MVS/SceneDensify.cpp:523-524, the `restore`
+    variant's up-sampling of the previous level's maps): a destination pixel that lies inside one source pixel copies it, one that
+    straddles two mixes them by the overlap (OpenCV 4.2 resize.cpp, area mode of the bilinear kernel)."""
+    src = np.array([[0, 10, 20, 30]], np.float32).repeat(3, 0)
+    out = O.resize_area_up(src, 8, 6)                       # exact factor 2: every destination pixel lies inside one source pixel
+    assert np.array_equal(out, np.repeat(np.repeat(src, 2, 0), 2, 1))
+    out = O.resize_area_up(src, 6, 3)                       # factor 1.5: destination x covers source [x / 1.5, (x + 1) / 1.5)
+    #   x = 1 covers [0.667, 1.333): one third in pixel 0, two thirds... OpenCV's weight of the RIGHT pixel is (x + 1) - (sx + 1) * 1.5 = 0.5
+    assert np.allclose(out[0], [0, 5, 10, 20, 25, 30], atol=1e-5)
+    rng = np.random.RandomState(3)
+    m = rng.uniform(1, 9, (13, 17, 3)).astype(np.float32)
+    up = O.resize_area_up(m, 40, 31)
+    assert up.shape == (31, 40, 3) and up.min() >= m.min() - 1e-5 and up.max() <= m.max() + 1e-5      # a convex mix of two neighbours
+    assert np.array_equal(up[0, 0], m[0, 0]) and np.array_equal(up[-1, -1], m[-1, -1])
+
+
+def test_c_abi_host_helper_equals_the_restatement():
+    """hcmvs_resize_area_up (host helper of the C-ABI, table-driven like OpenCV) against the oracle's per-pixel restatement: bit
+    for bit, one and three channels, integer and fractional factors, down to a 1-pixel source"""
+    import importlib
+    binding = importlib.import_module("hc-mvs_amd.binding")
+    rng = np.random.RandomState(5)
+    for (sh, sw, dh, dw) in [(48, 64, 96, 128), (45, 60, 90, 121), (30, 40, 77, 101), (1, 1, 5, 7), (16, 16, 16, 16), (7, 5, 8, 5)]:
+        for ch in (1, 3):
+            m = rng.uniform(0, 12, (sh, sw) if ch == 1 else (sh, sw, ch)).astype(np.float32)
+            m[rng.uniform(size=m.shape[:2]) < 0.1] = 0      # holes, as a depth map has them
+            assert np.array_equal(binding.resize_area_up(m, dw, dh), O.resize_area_up(m, dw, dh)), (sh, sw, dh, dw, ch)
+    with pytest.raises(binding.HcmvsError):
+        binding.resize_area_up(np.zeros((8, 8), np.float32), 4, 8)   # shrinking is not this entry's job

@@ -24,7 +24,7 @@ for b in range(B):
     keep.append((g, init, work))
 p = binding.default_params(adapthalfwin=6, n_estimation_iters=I)
 L = binding.lib(); L.hcmvs_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
-out = (C.c_uint64 * 16)()
+out = (C.c_uint64 * 32)()
 for rep in range(2):
     for g, init, work in keep: work.copy_(init)
     torch.cuda.synchronize()
@@ -40,3 +40,9 @@ npx = (W - 14) * (H - 14) * I * B
 print("B", B, "ms_sweep_avg %.2f" % st.ms_sweep_avg, "s_memtime ticks/pixel (wave0) %.0f" % (tot / npx))
 for i in range(14):
     print("%-32s %6.1f%%  %8.0f ticks/px" % (names[i], 100.0 * out[i] / tot, out[i] / npx))
+
+# executions of the blocks of the pixel state machine (BLOCK() in pm_kernels.hip), per pixel-sweep of wave 0's rows
+cn = ["pick", "gen_prop", "gen_rand", "gen_refine", "chunk", "score_chunk", "acc_prop", "acc_prop_cand", "acc_rand", "acc_refine", "smooth_chunks"]
+print("blocks per pixel-sweep:", ", ".join("%s=%.4f" % (n, out[16 + i] / npx) for i, n in enumerate(cn)))
+print("evals per pixel-sweep: sequential %.4f issued %.4f" % (st.evals / (npx + (W - 14) * (H - 14) * B) * (1 + 1.0 / I), st.evals_issued / npx))
+print("stats: evals %d issued %d (incl. the init-score pass: %d)" % (st.evals, st.evals_issued, (W - 14) * (H - 14) * B))
