@@ -58,7 +58,7 @@ SYMBOLS = ["hcmvs_default_params", "hcmvs_create", "hcmvs_destroy", "hcmvs_last_
            "hcmvs_get_gradient_map", "hcmvs_estimate", "hcmvs_estimate_device", "hcmvs_estimate_batch_device", "hcmvs_get_stats",
            "hcmvs_splat_init", "hcmvs_triangulate_init", "hcmvs_triangulate_points", "hcmvs_set_depthmap", "hcmvs_set_depthmap_device", "hcmvs_get_depthmap",
            "hcmvs_set_neighbors", "hcmvs_filter", "hcmvs_set_fuse_order", "hcmvs_fuse", "hcmvs_fuse_cloud", "hcmvs_estimate_point_colors",
-           "hcmvs_estimate_point_normals", "hcmvs_postfilter", "hcmvs_resize_area_up"]
+           "hcmvs_estimate_point_normals", "hcmvs_postfilter", "hcmvs_postfilter_sequence", "hcmvs_resize_area_up"]
 
 
 def triangulate_points(w, h, K, R, Cc, points_xyz, avg_depth=0.0, add_corners=True):
@@ -138,6 +138,7 @@ def lib():
                                  fp, fp, u8p, u32p, u64p, u64p]
         L.hcmvs_fuse_cloud.argtypes = [vp, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Cloud)]
         L.hcmvs_postfilter.argtypes = [vp, C.c_uint32, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, u64p]
+        L.hcmvs_postfilter_sequence.argtypes = [vp, u32p, C.c_int32, u32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, u64p]
         L.hcmvs_estimate_point_colors.argtypes = [vp, C.c_uint64, fp, u32p, u32p, u8p]
         L.hcmvs_estimate_point_normals.argtypes = [vp, C.c_uint64, fp, u32p, u32p, C.c_int32, fp]
         L.hcmvs_resize_area_up.argtypes = [fp, C.c_int32, C.c_int32, C.c_int32, fp, C.c_int32, C.c_int32]
@@ -197,14 +198,18 @@ class Context:
         self._chk(lib().hcmvs_synchronize(self._h))
 
     def upload_view(self, vid, gray, K, R, Cc, bgr=None):
-        gray = np.ascontiguousarray(gray, np.float32)
-        h, w = gray.shape
+        """gray None (with a colour image): a fuse-only view -- camera, colours, gradient map, no estimate"""
         Ka, Kp = _d(K); Ra, Rp = _d(R); Ca, Cp = _d(Cc)
         bp = None
         if bgr is not None:
             bgr = np.ascontiguousarray(bgr, np.uint8)
             bp = bgr.ctypes.data_as(C.POINTER(C.c_uint8))
-        self._chk(lib().hcmvs_upload_view(self._h, vid, w, h, _f(gray), bp, Kp, Rp, Cp))
+        if gray is not None:
+            gray = np.ascontiguousarray(gray, np.float32)
+            h, w = gray.shape
+        else:
+            h, w = bgr.shape[:2]
+        self._chk(lib().hcmvs_upload_view(self._h, vid, w, h, None if gray is None else _f(gray), bp, Kp, Rp, Cp))
         self.shapes[vid] = (h, w)
 
     def set_view_device(self, vid, w, h, d_gray_ptr, K, R, Cc, d_bgr_ptr=None):
@@ -376,4 +381,13 @@ class Context:
         ids = (C.c_uint32 * len(order))(*order)
         nf = C.c_uint64()
         self._chk(lib().hcmvs_postfilter(self._h, vid, ids, len(order), n_min_views_fuse, depth_diff_threshold, normal_diff_deg, gap_size, C.byref(nf)))
+        return nf.value
+
+    def postfilter_sequence(self, vids, order, n_min_views_fuse=2, depth_diff_threshold=0.01, normal_diff_deg=25.0, gap_size=7):
+        """the post-filters for the images vids one after the other (= postfilter(v) for v in vids); returns the pixels filled in total"""
+        ids = (C.c_uint32 * len(vids))(*vids)
+        ords = (C.c_uint32 * len(order))(*order)
+        nf = C.c_uint64()
+        self._chk(lib().hcmvs_postfilter_sequence(self._h, ids, len(vids), ords, len(order), n_min_views_fuse, depth_diff_threshold, normal_diff_deg,
+                                                  gap_size, C.byref(nf)))
         return nf.value

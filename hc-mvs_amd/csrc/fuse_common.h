@@ -48,13 +48,19 @@ FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_
                        uint32_t* nbrList, size_t stride);
 // ctl: 8 words, zero before the pass: [0] queue tail, [1] queue head, [2] pixels decided, [3] error flag, [4] pending pixels
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
-                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, float thDepth, float normalError, hipStream_t s);
-void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, hipStream_t s);
+                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, float thDepth, float normalError, const uint32_t* abort, hipStream_t s);
+void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, const uint32_t* abort, hipStream_t s);
+// a fusion enqueued without host synchronisation (hcmvs_postfilter_sequence): abort = its status words ([0] stall, [1] link lists too
+// small -> every later kernel of the fusion returns at once, [2] the size needed), null for the synchronous path
+void launch_fuse_links_check(const FuseTables& tb, unsigned long long capLinks, uint32_t* status, hipStream_t s);
+void launch_fuse_status(const uint32_t* ctl, uint32_t* status, hipStream_t s);
+void launch_reset_claims(const DevMap* maps, int nMaps, hipStream_t s);
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
-                      uint32_t* merged, int nMinViewsFuse, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, hipStream_t s);
+                      uint32_t* merged, int nMinViewsFuse, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, const uint32_t* abort,
+                      hipStream_t s);
 void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const uint32_t* claim, const uint8_t* gra, float* dF, float* nF,
-                       int gap, float thr, unsigned long long* filled, hipStream_t s);
+                       int gap, float thr, unsigned long long* filled, const uint32_t* abort, hipStream_t s);
 void launch_point_colors(unsigned long long n, const float* xyz, const unsigned long long* voff, const uint32_t* views, const DevMap* maps, uint8_t* bgr, hipStream_t s);
 size_t fuse_scan_temp_bytes(int n);
 void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,

@@ -230,7 +230,8 @@ __device__ __forceinline__ void rotate_normal(const DevMap& M, const float* nm, 
 // depth and normal, SceneDensify.cpp:3400-3404) or lies in front of it (:3418).  The pass itself only has to look at what
 // is left of the target when the pixel's turn comes.
 __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, uint32_t* pending, uint32_t* roundCnt, uint8_t* flag,
-                                  unsigned long long* counters, float thDepth, float normalError) {
+                                  unsigned long long* counters, float thDepth, float normalError, const uint32_t* abort) {
+	if (abort && abort[1] != 0u) return;
 	const int n = A.w * A.h;
 	unsigned nd = 0;
 	const int nPad = (n + 63) & ~63; // whole waves take part in list_append
@@ -273,7 +274,8 @@ __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, u
 	if (nd) atomicAdd(&counters[0], (unsigned long long)nd); // valid depths visited (SceneDensify.cpp:3359)
 }
 // write the per-target lists (any order inside a list)
-__global__ void fuse_fill_kernel(int nNb, FuseTables tb, const uint32_t* pending, const uint32_t* roundCnt) {
+__global__ void fuse_fill_kernel(int nNb, FuseTables tb, const uint32_t* pending, const uint32_t* roundCnt, const uint32_t* abort) {
+	if (abort && abort[1] != 0u) return;
 	const int n = (int)roundCnt[1];
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint32_t idx = pending[i];
@@ -290,7 +292,8 @@ __global__ void fuse_fill_kernel(int nNb, FuseTables tb, const uint32_t* pending
 // (it wakes them); pass 0 counts, pass 1 writes the lists at the scanned offsets
 // order: 0 = raster order (the reference's), 1 = a fixed pseudo-random order (a bijective hash of the raster index)
 __device__ __forceinline__ uint32_t fuse_prio(uint32_t idx, int order) { return order ? idx * 0x9E3779B1u : idx; }
-__global__ void fuse_links_kernel(int nNb, FuseTables tb, const uint32_t* pending, const uint32_t* roundCnt, int write, int order) {
+__global__ void fuse_links_kernel(int nNb, FuseTables tb, const uint32_t* pending, const uint32_t* roundCnt, int write, int order, const uint32_t* abort) {
+	if (abort && abort[1] != 0u) return; // the link lists do not fit (fuse_links_check_kernel): the host grows them and runs the fusion again
 	const int n = (int)roundCnt[1];
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint32_t idx = pending[i];
@@ -316,19 +319,40 @@ struct FuseOut { // per pixel of the current image, compacted in raster order af
 	float* xyz; float* normal; uint8_t* bgr; uint32_t* nviews; uint8_t* flag;
 	uint32_t* views; float* weights; int vstride; // optional: the point's view list (image ids ascending) and weights, vstride per pixel
 };
+// status words of a fusion enqueued without host synchronisation (hcmvs_postfilter_sequence): [0] a pass stalled or timed out,
+// [1] the link lists of a pass do not fit (nothing after that point has touched the maps), [2] the size they need
+__global__ void fuse_links_check_kernel(FuseTables tb, unsigned long long capLinks, uint32_t* status) {
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	const unsigned long long need = (unsigned long long)tb.offP[2 * tb.stride - 1] + tb.cntP[2 * tb.stride - 1];
+	if (need > capLinks) { status[1] = 1u; atomicMax(&status[2], (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need)); }
+}
+__global__ void fuse_status_kernel(const uint32_t* ctl, uint32_t* status) {
+	if (blockIdx.x != 0 || threadIdx.x != 0 || status[1] != 0u) return;
+	if (ctl[3] != 0u || ctl[2] != ctl[4]) status[0] = 1u;
+}
+__global__ void reset_claims_kernel(const DevMap* maps, int nMaps) {
+	for (int m = blockIdx.y; m < nMaps; m += gridDim.y) {
+		uint32_t* cl = maps[m].claim;
+		if (!cl || !maps[m].depth) continue;
+		const size_t n = (size_t)maps[m].w * maps[m].h;
+		for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) cl[i] = 0xFFFFFFFFu;
+	}
+}
 struct FusePass {
 	FuseTables tb;
 	uint32_t* queue;         // [pending] append-only ready queue, FS_EMPTY until written
 	uint32_t* ctl;           // [0] queue tail, [1] queue head, [2] pixels decided, [3] error flag, [4] pending (set by fuse_begin)
 	uint32_t* merged;        // [w*h] out: per point, which neighbours' estimates it merged (bit q = neighbour q)
 	uint32_t* levels;        // diagnostic (HCMVS_FUSE_DEBUG), else null: per-pixel depth in the dependence graph, maximum in ctl[5]
+	const uint32_t* abort;   // null, or the status words of an unsynchronised fusion: [1] != 0 -> do nothing
 	int nMinViewsFuse;
 };
 #define FS_EMPTY 0xFFFFFFFFu
 
 // seed of the pass: the pending pixels nobody blocks.  A launch of its own: the pass counts the countdowns down, and a
 // pixel that reaches zero there must not be taken for a seed as well.
-__global__ void fuse_seed_kernel(FuseTables tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl) {
+__global__ void fuse_seed_kernel(FuseTables tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl, const uint32_t* abort) {
+	if (abort && abort[1] != 0u) return;
 	const uint32_t nPending = ctl[4];
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nPending; i += gridDim.x * blockDim.x) {
 		const uint32_t idx = pending[i];
@@ -358,6 +382,7 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 	__shared__ uint32_t* claimOf[MAXV - 1];
 	__shared__ uint32_t ring[kFuseRing];
 	__shared__ uint32_t ringCnt;
+	if (fp.abort && fp.abort[1] != 0u) return; // wave-uniform
 	const int nNb = A.nNeighbors;
 	const int lane = threadIdx.x;
 	if (lane < nNb) { const DevMap& B = maps[A.neighbors[lane]]; depthOf[lane] = B.depth; claimOf[lane] = B.claim; }
@@ -611,7 +636,8 @@ __global__ void point_colors_kernel(unsigned long long n, const float* xyz, cons
 // the lines of a pass are independent), then the merge (SceneDensify.cpp:2989-3000).  The third, per-pixel pass of the
 // reference (SceneDensify.cpp:2717-2983) reads uninitialised variables and is not reproduced.
 
-__global__ void postfilter_mask_kernel(int n, const float* depth, const float* normal, const uint32_t* claim, float* dF, float* nF) {
+__global__ void postfilter_mask_kernel(int n, const float* depth, const float* normal, const uint32_t* claim, float* dF, float* nF, const uint32_t* abort) {
+	if (abort && abort[1] != 0u) return;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const bool on = claim[i] != NO_ID;
 		dF[i] = on ? depth[i] : 0.f;
@@ -619,7 +645,8 @@ __global__ void postfilter_mask_kernel(int n, const float* depth, const float* n
 	}
 }
 __global__ void gap_lines_kernel(float* dF, float* nF, float* conf, const uint8_t* gra, int nLines, int len, size_t lineStride, size_t stride, int gap,
-                                 float thr, unsigned long long* filledOut) {
+                                 float thr, unsigned long long* filledOut, const uint32_t* abort) {
+	if (abort && abort[1] != 0u) return;
 	const int line = blockIdx.x * blockDim.x + threadIdx.x;
 	if (line >= nLines) return;
 	const size_t base = (size_t)line * lineStride;
@@ -667,7 +694,8 @@ __global__ void gap_lines_kernel(float* dF, float* nF, float* conf, const uint8_
 	}
 	if (filled) atomicAdd(filledOut, filled);
 }
-__global__ void postfilter_merge_kernel(int n, float* depth, float* normal, const float* dF, const float* nF) {
+__global__ void postfilter_merge_kernel(int n, float* depth, float* normal, const float* dF, const float* nF, const uint32_t* abort) {
+	if (abort && abort[1] != 0u) return;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		if (dF[i] > 0.f) depth[i] = dF[i];
 		const float a = nF[3 * i], b = nF[3 * i + 1], c = nF[3 * i + 2];
@@ -675,12 +703,21 @@ __global__ void postfilter_merge_kernel(int n, float* depth, float* normal, cons
 	}
 }
 void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const uint32_t* claim, const uint8_t* gra, float* dF, float* nF,
-                       int gap, float thr, unsigned long long* filled, hipStream_t s) {
+                       int gap, float thr, unsigned long long* filled, const uint32_t* abort, hipStream_t s) {
 	const int n = w * h;
-	hipLaunchKernelGGL(postfilter_mask_kernel, kGrid, kBlock, 0, s, n, depth, normal, claim, dF, nF);
-	hipLaunchKernelGGL(gap_lines_kernel, dim3((h + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, h, w, (size_t)w, (size_t)1, gap, thr, filled);   // rows
-	hipLaunchKernelGGL(gap_lines_kernel, dim3((w + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, w, h, (size_t)1, (size_t)w, gap, thr, filled);   // columns
-	hipLaunchKernelGGL(postfilter_merge_kernel, kGrid, kBlock, 0, s, n, depth, normal, dF, nF);
+	hipLaunchKernelGGL(postfilter_mask_kernel, kGrid, kBlock, 0, s, n, depth, normal, claim, dF, nF, abort);
+	hipLaunchKernelGGL(gap_lines_kernel, dim3((h + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, h, w, (size_t)w, (size_t)1, gap, thr, filled, abort);   // rows
+	hipLaunchKernelGGL(gap_lines_kernel, dim3((w + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, w, h, (size_t)1, (size_t)w, gap, thr, filled, abort);   // columns
+	hipLaunchKernelGGL(postfilter_merge_kernel, kGrid, kBlock, 0, s, n, depth, normal, dF, nF, abort);
+}
+void launch_reset_claims(const DevMap* maps, int nMaps, hipStream_t s) {
+	hipLaunchKernelGGL(reset_claims_kernel, dim3(256, nMaps < 1024 ? (nMaps > 0 ? nMaps : 1) : 1024), dim3(256), 0, s, maps, nMaps);
+}
+void launch_fuse_links_check(const FuseTables& tb, unsigned long long capLinks, uint32_t* status, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_links_check_kernel, dim3(1), dim3(64), 0, s, tb, capLinks, status);
+}
+void launch_fuse_status(const uint32_t* ctl, uint32_t* status, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_status_kernel, dim3(1), dim3(64), 0, s, ctl, status);
 }
 
 void launch_point_colors(unsigned long long n, const float* xyz, const unsigned long long* voff, const uint32_t* views, const DevMap* maps, uint8_t* bgr, hipStream_t s) {
@@ -711,25 +748,26 @@ FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_
 // begin of an image pass: the pending list (its length in ctl[4]), targets, per-target lists, per-pixel link counts + offsets
 // (cntT / fillT / cntP must be zero).  fuse_links_fill writes the link lists once the host has sized them.
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
-                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, float thDepth, float normalError, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, ctl + 3, flag, counters, thDepth, normalError); // roundCnt[1] == ctl[4]
+                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, float thDepth, float normalError, const uint32_t* abort, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, ctl + 3, flag, counters, thDepth, normalError, abort); // roundCnt[1] == ctl[4]
 	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntT, tb.offT, (int)(tb.stride * (size_t)A.nNeighbors), s);
-	hipLaunchKernelGGL(fuse_fill_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3);
-	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3, 0, order);
+	hipLaunchKernelGGL(fuse_fill_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3, abort);
+	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3, 0, order, abort);
 	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntP, tb.offP, (int)(2 * tb.stride), s);
 }
-void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3, 1, order);
+void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, const uint32_t* abort, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3, 1, order, abort);
 }
 // the whole image pass in one launch of dataflow workers (one wave per workgroup; any grid size is correct), then the points
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
-                      uint32_t* merged, int nMinViewsFuse, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, hipStream_t s) {
+                      uint32_t* merged, int nMinViewsFuse, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, const uint32_t* abort,
+                      hipStream_t s) {
 	FuseOut out{oxyz, onormal, obgr, onv, oflag, oviews, oweights, vstride};
 	FusePass fp;
-	fp.tb = tb; fp.queue = queue; fp.ctl = ctl; fp.merged = merged; fp.levels = levels;
+	fp.tb = tb; fp.queue = queue; fp.ctl = ctl; fp.merged = merged; fp.levels = levels; fp.abort = abort;
 	fp.nMinViewsFuse = nMinViewsFuse;
-	hipLaunchKernelGGL(fuse_seed_kernel, kGrid, kBlock, 0, s, tb, pending, queue, ctl);
+	hipLaunchKernelGGL(fuse_seed_kernel, kGrid, kBlock, 0, s, tb, pending, queue, ctl, abort);
 	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_pass_kernel<16>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
 	else hipLaunchKernelGGL(fuse_pass_kernel<32>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
 	if (!wantPoints) return;

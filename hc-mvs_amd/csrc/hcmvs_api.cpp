@@ -91,6 +91,7 @@ struct hcmvs_ctx {
 	void* fuseScratch = nullptr; size_t capFuseScratch = 0;
 	std::vector<FuseLane> fuseLanes; // per-pass scratch of the concurrent fusion passes
 	bool errPending = false; // an estimate was enqueued since the error word was last read
+	int nCU = 0;          // compute units of the device (fusion worker count)
 	int wavesPerRow = 0; // 0 = automatic: 3 waves per row for one image, 2 for two (latency), 1 when >= 3 images fill the chip
 };
 
@@ -265,7 +266,9 @@ int hcmvs_synchronize(hcmvs_ctx* c) {
 static int set_view(hcmvs_ctx* c, uint32_t id, int w, int h, const float* gray, const uint8_t* bgr, const double* K,
                     const double* R, const double* C, bool copy) {
 	if (!c) return HCMVS_ERR_INVALID;
-	if (!gray || !K || !R || !C || w < 2 * kHalfWindow + 2 || h < 2 * kHalfWindow + 2 || w > 32768 || h > 32768 || id >= 65536)
+	// gray may be null when a colour image is given: a view that is only fused / filtered (camera, colours, gradient map), never the
+	// reference or a source view of an estimate -- what a rank of a multi-GPU job holds of the images other ranks estimate
+	if ((!gray && !bgr) || !K || !R || !C || w < 2 * kHalfWindow + 2 || h < 2 * kHalfWindow + 2 || w > 32768 || h > 32768 || id >= 65536)
 		return fail(c, HCMVS_ERR_INVALID, "upload_view: bad arguments (id %u, %dx%d)", id, w, h);
 	HIPCHK(c, hipSetDevice(c->device));
 	auto it = c->views.find(id);
@@ -274,8 +277,10 @@ static int set_view(hcmvs_ctx* c, uint32_t id, int w, int h, const float* gray, 
 	v.w = w; v.h = h; v.owned = copy;
 	const size_t n = (size_t)w * h;
 	if (copy) {
-		HIPCHK(c, hipMalloc(&v.gray, n * sizeof(float)));
-		HIPCHK(c, hipMemcpyAsync(v.gray, gray, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+		if (gray) {
+			HIPCHK(c, hipMalloc(&v.gray, n * sizeof(float)));
+			HIPCHK(c, hipMemcpyAsync(v.gray, gray, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+		}
 		if (bgr) {
 			HIPCHK(c, hipMalloc(&v.bgr, n * 3));
 			HIPCHK(c, hipMemcpyAsync(v.bgr, bgr, n * 3, hipMemcpyHostToDevice, c->stream));
@@ -304,6 +309,7 @@ int hcmvs_rescale_view(hcmvs_ctx* c, uint32_t src_id, uint32_t dst_id, float sca
 	if (it == c->views.end() || dst_id >= 65536 || dst_id == src_id) return fail(c, HCMVS_ERR_INVALID, "rescale_view: bad view ids %u -> %u", src_id, dst_id);
 	if (!(scale > 0.f) || fabsf(scale - 1.f) < 0.15f) return fail(c, HCMVS_ERR_INVALID, "rescale_view: scale %g is within 15 %% of 1 (DepthMap.h:234: not resampled)", scale);
 	const View src = it->second;
+	if (!src.gray) return fail(c, HCMVS_ERR_INVALID, "rescale_view: view %u has no gray image (fuse-only view)", src_id);
 	// cv::resize with dsize empty: Size(saturate_cast<int>(w * fx), saturate_cast<int>(h * fy)), saturate_cast<int>(double) = cvRound
 	const int nw = (int)lrint((double)src.w * (double)scale), nh = (int)lrint((double)src.h * (double)scale);
 	if (nw < 2 * kHalfWindow + 2 || nh < 2 * kHalfWindow + 2 || nw > 32768 || nh > 32768) return fail(c, HCMVS_ERR_INVALID, "rescale_view: %dx%d x %g gives an unusable size", src.w, src.h, scale);
@@ -334,7 +340,7 @@ int hcmvs_get_view_info(hcmvs_ctx* c, uint32_t id, int32_t* w, int32_t* h, doubl
 int hcmvs_get_view_gray(hcmvs_ctx* c, uint32_t id, float* out) {
 	if (!c || !out) return HCMVS_ERR_INVALID;
 	auto it = c->views.find(id);
-	if (it == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "get_view_gray: unknown view %u", id);
+	if (it == c->views.end() || !it->second.gray) return fail(c, HCMVS_ERR_INVALID, "get_view_gray: unknown view %u (or a fuse-only view)", id);
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, hipMemcpyAsync(out, it->second.gray, (size_t)it->second.w * it->second.h * sizeof(float), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -424,10 +430,13 @@ static int build_item(hcmvs_ctx* c, int slot, const hcmvs_batch_item& it, const 
 	if (!it.src_ids || !it.d_depth || !it.d_normal || !it.d_conf) return fail(c, HCMVS_ERR_INVALID, "estimate: null argument");
 	const int n_src = it.n_src;
 	if (n_src < 1 || n_src > HCMVS_MAX_VIEWS) return fail(c, HCMVS_ERR_INVALID, "estimate: n_src %d not in 1..%d", n_src, HCMVS_MAX_VIEWS);
-	if (!(it.d_min > 0.f) || !(it.d_max > it.d_min)) return fail(c, HCMVS_ERR_INVALID, "estimate: bad depth range [%g,%g)", it.d_min, it.d_max);
+	// d_min == 0 is what the `restore` variant ends up with (its range takes the enlarged previous-level map in, zeros included,
+	// restore/libs/MVS/SceneDensify.cpp:526-532)
+	if (!(it.d_min >= 0.f) || !(it.d_max > it.d_min)) return fail(c, HCMVS_ERR_INVALID, "estimate: bad depth range [%g,%g)", it.d_min, it.d_max);
 	auto rit = c->views.find(it.ref_id);
 	if (rit == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "estimate: unknown reference view %u", it.ref_id);
 	View& ref = rit->second;
+	if (!ref.gray) return fail(c, HCMVS_ERR_INVALID, "estimate: view %u was registered without a gray image (fuse-only view)", it.ref_id);
 	int rc = ensure_slot(c, slot, (size_t)ref.w * ref.h, ref.h);
 	if (rc) return rc;
 	rc = ensure_gradient(c, ref);
@@ -450,6 +459,7 @@ static int build_item(hcmvs_ctx* c, int slot, const hcmvs_batch_item& it, const 
 		auto sit = c->views.find(it.src_ids[v]);
 		if (sit == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "estimate: unknown source view %u", it.src_ids[v]);
 		View& s = sit->second;
+		if (!s.gray) return fail(c, HCMVS_ERR_INVALID, "estimate: source view %u was registered without a gray image (fuse-only view)", it.src_ids[v]);
 		rc = ensure_quads(c, s);
 		if (rc) return rc;
 		double KR[9], Hl[9], A[9];
@@ -1049,7 +1059,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 			LANECHK(hipMemsetAsync(queue, 0xFF, (size_t)n * 4, ls));                             // FS_EMPTY
 			LANECHK(hipMemsetAsync(cntT, 0, (oOffT - oCntT), ls));                               // per-target counts, fill cursors, per-pixel link counts
 			FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, cntP, offP, L.links, stride);
-			launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, c->fuseOrder, thDepth, normalError, ls);
+			launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, c->fuseOrder, thDepth, normalError, nullptr, ls);
 			uint32_t lastOff = 0, lastCnt = 0; // total size of the link lists = last offset + last count
 			LANECHK(hipMemcpyAsync(&lastOff, offP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, ls));
 			LANECHK(hipMemcpyAsync(&lastCnt, cntP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, ls));
@@ -1066,11 +1076,11 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 				L.capLinks = want;
 				tb.nbrList = L.links;
 			}
-			launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, ls);
+			launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, nullptr, ls);
 			if (debug) LANECHK(hipMemsetAsync(flag32, 0, (size_t)n * 4, ls)); // diagnostic: dependence depth per pixel (the buffer is free until the compaction)
 			const auto tPass = std::chrono::steady_clock::now();
 			launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
-			                 merged, n_min_views_fuse, counters, blocks, debug ? flag32 : nullptr, wantCloud, ls);
+			                 merged, n_min_views_fuse, counters, blocks, debug ? flag32 : nullptr, wantCloud, nullptr, ls);
 			unsigned long long cnt[5] = {0, 0, 0, 0, 0};
 			uint32_t ctlWords[6] = {0, 0, 0, 0, 0, 0};
 			LANECHK(hipMemcpyAsync(cnt, counters, 40, hipMemcpyDeviceToHost, ls));
@@ -1167,35 +1177,138 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	return rc;
 }
 
+// The post-filters of one outer iteration, image after image.  Every image costs a complete fusion over all maps (that IS the
+// fork's RemoveSmallSegments, SceneDensify.cpp:2048-2275), so the fusion here is the one thing that must be cheap: it produces no
+// cloud, and all its passes are enqueued on the context's stream WITHOUT host synchronisation -- stream order is the image order
+// of the sequential algorithm.  The one thing the synchronous path asks the host for, the size of a pass's link lists, is checked
+// on the device instead (fuse_links_check_kernel): when the lists do not fit, every later kernel of that fusion returns at once,
+// the depth maps are put back from a snapshot taken before it, the lists grow and the fusion runs again.  One synchronisation
+// per image.
+int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse,
+                              float depth_diff_threshold, float normal_diff_deg, int32_t gap_size, uint64_t* n_filled) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!ids || n_ids < 1 || !order || n_order < 1 || gap_size < 0) return fail(c, HCMVS_ERR_INVALID, "postfilter: bad arguments");
+	for (int k = 0; k < n_ids; ++k) {
+		auto it = c->views.find(ids[k]);
+		if (it == c->views.end() || !it->second.mDepth || !it->second.mNormal) return fail(c, HCMVS_ERR_INVALID, "postfilter: view %u has no registered depth + normal maps", ids[k]);
+	}
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	std::vector<DevMap> host;
+	int rc = build_map_table(c, host);
+	if (rc) return rc;
+	size_t maxArea = 0, stride = 0, allPx = 0, maxIdArea = 0;
+	int maxNb = 1;
+	for (int i = 0; i < n_order; ++i) {
+		if (order[i] >= host.size() || !host[order[i]].depth) return fail(c, HCMVS_ERR_INVALID, "postfilter: view %u has no maps", order[i]);
+		maxArea = std::max(maxArea, (size_t)host[order[i]].w * host[order[i]].h);
+		if (host[order[i]].nNeighbors > kFuseMaxViews - 1) return fail(c, HCMVS_ERR_INVALID, "postfilter: view %u has too many neighbours", order[i]);
+		maxNb = std::max(maxNb, (int)host[order[i]].nNeighbors);
+	}
+	stride = maxArea;
+	for (const auto& m : host) if (m.depth) { stride = std::max(stride, (size_t)m.w * m.h); allPx += (size_t)m.w * m.h; }
+	for (int k = 0; k < n_ids; ++k) { View& v = c->views.find(ids[k])->second; maxIdArea = std::max(maxIdArea, (size_t)v.w * v.h); rc = ensure_gradient(c, v); if (rc) return rc; }
+	const size_t tblElems = stride * (size_t)maxNb;
+	if (stride >= ((size_t)1 << 29) || tblElems > 0x7FFFFFFFull) return fail(c, HCMVS_ERR_CAPACITY, "postfilter: %d neighbours of %zu pixels exceed the per-pass tables", maxNb, stride);
+	const size_t scanBytes = (std::max({fuse_scan_temp_bytes((int)maxArea), fuse_scan_temp_bytes((int)tblElems), fuse_scan_temp_bytes((int)(2 * stride))}) + 255) & ~(size_t)255;
+	size_t off = 0;
+	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+	const size_t oPending = carve(maxArea * 4), oQueue = carve(maxArea * 4), oTgt = carve(maxArea * 4 * (size_t)maxNb),
+	             oCntT = carve(tblElems * 4), oFillT = carve(tblElems * 4), oCntP = carve(stride * 8), oOffT = carve(tblElems * 4), oOffP = carve(stride * 8),
+	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(64), oCounters = carve(64), oStatus = carve(64), oMerged = carve(maxArea * 4),
+	             oFlag = carve(maxArea), oNv = carve(maxArea * 4), oScan = carve(scanBytes), oDF = carve(maxIdArea * 4), oNF = carve(maxIdArea * 12),
+	             oSnap = carve(allPx * 4);
+	if (c->fuseLanes.empty()) c->fuseLanes.resize(1);
+	FuseLane& L = c->fuseLanes[0];
+	if (L.cap < off) {
+		if (L.scratch) (void)hipFree(L.scratch);
+		L.scratch = nullptr; L.cap = 0;
+		HIPCHK(c, hipMalloc(&L.scratch, off));
+		L.cap = off;
+	}
+	if (!L.links) { // first size of the link lists; HCMVS_FUSE_LINKS_INIT (entries) lets a test start too small and exercise the undo-and-grow path
+		size_t first = (size_t)8 << 20;
+		if (getenv("HCMVS_FUSE_LINKS_INIT") && atol(getenv("HCMVS_FUSE_LINKS_INIT")) > 0) first = (size_t)atol(getenv("HCMVS_FUSE_LINKS_INIT"));
+		HIPCHK(c, hipMalloc(&L.links, first * 4));
+		L.capLinks = first;
+	}
+	char* b = L.scratch;
+	uint32_t* pendingList = (uint32_t*)(b + oPending); uint32_t* queue = (uint32_t*)(b + oQueue); uint32_t* ctl = (uint32_t*)(b + oCtl);
+	unsigned long long* counters = (unsigned long long*)(b + oCounters);
+	uint32_t* status = (uint32_t*)(b + oStatus);
+	int32_t* targets = (int32_t*)(b + oTgt);
+	uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders),
+	         *cntP = (uint32_t*)(b + oCntP), *offP = (uint32_t*)(b + oOffP);
+	uint8_t* flag = (uint8_t*)(b + oFlag); uint32_t* merged = (uint32_t*)(b + oMerged); uint32_t* pnv = (uint32_t*)(b + oNv);
+	float* dF = (float*)(b + oDF); float* nF = (float*)(b + oNF); float* snap = (float*)(b + oSnap);
+	const float normalError = cosf(normal_diff_deg * (3.14159274101257324f / 180.f)); // plain thresholds (SceneDensify.cpp:2083, 2177)
+	const float thDepth = depth_diff_threshold;
+	if (c->nCU <= 0) {
+		hipDeviceProp_t prop;
+		HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+		c->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
+	}
+	int blocks = c->nCU * 4;
+	if (getenv("HCMVS_FUSE_BLOCKS")) blocks = std::min(c->nCU * 16, std::max(1, atoi(getenv("HCMVS_FUSE_BLOCKS"))));
+	hipStream_t s = c->stream;
+	unsigned long long filledAll = 0;
+	for (int k = 0; k < n_ids; ++k) {
+		View& v = c->views.find(ids[k])->second;
+		for (int attempt = 0;; ++attempt) {
+			HIPCHK(c, hipMemsetAsync(status, 0, 64, s));
+			HIPCHK(c, hipMemsetAsync(counters, 0, 64, s));
+			{ // the snapshot the fusion is undone from when a link list turns out too small
+				size_t o = 0;
+				for (const auto& m : host) if (m.depth) { HIPCHK(c, hipMemcpyAsync(snap + o, m.depth, (size_t)m.w * m.h * 4, hipMemcpyDeviceToDevice, s)); o += (size_t)m.w * m.h; }
+			}
+			launch_reset_claims(c->dMaps, (int)host.size(), s);
+			for (int oi = 0; oi < n_order; ++oi) {
+				const DevMap& A = host[order[oi]];
+				const int n = A.w * A.h;
+				HIPCHK(c, hipMemsetAsync(ctl, 0, 64, s));
+				HIPCHK(c, hipMemsetAsync(queue, 0xFF, (size_t)n * 4, s));                  // FS_EMPTY
+				HIPCHK(c, hipMemsetAsync(cntT, 0, (size_t)A.nNeighbors * stride * 4, s)); // per-target counts of this image's neighbours
+				HIPCHK(c, hipMemsetAsync(fillT, 0, (size_t)A.nNeighbors * stride * 4, s));
+				HIPCHK(c, hipMemsetAsync(cntP, 0, stride * 8, s));
+				FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, cntP, offP, L.links, stride);
+				launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, c->fuseOrder, thDepth, normalError, status, s);
+				launch_fuse_links_check(tb, (unsigned long long)L.capLinks, status, s);
+				launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, status, s);
+				launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, ctl, nullptr, nullptr, nullptr, pnv, flag, nullptr, nullptr, maxNb + 1, merged, n_min_views_fuse,
+				                 counters, blocks, nullptr, false, status, s);
+				launch_fuse_status(ctl, status, s);
+			}
+			launch_postfilter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, v.claim, v.gra, dF, nF, gap_size, depth_diff_threshold * 2.5f, counters + 5, status, s);
+			HIPCHK(c, hipGetLastError());
+			uint32_t st[4] = {0, 0, 0, 0};
+			unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};
+			HIPCHK(c, hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, s));
+			HIPCHK(c, hipMemcpyAsync(cnt, counters, 48, hipMemcpyDeviceToHost, s));
+			HIPCHK(c, hipStreamSynchronize(s));
+			if (st[1] != 0) { // a link list did not fit: undo, grow, again
+				size_t o = 0;
+				for (const auto& m : host) if (m.depth) { HIPCHK(c, hipMemcpyAsync(m.depth, snap + o, (size_t)m.w * m.h * 4, hipMemcpyDeviceToDevice, s)); o += (size_t)m.w * m.h; }
+				HIPCHK(c, hipStreamSynchronize(s));
+				if (attempt >= 4) return fail(c, HCMVS_ERR_CAPACITY, "postfilter: the link lists of a pass keep outgrowing their buffer (%u entries)", st[2]);
+				(void)hipFree(L.links);
+				L.links = nullptr; L.capLinks = 0;
+				const size_t want = (size_t)st[2] + (size_t)st[2] / 4 + ((size_t)1 << 20);
+				HIPCHK(c, hipMalloc(&L.links, want * 4));
+				L.capLinks = want;
+				continue;
+			}
+			if (st[0] != 0) return fail(c, HCMVS_ERR_TIMEOUT, "postfilter: a fusion pass stalled; the registered depth maps are left partially fused");
+			filledAll += cnt[5];
+			break;
+		}
+	}
+	if (n_filled) *n_filled = filledAll;
+	return HCMVS_OK;
+}
+
 int hcmvs_postfilter(hcmvs_ctx* c, uint32_t id, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
                      float normal_diff_deg, int32_t gap_size, uint64_t* n_filled) {
-	if (!c) return HCMVS_ERR_INVALID;
-	auto it = c->views.find(id);
-	if (it == c->views.end() || !it->second.mDepth || !it->second.mNormal) return fail(c, HCMVS_ERR_INVALID, "postfilter: view %u has no registered depth + normal maps", id);
-	if (gap_size < 0) return fail(c, HCMVS_ERR_INVALID, "postfilter: bad gap size");
-	HIPCHK(c, hipSetDevice(c->device));
-	// RemoveSmallSegments (fork version): the whole fusion, for its claim maps and invalidations only
-	hcmvs_cloud cl;
-	memset(&cl, 0, sizeof cl);
-	// (plain thresholds: COS(FD2R(fNormalDiffThreshold)) and IsDepthSimilar(.., fDepthDiffThreshold), SceneDensify.cpp:2083, 2177)
-	int rc = hcmvs_fuse_cloud(c, order, n_order, n_min_views_fuse, depth_diff_threshold, normal_diff_deg, 1.f, 1.f, &cl);
-	if (rc) return rc;
-	View& v = c->views.find(id)->second;
-	rc = ensure_gradient(c, v);
-	if (rc) return rc;
-	const size_t n = (size_t)v.w * v.h;
-	float* dF = nullptr; float* nF = nullptr;
-	if (hipMalloc(&dF, n * 4) != hipSuccess || hipMalloc(&nF, n * 12) != hipSuccess) { if (dF) (void)hipFree(dF); return fail(c, HCMVS_ERR_HIP, "postfilter: out of device memory"); }
-	hipStream_t s = c->stream;
-	(void)hipMemsetAsync(c->counters, 0, 64, s);
-	launch_postfilter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, v.claim, v.gra, dF, nF, gap_size, depth_diff_threshold * 2.5f, c->counters, s);
-	unsigned long long filled = 0;
-	const hipError_t e1 = hipMemcpyAsync(&filled, c->counters, 8, hipMemcpyDeviceToHost, s);
-	const hipError_t e2 = hipStreamSynchronize(s);
-	(void)hipFree(dF); (void)hipFree(nF);
-	if (e1 != hipSuccess || e2 != hipSuccess || hipGetLastError() != hipSuccess) return fail(c, HCMVS_ERR_HIP, "postfilter: device failure");
-	if (n_filled) *n_filled = filled;
-	return HCMVS_OK;
+	return hcmvs_postfilter_sequence(c, &id, 1, order, n_order, n_min_views_fuse, depth_diff_threshold, normal_diff_deg, gap_size, n_filled);
 }
 
 int hcmvs_estimate_point_colors(hcmvs_ctx* c, uint64_t n, const float* xyz, const uint32_t* n_views, const uint32_t* view_ids, uint8_t* bgr) {

@@ -76,21 +76,35 @@ def gather_scene_maps(order, my_maps, h, w, group=None, device=None):
 
 
 def densify_scene(ctx, views, srcs, neighbors, order, init, params, group=None, device=None, batch=32, capacity=None,
-                  fuse_kw=None):
-    """The multi-rank scene path (BASELINE.json configs[3]) over the C-ABI binding:
+                  fuse_kw=None, n_external_iters=1, postfilter=False, pf_kw=None):
+    """The multi-rank scene path (BASELINE.json configs[3]) over the C-ABI binding, with the reference's outer
+    iterations (SceneDensify.cpp:3684) and the fork's post-filters after outer iterations 1 and 2 (SceneDensify.cpp:3939-3958):
 
-        shard_order -> per-rank hcmvs_estimate_batch_device -> all-gather of the packed maps on the device ->
-        hcmvs_set_depthmap_device + hcmvs_fuse on every rank (replicated fusion, identical clouds).
+        shard_order
+        for it in 0 .. n_external_iters-1:
+            per-rank hcmvs_estimate_batch_device of the rank's reference images          (NO collective)
+            if postfilter and it in (1, 2):
+                all-gather of the packed maps -> hcmvs_postfilter_sequence over ALL images, on every rank -> the rank
+                takes its own images' filtered maps back out of the gathered buffer
+        all-gather of the packed maps -> hcmvs_set_depthmap_device + hcmvs_fuse on every rank (identical clouds)
+
+    The post-filter is REPLICATED, not sharded: filtering image k is a fusion over the whole scene whose result (the depths it
+    invalidates, the gaps it fills) is what image k + 1's fusion sees, so the images form one sequential chain; every rank runs that
+    chain on identical gathered maps with a deterministic kernel, hence every rank holds identical filtered maps and no scatter is
+    needed -- the result is independent of the number of ranks.  One all-gather per filtered outer iteration and one before the
+    fusion (SURVEY.md 8e budgets exactly that).
 
     ctx:       binding.Context of this rank's device (one process per GPU)
-    views:     {image id: dict(gray, K, R, C[, bgr])} of EVERY image (all the same size): images are read-only inputs each
-               rank needs for the source views of its own reference images and for the colours of the fused points
+    views:     {image id: dict(gray, K, R, C[, bgr])} of EVERY image (all the same size).  A rank uploads the gray image only of
+               its own reference images and their source views; of the others it registers the camera and the colour image (what
+               fusion and the post-filters read), so a 512-image scene does not sit on every GPU eight times
     srcs:      {image id: [source view ids]}            (DepthMapsData::InitViews, SceneDensify.cpp:336-397)
     neighbors: {image id: [neighbour ids]}              (DepthData::neighbors, decreasing importance)
     order:     fusion order, best connected first       (SceneDensify.cpp:3302)
     init:      {image id: (depth0 (H,W), normal0 (H,W,3), d_min, d_max)} numpy, at least for this rank's images
-    params:    binding.Params of the estimate (one outer iteration; call again for the next)
+    params:    binding.Params of the estimate; it_external / n_external_iters are set here
     Returns the fused cloud dict of binding.Context.fuse plus `maps`: {id: (depth, normal, conf) device tensors}."""
+    import copy
     import numpy as np
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -100,10 +114,16 @@ def densify_scene(ctx, views, srcs, neighbors, order, init, params, group=None, 
     hw = h * w
     for i in ids:
         assert views[i]["gray"].shape == (h, w), "densify_scene: all images must have one size (equal slabs for one all-gather)"
-    for i, v in views.items():
-        ctx.upload_view(i, v["gray"], v["K"], v["R"], v["C"], bgr=v.get("bgr"))
     mine = shard_order(ids, world)[rank]
     n_local = (len(ids) + world - 1) // world
+    need_gray = set(mine)
+    for img in mine:
+        need_gray.update(srcs[img])
+    for i, v in views.items():
+        if i in need_gray or v.get("bgr") is None:        # without a colour image the gradient map comes from the gray image
+            ctx.upload_view(i, v["gray"], v["K"], v["R"], v["C"], bgr=v.get("bgr"))
+        else:
+            ctx.upload_view(i, None, v["K"], v["R"], v["C"], bgr=v["bgr"])
     slabs = torch.zeros(n_local, FLOATS_PER_PIXEL * hw, dtype=torch.float32, device=dev)
     rng = torch.zeros(n_local, 2, dtype=torch.float32, device=dev)      # (d_min, d_max) travel with the maps
     items_by_class = {}
@@ -117,20 +137,36 @@ def densify_scene(ctx, views, srcs, neighbors, order, init, params, group=None, 
         cls = 8 if v <= 8 else 16   # the items of a batch share a lane-layout class (up to 8 views, or 9..16)
         items_by_class.setdefault(cls, []).append(dict(ref_id=img, src_ids=list(srcs[img]), d_min=float(dmin), d_max=float(dmax),
                                                        d_depth=base, d_normal=base + 4 * hw, d_conf=base + 16 * hw, seed_offset=img))
-    torch.cuda.synchronize(dev)
-    for cls, items in sorted(items_by_class.items()):     # NO collective on the estimation path
-        for b0 in range(0, len(items), batch):
-            ctx.estimate_batch_device(items[b0:b0 + batch], params)
-    ctx.synchronize()
-    allm = allgather_maps(slabs, group)                    # the one exchange: 20 B/px, rank-major equal slabs
     allr = allgather_maps(rng, group)
-    maps = {}
-    for k, img in enumerate(ids):
-        row = slab_index(k, world, n_local)
-        base = allm[row].data_ptr()
-        ctx.set_depthmap_device(img, base, base + 4 * hw, base + 16 * hw, float(allr[row, 0]), float(allr[row, 1]))
-        ctx.set_neighbors(img, [n for n in neighbors[img] if n in views][:31])
-        maps[img] = unpack_maps(allm[row], h, w)
+    gathered = torch.empty(world * n_local, FLOATS_PER_PIXEL * hw, dtype=torch.float32, device=dev) if world > 1 else None
+
+    def register(allm):
+        for k, img in enumerate(ids):
+            row = slab_index(k, world, n_local)
+            base = allm[row].data_ptr()
+            ctx.set_depthmap_device(img, base, base + 4 * hw, base + 16 * hw, float(allr[row, 0]), float(allr[row, 1]))
+            ctx.set_neighbors(img, [n for n in neighbors[img] if n in views][:31])
+
+    p = copy.copy(params)
+    p.n_external_iters = int(n_external_iters)
+    torch.cuda.synchronize(dev)
+    for it in range(int(n_external_iters)):
+        p.it_external = it
+        for cls, items in sorted(items_by_class.items()):     # NO collective on the estimation path
+            for b0 in range(0, len(items), batch):
+                ctx.estimate_batch_device(items[b0:b0 + batch], p)
+        ctx.synchronize()
+        if postfilter and it in (1, 2):
+            allm = allgather_maps(slabs, group, out=gathered)  # every rank: every image's current maps
+            register(allm)
+            ctx.postfilter_sequence(sorted(ids), ids, **(pf_kw or {}))   # image after image, as the reference's event loop runs them
+            ctx.synchronize()
+            if world > 1:                                      # my images' filtered maps: out of the gathered buffer, back into my slabs
+                for j, img in enumerate(mine):
+                    slabs[j].copy_(allm[slab_index(ids.index(img), world, n_local)])
+    allm = allgather_maps(slabs, group, out=gathered)          # the exchange before fusion: 20 B/px, rank-major equal slabs
+    register(allm)
+    maps = {img: unpack_maps(allm[slab_index(k, world, n_local)], h, w) for k, img in enumerate(ids)}
     cap = capacity if capacity is not None else hw * len(ids) // 2
     cloud = ctx.fuse(ids, cap, **(fuse_kw or {}))          # replicated on every rank: identical clouds
     cloud["maps"] = maps

@@ -514,7 +514,6 @@ std::string dirname_of(const std::string& p) { const size_t k = p.find_last_of('
 #define HIPOK(call) do { if ((call) != hipSuccess) { fprintf(stderr, "error: %s failed\n", #call); return EXIT_FAILURE; } } while (0)
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-static bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 static std::string map_path(const std::string& dir, const char* fmt, uint32_t id) { char nm[96]; snprintf(nm, sizeof nm, fmt, id); return dir + nm; }
 
 namespace {
@@ -646,21 +645,22 @@ int main(int argc, char** argv) {
 	}
 	hcmvs_ctx* ctx = nullptr;
 	if (hcmvs_create(o.device, &ctx) != HCMVS_OK) { fprintf(stderr, "error: no usable MI355X device (there is no CPU path)\n"); return EXIT_FAILURE; }
-	// decode + resize + gray conversion of the images and the view selection of every image, all cores, one work list: image i is
-	// item i, its view selection item N + i (every item writes only its own image; the selection reads cameras and sizes only,
-	// SceneDensify.cpp:3590-3634 is an OpenMP loop too).  An image goes to the device as soon as it is decoded.
+	// the view selection of every image, all cores (every image writes only its own lists; the selection reads cameras and sizes,
+	// no pixels; SceneDensify.cpp:3590-3634 is an OpenMP loop too)
 	std::vector<char> selected(images.size(), 0);
+#pragma omp parallel for schedule(dynamic, 1)
+	for (long i = 0; i < (long)images.size(); ++i)
+		if (images[i].valid) selected[i] = select_views(images, verts, (uint32_t)i, 12, o.numberViews) ? 1 : 0;
+	// decode + resize + gray conversion of the images on all cores; an image goes to the device as soon as it is decoded.  Runs
+	// AFTER the loader thread below has started: the triangulated initial maps need cameras and sparse points only, so the first
+	// batch's initialisation overlaps the decoding.
 	std::string loadError;
-	{
-		std::mutex upMu;
+	std::mutex upMu; std::condition_variable upCv;
+	bool uploadsDone = false;
+	auto load_images = [&]() {
 		const long N = (long)images.size();
 #pragma omp parallel for schedule(dynamic, 1)
-		for (long t = 0; t < 2 * N; ++t) {
-			if (t >= N) {
-				const long i = t - N;
-				if (images[i].valid) selected[i] = select_views(images, verts, (uint32_t)i, 12, o.numberViews) ? 1 : 0;
-				continue;
-			}
+		for (long t = 0; t < N; ++t) {
 			ImageData& im = images[t];
 			if (!im.valid) continue;
 			int fw = 0, fh = 0;
@@ -674,10 +674,9 @@ int main(int argc, char** argv) {
 			if (hcmvs_upload_view(ctx, im.id, im.w, im.h, gray.data(), bgr.data(), im.cam.K, im.cam.R, im.cam.C) != HCMVS_OK && loadError.empty())
 				loadError = std::string("upload of image '") + paths[t] + "' failed: " + hcmvs_last_error(ctx);
 		}
-	}
-	if (!loadError.empty()) { fprintf(stderr, "error: %s\n", loadError.c_str()); return EXIT_FAILURE; }
-	if (o.verbosity > 1) printf("Scene loaded: %zu images (%u calibrated), %zu sparse points\n", images.size(), nValid, verts.size());
-	const double tLoaded = now_s();
+		{ std::lock_guard<std::mutex> g(upMu); uploadsDone = true; }
+		upCv.notify_all();
+	};
 	std::vector<uint32_t> todo;
 	for (auto& im : images) {
 		if (!im.valid) continue;
@@ -696,30 +695,6 @@ int main(int argc, char** argv) {
 			printf(" (%zu shared points)\n", im.points.size());
 		}
 	}
-	// neighbours whose footprint scale differs by >= 15 % are resampled on the device and registered as views of their own
-	// (DepthData::ViewData::ScaleImage + Image::GetCamera, SceneDensify.cpp:372-374); one copy per (image, new size)
-	{
-		std::map<std::pair<uint32_t, std::pair<int, int>>, uint32_t> scaled;
-		uint32_t nextId = 0x8000;
-		for (uint32_t id : todo) {
-			ImageData& im = images[id];
-			im.srcImages = im.srcs;
-			for (size_t k = 0; k < im.srcs.size(); ++k) {
-				if (im.srcScale[k] == 1.f) continue;
-				const ImageData& sv = images[im.srcs[k]];
-				const std::pair<int, int> size((int)std::lrint((double)sv.w * im.srcScale[k]), (int)std::lrint((double)sv.h * im.srcScale[k]));
-				const auto key = std::make_pair(sv.id, size);
-				auto it = scaled.find(key);
-				if (it == scaled.end()) {
-					if (nextId >= 65536) { fprintf(stderr, "error: too many resampled neighbour views\n"); return EXIT_FAILURE; }
-					CHK(hcmvs_rescale_view(ctx, sv.id, nextId, im.srcScale[k]));
-					if (o.verbosity > 2) printf("Image %3u resampled by %.2f to %dx%d as view %u\n", sv.id, im.srcScale[k], size.first, size.second, nextId);
-					it = scaled.emplace(key, nextId++).first;
-				}
-				im.srcs[k] = it->second;
-			}
-		}
-	}
 	hcmvs_params prm;
 	hcmvs_default_params(&prm);
 	prm.adapthalfwin = o.adaptHalfWin; prm.n_estimation_iters = o.estimationIters; prm.n_external_iters = o.estimationItersExternal;
@@ -731,7 +706,7 @@ int main(int argc, char** argv) {
 		size_t freeB = 0, totalB = 0, maxPx = 0, allPx = 0;
 		HIPOK(hipMemGetInfo(&freeB, &totalB));
 		for (uint32_t id : todo) { const size_t px = (size_t)images[id].w * images[id].h; maxPx = std::max(maxPx, px); allPx += px; }
-		const size_t resident = allPx * (size_t)(20 + 16 + (o.restoreHypothesis ? 16 : 0)) + ((size_t)2 << 30);
+		const size_t resident = allPx * (size_t)(20 + 16 + 8 + (o.restoreHypothesis ? 16 : 0)) + ((size_t)2 << 30); // nothing is uploaded yet
 		while (o.batch > 1 && resident + (size_t)o.batch * maxPx * 24 > freeB) o.batch /= 2;
 		if (o.verbosity > 2) printf("Batch of %d reference images per launch (%.1f GiB of device memory free)\n", o.batch, freeB / 1073741824.0);
 	}
@@ -801,6 +776,7 @@ int main(int argc, char** argv) {
 				for (uint32_t idx : im.points) { pts.push_back(verts[idx].X[0]); pts.push_back(verts[idx].X[1]); pts.push_back(verts[idx].X[2]); }
 				M.d.assign(n, 0.f); M.n.assign(3 * n, 0.f);
 				if (o.minViewsTrustPoint < 2) {
+					{ std::unique_lock<std::mutex> g(upMu); upCv.wait(g, [&] { return uploadsDone; }); } // the splat helper looks the view up in the context
 					if (hcmvs_splat_init(ctx, im.id, pts.data(), (int32_t)im.points.size(), M.d.data(), M.n.data(), &im.dMin, &im.dMax) != HCMVS_OK) M.failed = 1;
 				} else if (o.initTriangulate || o.restoreHypothesis) { // the `restore` binary always triangulates (restore/libs/MVS/SceneDensify.cpp:508-511)
 					if (hcmvs_triangulate_points(im.w, im.h, im.cam.K, im.cam.R, im.cam.C, pts.data(), (int32_t)im.points.size(), 0.f, 1, M.d.data(), M.n.data(),
@@ -874,6 +850,34 @@ int main(int argc, char** argv) {
 	};
 	std::thread loaderThread(loader);
 	struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } loaderJoin{loaderThread};
+	load_images();
+	if (!loadError.empty()) { fprintf(stderr, "error: %s\n", loadError.c_str()); return EXIT_FAILURE; }
+	if (o.verbosity > 1) printf("Scene loaded: %zu images (%u calibrated), %zu sparse points\n", images.size(), nValid, verts.size());
+	const double tLoaded = now_s();
+	// neighbours whose footprint scale differs by >= 15 % are resampled on the device and registered as views of their own
+	// (DepthData::ViewData::ScaleImage + Image::GetCamera, SceneDensify.cpp:372-374); one copy per (image, new size)
+	{
+		std::map<std::pair<uint32_t, std::pair<int, int>>, uint32_t> scaled;
+		uint32_t nextId = 0x8000;
+		for (uint32_t id : todo) {
+			ImageData& im = images[id];
+			im.srcImages = im.srcs;
+			for (size_t k = 0; k < im.srcs.size(); ++k) {
+				if (im.srcScale[k] == 1.f) continue;
+				const ImageData& sv = images[im.srcs[k]];
+				const std::pair<int, int> size((int)std::lrint((double)sv.w * im.srcScale[k]), (int)std::lrint((double)sv.h * im.srcScale[k]));
+				const auto key = std::make_pair(sv.id, size);
+				auto it = scaled.find(key);
+				if (it == scaled.end()) {
+					if (nextId >= 65536) { fprintf(stderr, "error: too many resampled neighbour views\n"); return EXIT_FAILURE; }
+					CHK(hcmvs_rescale_view(ctx, sv.id, nextId, im.srcScale[k]));
+					if (o.verbosity > 2) printf("Image %3u resampled by %.2f to %dx%d as view %u\n", sv.id, im.srcScale[k], size.first, size.second, nextId);
+					it = scaled.emplace(key, nextId++).first;
+				}
+				im.srcs[k] = it->second;
+			}
+		}
+	}
 
 	// ---- the saver: copies + files of the final maps, behind the estimation ----
 	Saver sv;
@@ -999,11 +1003,8 @@ int main(int argc, char** argv) {
 			}
 			CHK(hcmvs_set_fuse_order(ctx, o.fuseOrder));
 			uint64_t filledAll = 0;
-			for (uint32_t id : work) {
-				uint64_t filled = 0;
-				CHK(hcmvs_postfilter(ctx, id, ord.data(), (int32_t)ord.size(), std::min<int>(o.numberViewsFuse, (int)images.size()), 0.01f, 25.f, 7, &filled));
-				filledAll += filled;
-			}
+			CHK(hcmvs_postfilter_sequence(ctx, work.data(), (int32_t)work.size(), ord.data(), (int32_t)ord.size(), std::min<int>(o.numberViewsFuse, (int)images.size()),
+			                              0.01f, 25.f, 7, &filledAll));
 			tPostfilter += now_s() - tp;
 			if (o.verbosity > 1) printf("Depth-maps filtered after outer iteration %d: fuse-consistency mask + gap interpolation, %llu pixels filled (%.2f s)\n", it,
 			                            (unsigned long long)filledAll, now_s() - tp);

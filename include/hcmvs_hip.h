@@ -96,7 +96,9 @@ int hcmvs_synchronize(hcmvs_ctx* ctx);
 
 /* register view `id` (any number < 65536): host buffers are copied to the device.  bgr (B,G,R u8) is
  * optional: it feeds the gradient map exactly as the reference does (SceneDensify.cpp:586) and the fused
- * colours; without it the gradient map is taken from round(gray*255). */
+ * colours; without it the gradient map is taken from round(gray*255).  gray may be NULL when bgr is given: such a view can be
+ * filtered and fused (camera, colours, gradient map) but not estimated or matched against -- what a rank of a multi-GPU job
+ * holds of the images the other ranks estimate. */
 int hcmvs_upload_view(hcmvs_ctx* ctx, uint32_t id, int32_t width, int32_t height, const float* gray,
                       const uint8_t* bgr_or_null, const double K[9], const double R[9], const double C[3]);
 /* same, but gray/bgr already live in device memory and stay owned by the caller */
@@ -229,6 +231,11 @@ int hcmvs_fuse(hcmvs_ctx* ctx, const uint32_t* order, int32_t n_order, int32_t n
  * n_filled: pixels the two interpolation passes wrote. */
 int hcmvs_postfilter(hcmvs_ctx* ctx, uint32_t id, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
                      float normal_diff_deg, int32_t gap_size, uint64_t* n_filled);
+/* The same for the images ids[0 .. n_ids) one after the other -- what the reference does over all images of an outer iteration
+ * (SceneDensify.cpp:3939-3958); identical in effect to n_ids calls of hcmvs_postfilter in that order (every image's fusion sees the
+ * maps the images before it left), with the per-call set-up paid once.  n_filled: total over the images. */
+int hcmvs_postfilter_sequence(hcmvs_ctx* ctx, const uint32_t* ids, int32_t n_ids, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse,
+                              float depth_diff_threshold, float normal_diff_deg, int32_t gap_size, uint64_t* n_filled);
 
 /* The fused cloud with everything PointCloud holds (PointCloud.h: points, pointViews, pointWeights, colors, normals).
  * Host buffers owned by the caller; any optional pointer may be NULL.  The view lists are stored back to back (CSR): point p's

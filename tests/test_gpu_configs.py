@@ -165,7 +165,7 @@ def test_config2_scene_64x1080p(tmp_path):
         t1 = time.time()
         r = subprocess.run([EXE, "-i", scene_path, "-o", os.path.join(tmp, "dense%d.mvs" % order), "--resolution-level", "0", "--number-views", "8",
                             "--n-EstimationIters", "8", "--n-EstimationIters-external", "1", "--n-adapthalfwin", "6", "--n-photometric_flow", "0",
-                            "--batch", "32", "-v", "2", "--fuse-order", str(order)], capture_output=True, text=True, timeout=1500)
+                            "-v", "2", "--fuse-order", str(order), "--resume", "0"], capture_output=True, text=True, timeout=1500)
         walls[order] = time.time() - t1
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         m = re.search(r"(\d+) depth-maps, (\d+) depths, (\d+) points.* in ([\d.]+) s", r.stdout)
@@ -177,6 +177,9 @@ def test_config2_scene_64x1080p(tmp_path):
         est = re.search(r"Depth-maps estimated: (\d+) images.* in ([\d.]+) s \(([\d.]+) Mpix/s", r.stdout)
         print("config2: fuse order %d: driver wall %.1f s; estimation %s s (%s Mpix/s); fusion %.2f s, %d points of %d depths" % (
             order, walls[order], est.group(2), est.group(3), counts[order][2], counts[order][1], counts[order][0]))
+        for ln in r.stdout.splitlines():
+            if ln.startswith(("Depth-maps estimated", "Scene, point cloud", "Scene loaded")):
+                print("config2:   ", ln)
     assert abs(counts[1][1] - counts[0][1]) <= 0.01 * counts[0][1]        # hashed order within 1 % of the reference's order
     acc = []
     for i in range(0, N, 8):

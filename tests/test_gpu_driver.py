@@ -118,6 +118,16 @@ def test_densify_driver_resolution_level_and_errors(tmp_path):
     assert r.returncode != 0 and "usage" in r.stderr
 
 
+def wipe(tmp):
+    """remove every depth map a run left in the working folder (depth%04u.dmap and the hand-off pair)"""
+    import shutil
+    for f in os.listdir(tmp):
+        if f.endswith(".dmap"):
+            os.remove(os.path.join(tmp, f))
+    for d in ("depthmap", "normalmap"):
+        shutil.rmtree(os.path.join(tmp, d), ignore_errors=True)
+
+
 def _accuracy(tmp, views, thr=0.01):
     acc = []
     for i, v in enumerate(views):
@@ -136,7 +146,7 @@ def test_densify_driver_coarse_to_fine_handoff(tmp_path):
     in the working folder, the next finer run starts from them (cubic resize) instead of the sparse points"""
     tmp = str(tmp_path)
     scene, views = make_scene(tmp, w=384, h=256, n_views=5)
-    common = ["--number-views", "4", "--fusion-mode", "1", "--n-EstimationIters-external", "1", "-v", "3"]
+    common = ["--number-views", "4", "--fusion-mode", "1", "--n-EstimationIters-external", "1", "-v", "3", "--resume", "0"]
     r = subprocess.run([EXE, "-i", scene, "--resolution-level", "1", "--min-resolution", "100", "--n-EstimationIters", "4"] + common, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert mvsio.read_dmap(os.path.join(tmp, "depth0000.dmap"))["depth"].shape == (128, 192)
@@ -151,24 +161,25 @@ def test_densify_driver_coarse_to_fine_handoff(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     tri = _accuracy(tmp, views)
     assert handoff is not None and handoff > 0.7 and handoff >= tri - 0.02
+    # the hand-off pair the next stage of run.sh moves (DepthMap.h:76-80, SceneDensify.cpp:3984-3988) is written beside depth%04u.dmap
+    hd = mvsio.read_dmap(os.path.join(tmp, "depthmap", "depth0000.dmap"))
+    assert hd["depth"].shape == (256, 384) and "normal" not in hd and np.array_equal(hd["depth"], mvsio.read_dmap(os.path.join(tmp, "depth0000.dmap"))["depth"])
+    assert os.path.exists(os.path.join(tmp, "normalmap", "normal0000.dmap"))
     # the `restore` binary's extra last-sweep hypothesis from the previous level (restore/libs/MVS/DepthMap.cpp:1527-1549,
     # restore/libs/MVS/SceneDensify.cpp:508-532): triangulated init + the coarser level's maps as one more hypothesis
-    for f in os.listdir(tmp):
-        if f.endswith(".dmap"):
-            os.remove(os.path.join(tmp, f))
+    wipe(tmp)
     r = subprocess.run([EXE, "-i", scene, "--resolution-level", "1", "--min-resolution", "100", "--n-EstimationIters", "4"] + common, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0
     r = subprocess.run([EXE, "-i", scene, "--resolution-level", "0", "--n-initTriangulate", "1", "--restore-hypothesis", "1", "--n-EstimationIters", "1"] + common,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     restore = _accuracy(tmp, views)
-    # the extra hypothesis wins even when it scores up to 0.1 worse (that is the variant's rule), so a coarser-level estimate
-    # can displace a finer one: the result is a different, still accurate map
-    assert restore > 0.7 and abs(restore - tri) > 1e-4
+    # the extra hypothesis wins even when it scores up to 0.1 worse (that is the variant's rule, restore/.../DepthMap.cpp:1542), so a
+    # coarser-level estimate can displace a finer one: the result is a different map that may be a little less accurate -- bounded
+    # from below; the hypothesis itself is checked bit for bit in test_gpu_estimate.py::test_restore_variant_hint_hypothesis
+    assert restore > 0.7 and restore >= tri - 0.06 and abs(restore - tri) > 1e-4
     # missing previous level -> clean error
-    for f in os.listdir(tmp):
-        if f.endswith(".dmap"):
-            os.remove(os.path.join(tmp, f))
+    wipe(tmp)
     r = subprocess.run([EXE, "-i", scene, "--resolution-level", "0", "--n-initTriangulate", "0"] + common, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "previous level" in r.stderr
 
@@ -178,7 +189,7 @@ def test_densify_driver_init_modes(tmp_path):
     """triangulated init (default, DepthMap.cpp:1796-1936) vs splat init (nMinViewsTrustPoint < 2, SceneDensify.cpp:783-808)"""
     tmp = str(tmp_path)
     scene, views = make_scene(tmp, w=256, h=192, n_views=4)
-    common = ["--resolution-level", "0", "--number-views", "3", "--fusion-mode", "1", "--n-EstimationIters", "2", "--n-EstimationIters-external", "1"]
+    common = ["--resolution-level", "0", "--number-views", "3", "--fusion-mode", "1", "--n-EstimationIters", "2", "--n-EstimationIters-external", "1", "--resume", "0"]
     acc = {}
     for name, extra in (("tri", []), ("splat", ["--min-views-trust-point", "1"])):
         r = subprocess.run([EXE, "-i", scene] + common + extra, capture_output=True, text=True, timeout=600)
@@ -312,3 +323,96 @@ def test_densify_driver_with_the_authors_command_line(tmp_path):
     assert good >= len(views) - 2, good
     ply = mvsio.read_ply(out[:-4] + ".ply")
     assert len(ply["x"]) > 10000 and "nx" in ply.dtype.names
+
+
+@pytest.mark.gpu
+def test_densify_driver_resume_and_noptimize(tmp_path):
+    """skip-if-exists resume (SceneDensify.cpp:3865-3880: an image whose depth map is already in the working folder is loaded, not
+    estimated) and --n-nOptimize as the gate of the post-filters (DepthMap.h:113-118 OPTIMIZE = REMOVE_SPECKLES | FILL_GAPS,
+    SceneDensify.cpp:3916; CLI default 2, DensifyPointCloud.cpp:164)"""
+    tmp = str(tmp_path)
+    scene, views = make_scene(tmp, w=256, h=192, n_views=5)
+    out = os.path.join(tmp, "dense.mvs")
+    common = [EXE, "-i", scene, "-o", out, "--resolution-level", "0", "--number-views", "4", "--n-EstimationIters", "2", "--n-EstimationIters-external", "3", "-v", "2"]
+    r = subprocess.run(common, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "filtered after outer iteration 1" in r.stdout and "filtered after outer iteration 2" in r.stdout and "loaded from" not in r.stdout   # default 2: on
+    ply = open(out[:-4] + ".ply", "rb").read()
+    maps = {i: open(os.path.join(tmp, "depth%04d.dmap" % i), "rb").read() for i in range(5)}
+    # run again: everything is resumed, nothing is estimated, the cloud is the same
+    r = subprocess.run(common, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.count("loaded from") == 5 and "Depth-maps estimated: 0 images (5 resumed)" in r.stdout, r.stdout
+    assert open(out[:-4] + ".ply", "rb").read() == ply
+    # one map lost (an interrupted run): only that image is estimated again; the others are not touched
+    os.remove(os.path.join(tmp, "depth0002.dmap"))
+    before = {i: os.path.getmtime(os.path.join(tmp, "depth%04d.dmap" % i)) for i in (0, 1, 3, 4)}
+    r = subprocess.run(common, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.count("loaded from") == 4 and "Depth-maps estimated: 1 images (4 resumed)" in r.stdout, r.stdout
+    assert all(os.path.getmtime(os.path.join(tmp, "depth%04d.dmap" % i)) == t for i, t in before.items())
+    assert os.path.exists(os.path.join(tmp, "depth0002.dmap"))
+    # --resume 0 estimates everything again and reproduces the first run bit for bit (same seeds, same schedule-independent maps)
+    r = subprocess.run(common + ["--resume", "0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "loaded from" not in r.stdout
+    assert all(open(os.path.join(tmp, "depth%04d.dmap" % i), "rb").read() == maps[i] for i in range(5)) and open(out[:-4] + ".ply", "rb").read() == ply
+    # --n-nOptimize: 0 (and 4: neither of the two bits) skips the post-filters, 1 / 2 / 3 run them; --n-postfilter overrides
+    for val, on in (("0", False), ("4", False), ("1", True), ("3", True)):
+        r = subprocess.run(common + ["--resume", "0", "--fusion-mode", "1", "--n-nOptimize", val], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and ("Depth-maps filtered after outer iteration" in r.stdout) == on, (val, r.stdout)
+        assert "--n-nOptimize" not in r.stderr
+    r = subprocess.run(common + ["--resume", "0", "--fusion-mode", "1", "--n-nOptimize", "0", "--n-postfilter", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Depth-maps filtered after outer iteration" in r.stdout
+
+
+@pytest.mark.gpu
+def test_hc_five_stage_schedule(tmp_path):
+    """HC-MVS's own schedule (/root/reference/run.sh:1-23): pyramid levels 3 -> 2 -> 2 -> 1 -> 1, alternating the `frame_main` binary
+    (data/frame_main/resize*/run.py: 4 outer x 3 inner sweeps, photometric_flow 0.26, --n-nOptimize 1; --n-initTriangulate 1 at the
+    first stage, 0 afterwards = start from the maps handed over) and the `restore` binary (data/restore/resize*/run.py: 3 x 3 sweeps,
+    photometric_flow 0.2, --n-nOptimize 0; triangulated start + the previous level's maps as the extra hypothesis), every stage in
+    its own working folder, the hand-off being the `mv depthmap normalmap` of run.sh.  The scene is 1024 px wide, so the levels are
+    128, 256, 256, 512 and 512 px.  No reference output exists (parity unpinned): every stage must run from the folders the stage
+    before left, and the accuracy against the analytic ground truth must not drop from stage to stage."""
+    import shutil
+    tmp = str(tmp_path)
+    scene, views = make_scene(tmp, w=1024, h=768, n_views=6)
+    px = 10.0 / (300.0 * 1024 / 256)
+    surface = synth.Scene(4, min_wavelength=3.5 * px, max_wavelength=150 * px)   # the scene make_scene renders (synth.make_views, seed 4)
+
+    def scene_at(K, v, w, h):
+        return surface.render(np.asarray(K, np.float64), v["R"], v["C"], w, h)
+    assert np.abs(scene_at(views[0]["K"], views[0], 1024, 768)[1] - views[0]["depth"]).max() < 1e-4
+    common = ["--number-views", "5", "--n-EstimationIters", "3", "--n-adapthalfwin", "7", "--n-propagatehalfwin", "5", "--n-propagatestep", "4",
+              "--min-resolution", "64", "-v", "2"]
+    frame_main = ["--n-EstimationIters-external", "4", "--n-photometric_flow", "0.26", "--n-nOptimize", "1"]
+    restore = ["--restore-hypothesis", "1", "--n-EstimationIters-external", "3", "--n-photometric_flow", "0.2", "--n-nOptimize", "0"]
+    stages = [("frame_main", 3, frame_main + ["--n-initTriangulate", "1"]), ("restore", 2, restore), ("frame_main", 2, frame_main + ["--n-initTriangulate", "0"]),
+              ("restore", 1, restore), ("frame_main", 1, frame_main + ["--n-initTriangulate", "0"])]
+    acc, prev = [], None
+    for k, (binary, level, flags) in enumerate(stages):
+        wd = os.path.join(tmp, "%s_resize%d" % (binary, level))
+        os.makedirs(wd)
+        if prev:   # run.sh: mv depthmap /.../mvs ; mv normalmap /.../mvs
+            shutil.move(os.path.join(prev, "depthmap"), os.path.join(wd, "depthmap"))
+            shutil.move(os.path.join(prev, "normalmap"), os.path.join(wd, "normalmap"))
+        last = k == len(stages) - 1
+        r = subprocess.run([EXE, "-i", scene, "-w", wd, "-o", os.path.join(wd, "scene_dense.mvs"), "--resolution-level", str(level),
+                            "--fusion-mode", "0" if last else "1"] + common + flags, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, "stage %d (%s, level %d):\n%s%s" % (k, binary, level, r.stdout[-2000:], r.stderr[-2000:])
+        assert ("filtered after outer iteration 1" in r.stdout) == (binary == "frame_main")
+        good = []
+        for i, v in enumerate(views):
+            dm = mvsio.read_dmap(os.path.join(wd, "depth%04d.dmap" % i))
+            h, w = dm["depth"].shape
+            assert max(w, h) == 1024 >> level
+            m = dm["depth"] > 0
+            # ground truth at this level: the analytic surface seen through the camera the driver wrote
+            _, gt, _ = scene_at(dm["K"], v, w, h)
+            good.append(float(((np.abs(dm["depth"] - gt) / gt < 0.01) & m).mean()))
+        acc.append(float(np.mean(good)))
+        prev = wd
+    print("HC schedule: fraction of pixels within 1 % of ground truth per stage:", [round(a, 3) for a in acc])
+    assert acc[0] > 0.4 and acc[-1] > 0.75
+    for a, b in zip(acc, acc[1:]):
+        assert b >= a - 0.02, acc
+    ply = mvsio.read_ply(os.path.join(prev, "scene_dense.ply"))
+    assert len(ply["x"]) > 50000

@@ -238,3 +238,44 @@ def test_postfilter_gradient_ratio_literal(ctx, pairs):
     assert np.array_equal(d, dd[0]) and np.array_equal(n, nd) and np.array_equal(c, cd)
     for y in rows:
         assert ((d[y, x0 + 1:x1] > 0).all() if pairs == [(20, 21)] else (d[y, x0 + 1:x1] == 0).all())
+
+
+def test_postfilter_sequence_equals_image_after_image(ctx):
+    """hcmvs_postfilter_sequence (all passes of a fusion enqueued without host synchronisation, one synchronisation per image)
+    against the oracle run image after image, as the reference does over an outer iteration (SceneDensify.cpp:3939-3958): every
+    image's fusion sees the maps the images before it left.  Depth, normal, confidence of every image: bit for bit."""
+    maps, order = make_maps(w=144, h=112, f=130.0, n_views=5, noise=0.002, outliers=0.05, holes=0.12)
+    for m in maps:
+        m["conf"] = np.where(m["depth"] > 0, 1.3 - m["conf"], 0).astype(np.float32)
+    upload(ctx, maps)
+    seq = [3, 0, 4, 1, 2]
+    cur = [dict(m) for m in maps]
+    total = 0
+    for vid in seq:
+        dd, nd, cd, filled = O.postfilter(cur, vid, ctx.gradient_map(vid), order, mode=O.ARITH_DEVICE)
+        total += filled
+        for i in range(len(cur)):
+            cur[i]["depth"] = dd[i]
+        cur[vid]["normal"] = nd; cur[vid]["conf"] = cd
+    assert ctx.postfilter_sequence(seq, order) == total > 500
+    for i in range(len(maps)):
+        d, n, c = ctx.get_depthmap(i, with_normal=True)
+        assert np.array_equal(d, cur[i]["depth"]) and np.array_equal(n, cur[i]["normal"]) and np.array_equal(c, cur[i]["conf"]), i
+    # the same through single calls ...
+    upload(ctx, maps)
+    assert sum(ctx.postfilter(v, order) for v in seq) == total
+    for i in range(len(maps)):
+        assert np.array_equal(ctx.get_depthmap(i)[0], cur[i]["depth"])
+    # ... and with the link lists starting far too small: a fusion finds out on the device, is undone from its snapshot and runs again
+    import os
+    os.environ["HCMVS_FUSE_LINKS_INIT"] = "64"
+    try:
+        c2 = binding.Context(0)
+        upload(c2, maps)
+        assert c2.postfilter_sequence(seq, order) == total
+        for i in range(len(maps)):
+            d, n, c = c2.get_depthmap(i, with_normal=True)
+            assert np.array_equal(d, cur[i]["depth"]) and np.array_equal(n, cur[i]["normal"]) and np.array_equal(c, cur[i]["conf"]), i
+        c2.close()
+    finally:
+        del os.environ["HCMVS_FUSE_LINKS_INIT"]

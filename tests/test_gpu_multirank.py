@@ -24,7 +24,7 @@ def _scene():
     return base, views, srcs, neighbors, order
 
 
-def _run(rank, world, port, ret):
+def _run(rank, world, port, ret, outer=1, postfilter=False):
     import torch
     import torch.distributed as dist
     binding = importlib.import_module("hc-mvs_amd.binding")
@@ -43,8 +43,8 @@ def _run(rank, world, port, ret):
         for i in order:
             pts = synth.sparse_points([base[i]], 120, seed=40 + i)
             init[i] = ctx.splat_init(i, pts)
-        p = binding.default_params(adapthalfwin=6, n_estimation_iters=3, seed=900)
-        cloud = D.densify_scene(ctx, views, srcs, neighbors, order, init, p, device=torch.device("cuda", 0))
+        p = binding.default_params(adapthalfwin=6, n_estimation_iters=3 if outer == 1 else 2, seed=900, propagate_halfwin=5, propagate_step=4)
+        cloud = D.densify_scene(ctx, views, srcs, neighbors, order, init, p, device=torch.device("cuda", 0), n_external_iters=outer, postfilter=postfilter)
         ret[rank] = (cloud["n_points"], cloud["n_depths"], cloud["xyz"].tobytes(), cloud["n_views"].tobytes(),
                      {i: cloud["maps"][i][0].cpu().numpy().tobytes() for i in order})
         ctx.close()
@@ -68,3 +68,27 @@ def test_two_ranks_produce_the_single_rank_cloud():
     # fusion mutates the gathered depth maps (SceneDensify.cpp:3447-3449) identically on every rank
     for i in single[0][4]:
         assert ret[0][4][i] == ret[1][4][i] == single[0][4][i]
+
+
+def test_two_ranks_outer_iterations_with_postfilters():
+    """the authors' schedule shape across ranks -- three outer iterations (cross pattern from the second on),
+    the fork's post-filters after outer iterations 1 and 2 (an all-gather each, the filter replicated on every rank), then the
+    all-gather before fusion.  A rank registers the images it neither estimates nor matches against WITHOUT their gray image.
+    Cloud and final maps of both ranks == the single-rank run, bit for bit."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    single = mgr.dict()
+    mp.spawn(_run, args=(1, 0, single, 3, True), nprocs=1, join=True)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ret = mgr.dict()
+    mp.spawn(_run, args=(2, port, ret, 3, True), nprocs=2, join=True)
+    assert len(ret) == 2 and single[0][0] > 2000
+    for r in (0, 1):
+        assert ret[r][0] == single[0][0] and ret[r][1] == single[0][1]
+        assert ret[r][2] == single[0][2] and ret[r][3] == single[0][3]
+    for i in single[0][4]:
+        assert ret[0][4][i] == ret[1][4][i] == single[0][4][i]
+    # and the post-filters did act: the same schedule without them gives another cloud
+    plain = mgr.dict()
+    mp.spawn(_run, args=(1, 0, plain, 3, False), nprocs=1, join=True)
+    assert plain[0][2] != single[0][2]
