@@ -354,9 +354,10 @@ struct FusePass {
 __global__ void fuse_seed_kernel(FuseTables tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl, const uint32_t* abort) {
 	if (abort && abort[1] != 0u) return;
 	const uint32_t nPending = ctl[4];
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nPending; i += gridDim.x * blockDim.x) {
-		const uint32_t idx = pending[i];
-		if (tb.cntP[idx] == 0u) queue[atomicAdd(ctl, 1u)] = idx;
+	const uint32_t nPad = (nPending + 63u) & ~63u; // whole waves take part in list_append (one atomic per wave, not per pixel)
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nPad; i += gridDim.x * blockDim.x) {
+		const uint32_t idx = i < nPending ? pending[i] : 0u;
+		list_append(i < nPending && tb.cntP[idx] == 0u, (int)idx, queue, ctl);
 	}
 }
 
@@ -397,7 +398,18 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 		else st_u32(&fp.queue[atomicAdd(qTail, 1u)], v);
 	};
 	unsigned accepted = 0, decided = 0, viewEntries = 0;
-	uint32_t item = FS_EMPTY, slot = atomicAdd(qHead, 1u); // the pixel I run next; the queue slot I wait on
+	// queue slots are taken by the wave, not by the lane: one atomic on the (single, hot) head word for all the lanes that need one
+	auto take_slots = [&](bool want, uint32_t& slot_) {
+		const unsigned long long wm = __ballot(want);
+		if (wm == 0ull) return;
+		const int leader = __builtin_ctzll(wm);
+		uint32_t base = 0u;
+		if (lane == leader) base = atomicAdd(qHead, (uint32_t)__builtin_popcountll(wm));
+		base = (uint32_t)__shfl((int)base, leader, 64);
+		if (want) slot_ = base + (uint32_t)__builtin_popcountll(wm & ((1ull << lane) - 1ull));
+	};
+	uint32_t item = FS_EMPTY, slot = FS_EMPTY; // the pixel I run next; the queue slot I wait on
+	take_slots(true, slot);
 	unsigned spins = 0;
 	for (;;) {
 		uint32_t polled = FS_EMPTY;
@@ -490,7 +502,7 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 			if (++spins > (1u << 22)) { st_u32(errFlag, 1u); break; } // bounded: never hang the device
 			__builtin_amdgcn_s_sleep(8);
 		}
-		if (item == FS_EMPTY && slot == FS_EMPTY) slot = atomicAdd(qHead, 1u);
+		take_slots(item == FS_EMPTY && slot == FS_EMPTY, slot);
 	}
 	if (decided) atomicAdd(nDone, decided);
 	if (accepted) { atomicAdd(&counters[3], (unsigned long long)accepted); atomicAdd(&counters[4], (unsigned long long)viewEntries); }

@@ -469,7 +469,7 @@ __device__ __forceinline__ void make_homography(const EstConst& c, const float (
 // DepthMap.cpp:522-606 ScorePixelImage up to the ZNCC sums, all views at once: every lane warps and samples its taps of
 // its own view through H (the homography of the lane's view), the partial sums are combined inside the view group.
 // (1) warp every tap, (2) issue all loads, (3) interpolate + accumulate.  The inside-the-image test (Types.h:1633-1635)
-// is done once on the min/max of the warped coordinates; a lane with a tap outside skips (2) and (3) altogether.
+// is done on the two end taps of the lane's column (see below); a lane that fails it skips (2) and (3) altogether.
 // NR: as in fill_patch_n -- steps >= NR are zero-weight repeats of step NR - 1 in every lane and are skipped; the grouped
 // reciprocal still multiplies the repeated denominators, so every remaining tap gets the same bits as with all steps.
 // REDUCE = false: the lane's own partial sums are returned (the sweep parks them in LDS and adds them up once per chunk of
@@ -509,13 +509,17 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 			if constexpr (MAXM > 6) iz[6] = r67 * z7;
 			if constexpr (MAXM > 7) iz[7] = r67 * z6;
 		}
-		float qxlo = __builtin_huge_valf(), qxhi = -__builtin_huge_valf(), qylo = __builtin_huge_valf(), qyhi = -__builtin_huge_valf();
 #pragma unroll
-		for (int m = 0; m < MAXM; ++m) {
-			qx[m] = Xx[m] * iz[m]; qy[m] = Xy[m] * iz[m];
-			qxlo = fminf(qxlo, qx[m]); qxhi = fmaxf(qxhi, qx[m]); qylo = fminf(qylo, qy[m]); qyhi = fmaxf(qyhi, qy[m]);
-		}
-		bad = nan || !(qxlo >= 1.f && qylo >= 1.f && qxhi <= L.wmax && qyhi <= L.hmax);
+		for (int m = 0; m < MAXM; ++m) { qx[m] = Xx[m] * iz[m]; qy[m] = Xy[m] * iz[m]; }
+		// The inside-the-image test (Types.h:1633-1635) on the two END taps of the lane's column only: the column is a straight
+		// segment of the reference patch, a homography maps it to a straight segment as long as the depth z keeps its sign along
+		// it (z is affine in the step, so the two ends decide that too), and both image coordinates are monotone along such a
+		// segment -- if the ends lie inside the (convex) image, so does everything between them.  A column whose ends see z of
+		// opposite signs is treated as leaving the image.  Device association; the reference tests every tap.
+		constexpr int e = MAXM - 1;
+		const bool ends = qx[0] >= 1.f && qy[0] >= 1.f && qx[0] <= L.wmax && qy[0] <= L.hmax &&
+		                  qx[e] >= 1.f && qy[e] >= 1.f && qx[e] <= L.wmax && qy[e] <= L.hmax;
+		bad = nan || !ends || !(Xz[0] * Xz[e] > 0.f);
 	}
 	// Only lanes whose taps all lie inside the image (Types.h:1633-1635) sample it: their texel addresses need no clamping, and
 	// a lane with a tap outside contributes nothing but the NaN that turns its view's score into thRobust below.
@@ -534,10 +538,10 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 			const unsigned off = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 4);
 #if defined(HCMVS_ABL) && HCMVS_ABL == 1 /* diagnostic ablation: no gather loads (results are wrong) */
 			const float fake = (float)(off & 255u) * (1.f / 255.f);
-			top[m] = make_float2(fake, fake * 0.9f);
-			bot[m] = make_float2(fake * 0.8f, fake * 0.7f);
+			top[m] = make_float2(fake, fake * -0.1f);
+			bot[m] = make_float2(fake * 0.8f, fake * -0.1f);
 #else
-			const f32x4 fp = *(const HC_GLOBAL f32x4*)(imgBase + off);
+			const f32x4 fp = *(const HC_GLOBAL f32x4*)(imgBase + off); // (I00, I10 - I00, I01, I11 - I01), see quad_kernel
 			top[m] = make_float2(fp.x, fp.y);
 			bot[m] = make_float2(fp.z, fp.w);
 #endif
@@ -546,9 +550,9 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 		st.get_w(Pw, Ptw);
 #pragma unroll
 		for (int m = 0; m < MAXM; ++m) {
-			// bilinear sample (Types.inl:2250-2258) in lerp form
-			const float t = fmaf(fx[m], top[m].y - top[m].x, top[m].x);
-			const float b = fmaf(fx[m], bot[m].y - bot[m].x, bot[m].x);
+			// bilinear sample (Types.inl:2250-2258) in lerp form; the horizontal differences come ready from the footprint layout
+			const float t = fmaf(fx[m], top[m].y, top[m].x);
+			const float b = fmaf(fx[m], bot[m].y, bot[m].x);
 			const float val = fmaf(fy[m], b - t, t);
 			const float vw = val * Pw[m];
 			a = a + vw;
@@ -604,8 +608,8 @@ __device__ __forceinline__ void score_taps_big(const EstConst& c, const LaneCtx<
 		for (int u = 0; u < CH; ++u) {
 			if (m0 + u >= MB) continue;
 			const int k = (m0 + u) * S + L.seg;
-			const float t = fmaf(fx[u], tv[u].y - tv[u].x, tv[u].x);
-			const float b = fmaf(fx[u], bv[u].y - bv[u].x, bv[u].x);
+			const float t = fmaf(fx[u], tv[u].y, tv[u].x);
+			const float b = fmaf(fx[u], bv[u].y, bv[u].x);
 			const float val = fmaf(fy[u], b - t, t);
 			const float vw = val * bw[2][k];
 			a = a + vw;
@@ -1595,15 +1599,18 @@ __global__ void gradient_kernel(const uint8_t* g, uint8_t* gra, int W, int H) {
 	if ((s2 & 1) && (r & 1)) r += 1;
 	gra[y * W + x] = (uint8_t)(r > 255 ? 255 : r);
 }
-// The layout the scorer gathers from: per pixel the 2 x 2 footprint of a bilinear sample, (I(x,y), I(x+1,y), I(x,y+1), I(x+1,y+1))
-// (Types.inl:2250-2258 reads exactly these four), so that one 16-byte load serves a sample; the last column / row repeat
-// (never sampled: positions are inside the image with a border of 1, Types.h:1633-1635).  Four times the bytes of the image --
-// HBM is sized for it -- and the same number of cache lines per wave-instruction as two 8-byte gathers from two rows.
+// The layout the scorer gathers from: per pixel the 2 x 2 footprint of a bilinear sample (Types.inl:2250-2258 reads I(x,y), I(x+1,y),
+// I(x,y+1), I(x+1,y+1)) as (I00, I10 - I00, I01, I11 - I01): one 16-byte load serves a sample, and the two horizontal differences
+// of the lerp form are taken here, once per texel, instead of once per sample -- the same IEEE subtraction of the same operands,
+// so the sample's bits do not change.  The last column / row repeat (never sampled: positions are inside the image with a border
+// of 1, Types.h:1633-1635).  Four times the bytes of the image -- HBM is sized for it -- and the same number of cache lines per
+// wave-instruction as two 8-byte gathers from two rows.
 __global__ void quad_kernel(const float* g, float4* out, int W, int H) {
 	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
 	if (x >= W || y >= H) return;
 	const int x1 = x + 1 < W ? x + 1 : W - 1, y1 = y + 1 < H ? y + 1 : H - 1;
-	out[(size_t)y * W + x] = make_float4(g[(size_t)y * W + x], g[(size_t)y * W + x1], g[(size_t)y1 * W + x], g[(size_t)y1 * W + x1]);
+	const float i00 = g[(size_t)y * W + x], i10 = g[(size_t)y * W + x1], i01 = g[(size_t)y1 * W + x], i11 = g[(size_t)y1 * W + x1];
+	out[(size_t)y * W + x] = make_float4(i00, i10 - i00, i01, i11 - i01);
 }
 __global__ void median3_kernel(const float* in, float* out, int W, int H) {
 	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;

@@ -733,9 +733,18 @@ static float score_view_dev(const est_ctx* c, const pix_state* ps, int v, float 
 			iz[4] = r45 * Xz[5]; iz[5] = r45 * Xz[4]; iz[6] = r67 * Xz[7]; iz[7] = r67 * Xz[6];
 		}
 		float sum = 0, sumSq = 0, num = 0;
+		int colOk = 1;
+		if (!big) {
+			/* device association of the inside test: a lane holds one patch COLUMN; a homography maps that segment to a segment
+			 * as long as z keeps its sign along it (z is affine in the step: the two ends decide), and both coordinates are
+			 * monotone along it, so the two end taps are tested instead of every tap (the reference: every tap, DM.cpp:566) */
+			const int e = nside - 1; /* the column's last REAL row (steps past it repeat it; their reciprocals come out of another branch of the product tree) */
+			colOk = inside_border1(im, Xx[0] * iz[0], Xy[0] * iz[0]) && inside_border1(im, Xx[e] * iz[e], Xy[e] * iz[e]) && Xz[0] * Xz[e] > 0.f;
+			if (!colOk) { ok = 0; p0[s] = p1[s] = p2[s] = 0; continue; }
+		}
 		for (int m = 0; m < MAXM; ++m) {
 			const float qx = Xx[m] * iz[m], qy = Xy[m] * iz[m];
-			if (!inside_border1(im, qx, qy)) { ok = 0; continue; }
+			if (big && !inside_border1(im, qx, qy)) { ok = 0; continue; }
 			if (!vv[m]) continue; /* clamped duplicate of a real tap: zero weight */
 			const int k = kk[m];
 			const float val = sample_dev(im, qx, qy);

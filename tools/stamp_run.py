@@ -5,8 +5,9 @@ import numpy as np, torch
 binding = importlib.import_module("hc-mvs_amd.binding")
 binding.LIB_PATH = binding.LIB_PATH.replace("libhcmvs_hip.so", "libhcmvs_hip_stamps.so")
 synth = importlib.import_module("hc-mvs_amd.synth")
-W, H, F, V, I = 1920, 1080, 1600.0, 8, 4
+W, H, F, V = 1920, 1080, 1600.0, 8
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+I = int(sys.argv[2]) if len(sys.argv) > 2 else 4   # sweeps (bench.py: 8)
 dev = torch.device("cuda:0")
 ctx = binding.Context(0)
 items, keep = [], []
