@@ -52,7 +52,7 @@ typedef struct hcmvs_ctx hcmvs_ctx;
 
 /* replaces the OPTDENSE globals read on this path; hcmvs_default_params() fills the reference defaults */
 typedef struct {
-	int32_t adapthalfwin;           /* --n-adapthalfwin 1..7, patch half window (DepthMap.cpp:455-461) */
+	int32_t adapthalfwin;           /* --n-adapthalfwin 1..10, patch half window (DepthMap.cpp:455-461; beyond 7 = more than the reference's 64 taps) */
 	int32_t n_estimation_iters;     /* --n-EstimationIters, inner sweeps (SceneDensify.cpp:949) */
 	int32_t it_external;            /* outer iteration index of this call (SceneDensify.cpp:758) */
 	int32_t n_external_iters;       /* --n-EstimationIters-external; the end pass runs on the last one */
