@@ -16,11 +16,11 @@ struct DevMap {
 	uint32_t id;
 	int32_t w, h, nNeighbors;
 	double K[9], R[9], C[3], P[12]; // P = K [R | -R C] (Camera.h:276-282)
-	float* depth;            // mutated by fusion (SceneDensify.cpp:3447-3449)
+	float* depth;            // mutated by fusion (SceneDensify.cpp:3447-3449); while a fusion runs a NEGATIVE depth marks an estimate that is
+	                         // part of a point (SceneDensify.cpp:3313 arrDepthIdx); launch_unclaim() restores the sign
 	const float* normal;     // camera space, may be null
 	const float* conf;
 	const uint8_t* bgr;      // may be null
-	uint32_t* claim;         // SceneDensify.cpp:3313 arrDepthIdx: NO_ID or claimed
 	const uint32_t* neighbors; // device array of image ids, decreasing importance
 	float dMin, dMax;
 };
@@ -54,12 +54,12 @@ void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_
 // small -> every later kernel of the fusion returns at once, [2] the size needed), null for the synchronous path
 void launch_fuse_links_check(const FuseTables& tb, unsigned long long capLinks, uint32_t* status, hipStream_t s);
 void launch_fuse_status(const uint32_t* ctl, uint32_t* status, hipStream_t s);
-void launch_reset_claims(const DevMap* maps, int nMaps, hipStream_t s);
+void launch_unclaim(const DevMap* maps, int nMaps, hipStream_t s); // takes the claim marks (negative depths) off every map
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
                       uint32_t* merged, int nMinViewsFuse, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, const uint32_t* abort,
                       hipStream_t s);
-void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const uint32_t* claim, const uint8_t* gra, float* dF, float* nF,
+void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const DevMap* maps, int nMaps, const uint8_t* gra, float* dF, float* nF,
                        int gap, float thr, unsigned long long* filled, const uint32_t* abort, hipStream_t s);
 void launch_point_colors(unsigned long long n, const float* xyz, const unsigned long long* voff, const uint32_t* views, const DevMap* maps, uint8_t* bgr, hipStream_t s);
 size_t fuse_scan_temp_bytes(int n);

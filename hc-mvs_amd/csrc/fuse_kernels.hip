@@ -22,6 +22,10 @@
  *     no co-residency assumption: one dependent hop costs a body plus one atomic instead of a whole round.
  *     Pixels sharing a target are decided in raster order, so the cloud is identical to the sequential one,
  *     point order included (ordered compaction).
+ *     "Claimed" (SceneDensify.cpp:3313 arrDepthIdx != NO_ID) is the SIGN of the depth while a fusion runs: an estimate that became
+ *     part of a point holds -depth, an invalidated one 0, a free one +depth -- one 4-byte load tells a pixel everything about a
+ *     target (depth and claim were two scattered loads from two maps; the pass is bound by exactly those), and there are no claim
+ *     maps to allocate and reset.  launch_unclaim() takes the signs off again when the fusion is over.
  *
  * Double precision follows the reference (Point3 = double); no contraction (-ffp-contract=off).
  */
@@ -240,7 +244,7 @@ __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, u
 		if (idx < n) {
 			if (A.depth[idx] != 0.f) {
 				++nd;
-				pend = A.claim[idx] == NO_ID;
+				pend = A.depth[idx] > 0.f; // valid and not part of a point yet
 			}
 			flag[idx] = 0;
 		}
@@ -254,7 +258,7 @@ __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, u
 				int32_t t = -1;
 				if (B.depth && project_target(B, point, ptz, ib, xB, yB)) {
 					const float depthB = B.depth[ib];
-					if (depthB != 0.f && B.claim[ib] == NO_ID) {
+					if (depthB > 0.f) { // valid and free
 						int cls = 0;
 						if (is_depth_similar(ptz, depthB, thDepth)) {
 							float normalB[3] = {0.f, 0.f, -1.f};
@@ -330,12 +334,16 @@ __global__ void fuse_status_kernel(const uint32_t* ctl, uint32_t* status) {
 	if (blockIdx.x != 0 || threadIdx.x != 0 || status[1] != 0u) return;
 	if (ctl[3] != 0u || ctl[2] != ctl[4]) status[0] = 1u;
 }
-__global__ void reset_claims_kernel(const DevMap* maps, int nMaps) {
+// the end of a fusion: the claim marks (negative depths) come off every map
+__global__ void unclaim_kernel(const DevMap* maps, int nMaps) {
 	for (int m = blockIdx.y; m < nMaps; m += gridDim.y) {
-		uint32_t* cl = maps[m].claim;
-		if (!cl || !maps[m].depth) continue;
+		float* d = maps[m].depth;
+		if (!d) continue;
 		const size_t n = (size_t)maps[m].w * maps[m].h;
-		for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) cl[i] = 0xFFFFFFFFu;
+		for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+			const float v = d[i];
+			if (v < 0.f) d[i] = -v;
+		}
 	}
 }
 struct FusePass {
@@ -380,13 +388,12 @@ template <int MAXV>
 __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* maps, FusePass fp, FuseOut out, const uint32_t* pending,
                                                         unsigned long long* counters) {
 	__shared__ float* depthOf[MAXV - 1];
-	__shared__ uint32_t* claimOf[MAXV - 1];
 	__shared__ uint32_t ring[kFuseRing];
 	__shared__ uint32_t ringCnt;
 	if (fp.abort && fp.abort[1] != 0u) return; // wave-uniform
 	const int nNb = A.nNeighbors;
 	const int lane = threadIdx.x;
-	if (lane < nNb) { const DevMap& B = maps[A.neighbors[lane]]; depthOf[lane] = B.depth; claimOf[lane] = B.claim; }
+	if (lane < nNb) { const DevMap& B = maps[A.neighbors[lane]]; depthOf[lane] = B.depth; }
 	if (lane == 0) ringCnt = 0u;
 	__syncthreads();
 	const FuseTables& tb = fp.tb;
@@ -424,14 +431,14 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 			int32_t t[MAXV - 1];
 #pragma unroll
 			for (int j = 0; j < MAXV - 1; ++j) t[j] = j < nNb ? tg[j] : -1;
+			const float dA = A.depth[idx]; // my own estimate: nobody else writes it during my image's pass
 			// round trip B
-			float dB[MAXV - 1]; uint32_t clB[MAXV - 1];
+			float dB[MAXV - 1];
 #pragma unroll
 			for (int j = 0; j < MAXV - 1; ++j) {
-				dB[j] = 0.f; clB[j] = 0u;
+				dB[j] = 0.f;
 				if (t[j] < 0) continue;
-				dB[j] = ld_f32(depthOf[j] + (t[j] & kTargetIndexMask));
-				clB[j] = ld_u32(claimOf[j] + (t[j] & kTargetIndexMask));
+				dB[j] = ld_f32(depthOf[j] + (t[j] & kTargetIndexMask)); // > 0 free, < 0 part of a point, 0 invalidated
 			}
 			uint32_t rel[8];
 #pragma unroll
@@ -440,15 +447,15 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 			uint32_t merge = 0u, inFront = 0u;
 #pragma unroll
 			for (int j = 0; j < MAXV - 1; ++j) {
-				if (t[j] < 0 || dB[j] == 0.f || clB[j] != NO_ID) continue;
+				if (t[j] < 0 || !(dB[j] > 0.f)) continue;
 				if ((t[j] >> kTargetShift) == kTargetMerge) merge |= 1u << j; else inFront |= 1u << j;
 			}
 			const int nv = 1 + __builtin_popcount(merge);
 			if (nv >= fp.nMinViewsFuse) { // a point: claim the merged estimates, remove the ones in front of it
-				st_u32(&A.claim[idx], 0u);
+				st_f32(&A.depth[idx], -dA);
 #pragma unroll
 				for (int j = 0; j < MAXV - 1; ++j) {
-					if (merge >> j & 1u) st_u32(claimOf[j] + (t[j] & kTargetIndexMask), 0u);
+					if (merge >> j & 1u) st_f32(depthOf[j] + (t[j] & kTargetIndexMask), -dB[j]);
 					if (inFront >> j & 1u) st_f32(depthOf[j] + (t[j] & kTargetIndexMask), 0.f);
 				}
 				out.nviews[idx] = (uint32_t)nv;
@@ -520,7 +527,7 @@ __global__ void fuse_points_kernel(DevMap A, const DevMap* maps, FuseTables tb, 
 		const int idx = (int)pending[i];
 		if (!out.flag[idx]) continue;
 		const uint32_t merge = merged[idx];
-		const float depth = A.depth[idx];
+		const float depth = fabsf(A.depth[idx]); // the pixels of a point carry the claim mark (negative depth) until the fusion ends
 		float point[3];
 		pixel_point(A, idx, depth, point);
 		uint32_t vimg[MAXV]; float vwt[MAXV]; int nv = 0;
@@ -538,7 +545,7 @@ __global__ void fuse_points_kernel(DevMap A, const DevMap* maps, FuseTables tb, 
 			const DevMap& B = maps[A.neighbors[q]];
 			const int ib = tb.targets[(size_t)idx * nNb + q] & kTargetIndexMask;
 			const int yB = ib / B.w, xB = ib - yB * B.w;
-			const float depthB = B.depth[ib];
+			const float depthB = fabsf(B.depth[ib]);
 			float normalB[3] = {0.f, 0.f, -1.f};
 			if (B.normal) rotate_normal(B, B.normal + 3 * (size_t)ib, normalB);
 			const float confB = conf2weight(B.conf[ib], depthB);
@@ -648,11 +655,12 @@ __global__ void point_colors_kernel(unsigned long long n, const float* xyz, cons
 // the lines of a pass are independent), then the merge (SceneDensify.cpp:2989-3000).  The third, per-pixel pass of the
 // reference (SceneDensify.cpp:2717-2983) reads uninitialised variables and is not reproduced.
 
-__global__ void postfilter_mask_kernel(int n, const float* depth, const float* normal, const uint32_t* claim, float* dF, float* nF, const uint32_t* abort) {
+// runs BEFORE the claim marks come off: a negative depth = the pixel ended up in a fused point
+__global__ void postfilter_mask_kernel(int n, const float* depth, const float* normal, float* dF, float* nF, const uint32_t* abort) {
 	if (abort && abort[1] != 0u) return;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const bool on = claim[i] != NO_ID;
-		dF[i] = on ? depth[i] : 0.f;
+		const bool on = depth[i] < 0.f;
+		dF[i] = on ? -depth[i] : 0.f;
 		for (int k = 0; k < 3; ++k) nF[3 * i + k] = on ? normal[3 * i + k] : 0.f;
 	}
 }
@@ -714,16 +722,18 @@ __global__ void postfilter_merge_kernel(int n, float* depth, float* normal, cons
 		if (a != 0.f || b != 0.f || c != 0.f) { normal[3 * i] = a; normal[3 * i + 1] = b; normal[3 * i + 2] = c; }
 	}
 }
-void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const uint32_t* claim, const uint8_t* gra, float* dF, float* nF,
+// the image's own maps still carry the claim marks of the fusion that has just run; `maps` = all maps, unmarked after the mask is taken
+void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const DevMap* maps, int nMaps, const uint8_t* gra, float* dF, float* nF,
                        int gap, float thr, unsigned long long* filled, const uint32_t* abort, hipStream_t s) {
 	const int n = w * h;
-	hipLaunchKernelGGL(postfilter_mask_kernel, kGrid, kBlock, 0, s, n, depth, normal, claim, dF, nF, abort);
+	hipLaunchKernelGGL(postfilter_mask_kernel, kGrid, kBlock, 0, s, n, depth, normal, dF, nF, abort);
+	launch_unclaim(maps, nMaps, s);
 	hipLaunchKernelGGL(gap_lines_kernel, dim3((h + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, h, w, (size_t)w, (size_t)1, gap, thr, filled, abort);   // rows
 	hipLaunchKernelGGL(gap_lines_kernel, dim3((w + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, w, h, (size_t)1, (size_t)w, gap, thr, filled, abort);   // columns
 	hipLaunchKernelGGL(postfilter_merge_kernel, kGrid, kBlock, 0, s, n, depth, normal, dF, nF, abort);
 }
-void launch_reset_claims(const DevMap* maps, int nMaps, hipStream_t s) {
-	hipLaunchKernelGGL(reset_claims_kernel, dim3(256, nMaps < 1024 ? (nMaps > 0 ? nMaps : 1) : 1024), dim3(256), 0, s, maps, nMaps);
+void launch_unclaim(const DevMap* maps, int nMaps, hipStream_t s) {
+	hipLaunchKernelGGL(unclaim_kernel, dim3(256, nMaps < 1024 ? (nMaps > 0 ? nMaps : 1) : 1024), dim3(256), 0, s, maps, nMaps);
 }
 void launch_fuse_links_check(const FuseTables& tb, unsigned long long capLinks, uint32_t* status, hipStream_t s) {
 	hipLaunchKernelGGL(fuse_links_check_kernel, dim3(1), dim3(64), 0, s, tb, capLinks, status);

@@ -43,7 +43,7 @@ struct View {
 	float *mDepth = nullptr, *mNormal = nullptr, *mConf = nullptr;
 	bool mapsOwned = false;
 	float dMin = 0.f, dMax = 0.f;
-	uint32_t *claim = nullptr, *dNeighbors = nullptr;
+	uint32_t* dNeighbors = nullptr;
 	std::vector<uint32_t> neighbors;
 };
 
@@ -92,6 +92,8 @@ struct hcmvs_ctx {
 	std::vector<FuseLane> fuseLanes; // per-pass scratch of the concurrent fusion passes
 	bool errPending = false; // an estimate was enqueued since the error word was last read
 	int nCU = 0;          // compute units of the device (fusion worker count)
+	hipEvent_t upEv[2] = {nullptr, nullptr};
+	char* pinned = nullptr; size_t capPinned = 0; // page-locked staging of the host-buffer uploads (a pageable hipMemcpy crawls at ~1.3 GB/s here)
 	int wavesPerRow = 0; // 0 = automatic: 3 waves per row for one image, 2 for two (latency), 1 when >= 3 images fill the chip
 };
 
@@ -206,8 +208,7 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 
 static void free_maps(View& v) {
 	if (v.mapsOwned) for (void* p : {(void*)v.mDepth, (void*)v.mNormal, (void*)v.mConf}) if (p) (void)hipFree(p);
-	if (v.claim) (void)hipFree(v.claim);
-	v.mDepth = v.mNormal = v.mConf = nullptr; v.claim = nullptr; v.mapsOwned = false;
+	v.mDepth = v.mNormal = v.mConf = nullptr; v.mapsOwned = false;
 }
 static void free_view(View& v) {
 	if (v.owned) { if (v.gray) (void)hipFree(v.gray); if (v.bgr) (void)hipFree(v.bgr); }
@@ -233,6 +234,8 @@ void hcmvs_destroy(hcmvs_ctx* c) {
 		if (L.stream) (void)hipStreamDestroy(L.stream);
 	}
 	for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+	if (c->pinned) (void)hipHostFree(c->pinned);
+	for (auto& e : c->upEv) if (e) (void)hipEventDestroy(e);
 	if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
 	delete c;
 }
@@ -263,6 +266,46 @@ int hcmvs_synchronize(hcmvs_ctx* c) {
 	return check_sweep_error(c);
 }
 
+// host -> device through the context's page-locked staging buffer, in pieces: the caller's buffer is pageable, and a pageable
+// hipMemcpy is an order of magnitude slower than memcpy + a pinned transfer
+static int upload_staged(hcmvs_ctx* c, void* dst, const void* src, size_t bytes) {
+	{ // a caller that already holds the data in page-locked memory (hipHostMalloc / hipHostRegister) needs no staging
+		hipPointerAttribute_t at;
+		if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost) {
+			HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			return HCMVS_OK;
+		}
+		(void)hipGetLastError(); // pageable memory is "invalid value" to the query
+	}
+	const size_t piece = (size_t)32 << 20;
+	if (c->capPinned < 2 * piece) {
+		if (c->pinned) (void)hipHostFree(c->pinned);
+		c->pinned = nullptr; c->capPinned = 0;
+		if (hipHostMalloc((void**)&c->pinned, 2 * piece, hipHostMallocDefault) != hipSuccess) { // no pinned memory to be had: the plain copy
+			(void)hipGetLastError();
+			HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			return HCMVS_OK;
+		}
+		c->capPinned = 2 * piece;
+	}
+	for (auto& e : c->upEv) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	hipEvent_t done[2] = {c->upEv[0], c->upEv[1]};
+	bool used[2] = {false, false};
+	int k = 0;
+	for (size_t off = 0; off < bytes; off += piece, k ^= 1) {
+		const size_t n = std::min(piece, bytes - off);
+		if (used[k]) HIPCHK(c, hipEventSynchronize(done[k])); // the half I am about to overwrite has left
+		memcpy(c->pinned + (size_t)k * piece, (const char*)src + off, n);
+		HIPCHK(c, hipMemcpyAsync((char*)dst + off, c->pinned + (size_t)k * piece, n, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipEventRecord(done[k], c->stream));
+		used[k] = true;
+	}
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return HCMVS_OK;
+}
+
 static int set_view(hcmvs_ctx* c, uint32_t id, int w, int h, const float* gray, const uint8_t* bgr, const double* K,
                     const double* R, const double* C, bool copy) {
 	if (!c) return HCMVS_ERR_INVALID;
@@ -279,13 +322,14 @@ static int set_view(hcmvs_ctx* c, uint32_t id, int w, int h, const float* gray, 
 	if (copy) {
 		if (gray) {
 			HIPCHK(c, hipMalloc(&v.gray, n * sizeof(float)));
-			HIPCHK(c, hipMemcpyAsync(v.gray, gray, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+			const int rc = upload_staged(c, v.gray, gray, n * sizeof(float));
+			if (rc) return rc;
 		}
 		if (bgr) {
 			HIPCHK(c, hipMalloc(&v.bgr, n * 3));
-			HIPCHK(c, hipMemcpyAsync(v.bgr, bgr, n * 3, hipMemcpyHostToDevice, c->stream));
-		}
-		HIPCHK(c, hipStreamSynchronize(c->stream)); // the caller may free its host buffers on return
+			const int rc = upload_staged(c, v.bgr, bgr, n * 3);
+			if (rc) return rc;
+		} // (upload_staged has synchronised: the caller may free its host buffers on return)
 	} else {
 		v.gray = const_cast<float*>(gray);
 		v.bgr = const_cast<uint8_t*>(bgr);
@@ -758,18 +802,19 @@ static int set_maps(hcmvs_ctx* c, uint32_t id, const float* depth, const float* 
 	if (copy) {
 		HIPCHK(c, hipMalloc(&v.mDepth, n * 4));
 		HIPCHK(c, hipMalloc(&v.mConf, n * 4));
-		HIPCHK(c, hipMemcpy(v.mDepth, depth, n * 4, hipMemcpyHostToDevice));
-		HIPCHK(c, hipMemcpy(v.mConf, conf, n * 4, hipMemcpyHostToDevice));
+		int rc = upload_staged(c, v.mDepth, depth, n * 4);
+		if (!rc) rc = upload_staged(c, v.mConf, conf, n * 4);
+		if (rc) return rc;
 		if (normal) {
 			HIPCHK(c, hipMalloc(&v.mNormal, n * 12));
-			HIPCHK(c, hipMemcpy(v.mNormal, normal, n * 12, hipMemcpyHostToDevice));
+			rc = upload_staged(c, v.mNormal, normal, n * 12);
+			if (rc) return rc;
 		}
 		v.mapsOwned = true;
 	} else {
 		v.mDepth = const_cast<float*>(depth); v.mNormal = const_cast<float*>(normal); v.mConf = const_cast<float*>(conf);
 	}
 	v.dMin = dmin; v.dMax = dmax;
-	HIPCHK(c, hipMalloc(&v.claim, n * 4));
 	return HCMVS_OK;
 }
 int hcmvs_set_depthmap(hcmvs_ctx* c, uint32_t id, const float* depth, const float* normal, const float* conf, float d_min, float d_max) {
@@ -817,7 +862,7 @@ static void fill_devmap(uint32_t id, const View& v, DevMap& m) {
 		for (int j = 0; j < 3; ++j) m.P[i * 4 + j] = v.K[i * 3] * v.R[j] + v.K[i * 3 + 1] * v.R[3 + j] + v.K[i * 3 + 2] * v.R[6 + j];
 		m.P[i * 4 + 3] = v.K[i * 3] * t[0] + v.K[i * 3 + 1] * t[1] + v.K[i * 3 + 2] * t[2];
 	}
-	m.depth = v.mDepth; m.normal = v.mNormal; m.conf = v.mConf; m.bgr = v.bgr; m.claim = v.claim;
+	m.depth = v.mDepth; m.normal = v.mNormal; m.conf = v.mConf; m.bgr = v.bgr;
 	m.neighbors = v.dNeighbors; m.dMin = v.dMin; m.dMax = v.dMax;
 }
 // device table indexed by image id (views without maps have depth == null)
@@ -923,7 +968,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 		if (host[order[i]].nNeighbors > kFuseMaxViews - 1) return fail(c, HCMVS_ERR_INVALID, "fuse: view %u has too many neighbours", order[i]);
 	}
 	hipStream_t s = c->stream;
-	for (auto& m : host) if (m.depth) { launch_fill_u32(m.claim, 0xFFFFFFFFu, (size_t)m.w * m.h, s); }
+	launch_unclaim(c->dMaps, (int)host.size(), s); // no claim mark may be left over from a fusion that failed half way
 	int maxNb = 1;
 	size_t stride = maxArea; // pixels reserved per neighbour map in the per-target tables
 	for (int i = 0; i < n_order; ++i) maxNb = std::max(maxNb, (int)host[order[i]].nNeighbors);
@@ -1140,6 +1185,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	for (int i = 0; i < n_order; ++i) { total += sh.accepted[i]; viewTotal += wantCloud ? sh.entries[i] : 0; }
 	if (!viewCapacity) viewTotal = 0;
 	const unsigned long long depths = sh.depths;
+	launch_unclaim(c->dMaps, (int)host.size(), s); // every lane has synchronised its stream: the claim marks come off the depth maps
 	HIPCHK(c, hipGetLastError());
 	const auto tCopy = std::chrono::steady_clock::now();
 	if (wantCloud) HIPCHK(c, hipMemcpyAsync(xyz, cX, total * 12, hipMemcpyDeviceToHost, s));
@@ -1261,7 +1307,6 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 				size_t o = 0;
 				for (const auto& m : host) if (m.depth) { HIPCHK(c, hipMemcpyAsync(snap + o, m.depth, (size_t)m.w * m.h * 4, hipMemcpyDeviceToDevice, s)); o += (size_t)m.w * m.h; }
 			}
-			launch_reset_claims(c->dMaps, (int)host.size(), s);
 			for (int oi = 0; oi < n_order; ++oi) {
 				const DevMap& A = host[order[oi]];
 				const int n = A.w * A.h;
@@ -1278,7 +1323,7 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 				                 counters, blocks, nullptr, false, status, s);
 				launch_fuse_status(ctl, status, s);
 			}
-			launch_postfilter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, v.claim, v.gra, dF, nF, gap_size, depth_diff_threshold * 2.5f, counters + 5, status, s);
+			launch_postfilter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, c->dMaps, (int)host.size(), v.gra, dF, nF, gap_size, depth_diff_threshold * 2.5f, counters + 5, status, s);
 			HIPCHK(c, hipGetLastError());
 			uint32_t st[4] = {0, 0, 0, 0};
 			unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};

@@ -529,6 +529,31 @@ struct InitMaps { std::vector<float> d, n, hd, hn; int failed = 0; };
 // estimating), writer threads put them on disk.  The fusion mutates the depth maps (SceneDensify.cpp:3447-3449), so it waits for
 // the copies -- not for the files.
 struct SaveJob { uint32_t id; std::vector<float> d, n, c; };
+
+// host -> device through two page-locked buffers on a stream of its own: memcpy into one half while the other is on its way
+struct Uploader {
+	static constexpr size_t kPiece = (size_t)32 << 20;
+	hipStream_t s = nullptr; char* pin = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false}; int k = 0;
+	bool init() {
+		if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+		if (hipHostMalloc((void**)&pin, 2 * kPiece, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pin = nullptr; }
+		for (auto& e : ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+		return true;
+	}
+	bool copy(void* dst, const void* src, size_t bytes) {
+		if (!pin) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+		for (size_t off = 0; off < bytes; off += kPiece, k ^= 1) {
+			const size_t n = std::min(kPiece, bytes - off);
+			if (used[k] && hipEventSynchronize(ev[k]) != hipSuccess) return false;
+			memcpy(pin + (size_t)k * kPiece, (const char*)src + off, n);
+			if (hipMemcpyAsync((char*)dst + off, pin + (size_t)k * kPiece, n, hipMemcpyHostToDevice, s) != hipSuccess || hipEventRecord(ev[k], s) != hipSuccess) return false;
+			used[k] = true;
+		}
+		return true;
+	}
+	bool drain() { return hipStreamSynchronize(s) == hipSuccess; }
+	~Uploader() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } if (pin) (void)hipHostFree(pin); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+};
 struct Saver {
 	std::mutex mu; std::condition_variable cv;
 	std::deque<uint32_t> toCopy; std::deque<std::unique_ptr<SaveJob>> toWrite;
@@ -611,6 +636,11 @@ int main(int argc, char** argv) {
 	if (o.batch > HCMVS_MAX_BATCH) o.batch = HCMVS_MAX_BATCH;
 	if (o.estimationItersExternal < 1) o.estimationItersExternal = 1;
 
+	// the device context comes up (HIP runtime start, ~0.4 s) while the scene is read and the views are selected on the host
+	hcmvs_ctx* ctx = nullptr;
+	int createRc = HCMVS_OK;
+	std::thread createThread([&] { createRc = hcmvs_create(o.device, &ctx); });
+	struct CreateJoin { std::thread& t; ~CreateJoin() { if (t.joinable()) t.join(); } } createJoin{createThread};
 	std::vector<MvsPlatform> platforms; std::vector<MvsImage> mimages; std::vector<Vertex> verts;
 	if (!load_mvs(o.input, platforms, mimages, verts)) { fprintf(stderr, "error: can not load '%s'\n", o.input.c_str()); return EXIT_FAILURE; }
 	std::vector<ImageData> images(mimages.size());
@@ -643,8 +673,6 @@ int main(int argc, char** argv) {
 		im.valid = true;
 		++nValid;
 	}
-	hcmvs_ctx* ctx = nullptr;
-	if (hcmvs_create(o.device, &ctx) != HCMVS_OK) { fprintf(stderr, "error: no usable MI355X device (there is no CPU path)\n"); return EXIT_FAILURE; }
 	// the view selection of every image, all cores (every image writes only its own lists; the selection reads cameras and sizes,
 	// no pixels; SceneDensify.cpp:3590-3634 is an OpenMP loop too)
 	std::vector<char> selected(images.size(), 0);
@@ -667,16 +695,32 @@ int main(int argc, char** argv) {
 			std::vector<uint8_t> bgr;
 			if (!load_pnm(paths[t], fw, fh, bgr)) { std::lock_guard<std::mutex> g(upMu); loadError = "failed loading image '" + paths[t] + "'"; continue; }
 			if (fw != im.w || fh != im.h) resize_area_bgr(fw, fh, bgr, im.w, im.h);
-			std::vector<float> gray((size_t)im.w * im.h);
-			for (size_t k = 0; k < gray.size(); ++k) // Types.inl:2354-2400 toGray, normalised
+			// gray and colour image go into page-locked memory of this thread: what is left for the (serial) upload is the transfer
+			static thread_local struct Pinned { char* p = nullptr; size_t cap = 0; } pin; // lives as long as its thread; the process ends with them
+			const size_t px = (size_t)im.w * im.h, need = px * 4 + px * 3;
+			if (pin.cap < need) {
+				if (pin.p) (void)hipHostFree(pin.p);
+				pin.p = nullptr; pin.cap = 0;
+				if (hipSetDevice(o.device) == hipSuccess && hipHostMalloc((void**)&pin.p, need, hipHostMallocDefault) == hipSuccess) pin.cap = need;
+				else { (void)hipGetLastError(); pin.p = nullptr; }
+			}
+			std::vector<float> grayVec;
+			float* gray = (float*)pin.p;
+			uint8_t* bgrUp = pin.p ? (uint8_t*)(pin.p + px * 4) : bgr.data();
+			if (!pin.p) { grayVec.resize(px); gray = grayVec.data(); } // no page-locked memory to be had: the library stages the copy
+			else memcpy(bgrUp, bgr.data(), px * 3);
+			for (size_t k = 0; k < px; ++k) // Types.inl:2354-2400 toGray, normalised
 				gray[k] = (0.114f * bgr[3 * k] + 0.587f * bgr[3 * k + 1] + 0.299f * bgr[3 * k + 2]) / 255.f;
 			std::lock_guard<std::mutex> g(upMu); // one HIP stream: uploads one after the other, while the other cores decode
-			if (hcmvs_upload_view(ctx, im.id, im.w, im.h, gray.data(), bgr.data(), im.cam.K, im.cam.R, im.cam.C) != HCMVS_OK && loadError.empty())
+			if (hcmvs_upload_view(ctx, im.id, im.w, im.h, gray, bgrUp, im.cam.K, im.cam.R, im.cam.C) != HCMVS_OK && loadError.empty())
 				loadError = std::string("upload of image '") + paths[t] + "' failed: " + hcmvs_last_error(ctx);
 		}
 		{ std::lock_guard<std::mutex> g(upMu); uploadsDone = true; }
 		upCv.notify_all();
 	};
+	createThread.join();
+	if (createRc != HCMVS_OK) { fprintf(stderr, "error: no usable MI355X device (there is no CPU path)\n"); return EXIT_FAILURE; }
+	if (hipSetDevice(o.device) != hipSuccess) { fprintf(stderr, "error: hipSetDevice failed\n"); return EXIT_FAILURE; }
 	std::vector<uint32_t> todo;
 	for (auto& im : images) {
 		if (!im.valid) continue;
@@ -764,6 +808,8 @@ int main(int argc, char** argv) {
 	};
 	auto loader = [&]() {
 		if (hipSetDevice(o.device) != hipSuccess) { std::lock_guard<std::mutex> g(prepMu); prepError = "hipSetDevice failed in the loader"; prepCv.notify_all(); return; }
+		Uploader up; // page-locked staging: a pageable hipMemcpy of the initial maps (33 MB per 1080p image) crawls
+		if (!up.init()) { std::lock_guard<std::mutex> g(prepMu); prepError = "no copy stream for the loader"; prepCv.notify_all(); return; }
 		for (size_t b = 0; b < batches.size(); ++b) {
 			const std::vector<uint32_t>& ids = batches[b];
 			std::vector<InitMaps> maps(ids.size());
@@ -831,14 +877,13 @@ int main(int argc, char** argv) {
 				ImageData& im = images[ids[k]];
 				const size_t n = (size_t)im.w * im.h;
 				bool ok = hipMalloc(&im.dDepth, n * 4) == hipSuccess && hipMalloc(&im.dNormal, n * 12) == hipSuccess && hipMalloc(&im.dConf, n * 4) == hipSuccess &&
-				          hipMemcpy(im.dDepth, maps[k].d.data(), n * 4, hipMemcpyHostToDevice) == hipSuccess &&
-				          hipMemcpy(im.dNormal, maps[k].n.data(), n * 12, hipMemcpyHostToDevice) == hipSuccess && hipMemset(im.dConf, 0, n * 4) == hipSuccess;
+				          up.copy(im.dDepth, maps[k].d.data(), n * 4) && up.copy(im.dNormal, maps[k].n.data(), n * 12) && hipMemsetAsync(im.dConf, 0, n * 4, up.s) == hipSuccess;
 				if (ok && o.restoreHypothesis)
 					ok = hipMalloc(&im.dHintDepth, n * 4) == hipSuccess && hipMalloc(&im.dHintNormal, n * 12) == hipSuccess &&
-					     hipMemcpy(im.dHintDepth, maps[k].hd.data(), n * 4, hipMemcpyHostToDevice) == hipSuccess &&
-					     hipMemcpy(im.dHintNormal, maps[k].hn.data(), n * 12, hipMemcpyHostToDevice) == hipSuccess;
+					     up.copy(im.dHintDepth, maps[k].hd.data(), n * 4) && up.copy(im.dHintNormal, maps[k].hn.data(), n * 12);
 				if (!ok) { res.failed = 4; res.failedId = ids[k]; }
 			}
+			if (!res.failed && !up.drain()) { res.failed = 4; res.failedId = ids.empty() ? 0 : ids[0]; }
 			res.ready = true;
 			{
 				std::lock_guard<std::mutex> g(prepMu);

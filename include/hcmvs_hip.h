@@ -183,7 +183,8 @@ int hcmvs_resize_area_up(const float* src, int32_t src_w, int32_t src_h, int32_t
 int hcmvs_set_depthmap(hcmvs_ctx* ctx, uint32_t id, const float* depth, const float* normal_or_null,
                        const float* conf, float d_min, float d_max);
 /* same for maps that already live in device memory; d_depth is MUTATED by hcmvs_fuse like the reference does
- * (SceneDensify.cpp:3447-3449) */
+ * (SceneDensify.cpp:3447-3449).  Depths must be >= 0 (0 = no estimate): while a fusion or a post-filter runs, the sign of a depth
+ * marks the estimates that already belong to a point; it is restored before the call returns. */
 int hcmvs_set_depthmap_device(hcmvs_ctx* ctx, uint32_t id, float* d_depth, const float* d_normal_or_null,
                               const float* d_conf, float d_min, float d_max);
 /* read the (possibly mutated) maps back; any pointer may be NULL */
