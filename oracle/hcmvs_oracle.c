@@ -689,6 +689,14 @@ static float score_view_ref(const est_ctx* c, const pix_state* ps, int v, float 
 	return (1.f - c->p.photometric_flow) * s + c->p.photometric_flow * 0.f;
 }
 
+/* statistics of the device association's inside test (see score_view_dev) */
+static unsigned long long g_inside_cols, g_inside_differ;
+void hcor_inside_rule_stats(uint64_t* columns, uint64_t* differ, int reset) {
+	if (columns) *columns = __atomic_load_n(&g_inside_cols, __ATOMIC_RELAXED);
+	if (differ) *differ = __atomic_load_n(&g_inside_differ, __ATOMIC_RELAXED);
+	if (reset) { __atomic_store_n(&g_inside_cols, 0ull, __ATOMIC_RELAXED); __atomic_store_n(&g_inside_differ, 0ull, __ATOMIC_RELAXED); }
+}
+
 /* device association of the same computation */
 static void device_H(const est_ctx* c, const pix_state* ps, int v, float depth, const float* normal, float* H) {
 	const float n0 = normal[0], n1 = normal[1], n2 = normal[2];
@@ -740,6 +748,12 @@ static float score_view_dev(const est_ctx* c, const pix_state* ps, int v, float 
 			 * monotone along it, so the two end taps are tested instead of every tap (the reference: every tap, DM.cpp:566) */
 			const int e = nside - 1; /* the column's last REAL row (steps past it repeat it; their reciprocals come out of another branch of the product tree) */
 			colOk = inside_border1(im, Xx[0] * iz[0], Xy[0] * iz[0]) && inside_border1(im, Xx[e] * iz[e], Xy[e] * iz[e]) && Xz[0] * Xz[e] > 0.f;
+			{ /* how often the end-tap rule and the reference's every-tap rule disagree (hcor_inside_rule_stats, tests only) */
+				int all = 1;
+				for (int m = 0; m <= e; ++m) all = all && inside_border1(im, Xx[m] * iz[m], Xy[m] * iz[m]);
+				__atomic_fetch_add(&g_inside_cols, 1ull, __ATOMIC_RELAXED);
+				if (all != colOk) __atomic_fetch_add(&g_inside_differ, 1ull, __ATOMIC_RELAXED);
+			}
 			if (!colOk) { ok = 0; p0[s] = p1[s] = p2[s] = 0; continue; }
 		}
 		for (int m = 0; m < MAXM; ++m) {

@@ -86,6 +86,11 @@ void hcor_resize_gray(const float* src, int sw, int sh, float scale, float* dst,
  * (restore/libs/MVS/SceneDensify.cpp:523-524).  Restated from OpenCV 4.2's published source (parity unpinned). */
 void hcor_resize_area_up(const float* src, int sw, int sh, int ch, float* dst, int dw, int dh);
 
+/* The device association tests the two END taps of a patch column for "inside the image" (plus: z keeps its sign between them) where
+ * the reference tests every tap (DM.cpp:566).  Counters of the device-mode evaluations since the last reset: patch columns tested,
+ * and columns on which the two rules disagree. */
+void hcor_inside_rule_stats(uint64_t* columns, uint64_t* differ, int reset);
+
 /* ---- small pieces, exposed for known-answer tests ------------------------------------------- */
 
 /* DM.cpp:354-381 MapMatrix2ZigzagIdx (no mask). coords_xy: 2*w*h uint16 (x,y pairs). returns count */

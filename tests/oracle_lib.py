@@ -75,6 +75,7 @@ def lib():
         L.hcor_resize_size.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.hcor_resize_gray.argtypes = [fp, C.c_int, C.c_int, C.c_float, fp, C.c_int, C.c_int]
         L.hcor_resize_area_up.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+        L.hcor_inside_rule_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
         L.hcor_splat_init.argtypes = [C.POINTER(View), fp, C.c_int, fp, fp, fp, fp]
         L.hcor_fill_patch.argtypes = [C.POINTER(View), u8p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, fp, fp, fp, fp]
         L.hcor_fill_patch.restype = C.c_int

@@ -108,3 +108,21 @@ def test_fused_point_count_within_one_percent():
     print("bridge fused clouds (reference, device):", counts)
     assert abs(counts[0][0] - counts[1][0]) <= TOL["fused_points"] * counts[0][0]
     assert abs(counts[0][1] - counts[1][1]) <= 0.02 * counts[0][1]
+
+
+def test_end_tap_inside_rule_against_every_tap_rule():
+    """The device association tests the two end taps of a patch column for "inside the image with a border of 1" (Types.h:1633-1635)
+    plus "z keeps its sign between them"; the reference tests every tap (DepthMap.cpp:566).  In exact arithmetic the two are the same
+    (a homography maps the column to a segment along which both coordinates are monotone, the image is convex); in floats they could
+    part where an interior tap lands within an ulp of the border.  Counted over every device-mode evaluation of a scene whose
+    hypotheses do leave the image (small image, eight views, random start): no column disagrees."""
+    cols = C.c_uint64(); diff = C.c_uint64()
+    O.lib().hcor_inside_rule_stats(None, None, 1)
+    views = synth.make_views(96, 72, 80.0, 8, seed=21, baseline=(0.08, 0.2))
+    pts = synth.sparse_points(views, 40)
+    d0, n0, dmin, dmax = splat(views[0], pts)
+    p = O.default_params(arith_mode=O.ARITH_DEVICE, order=O.ORDER_ROWS, n_threads=8, adapthalfwin=6, n_estimation_iters=3)
+    O.estimate(views, p, dmin * 0.5, dmax * 2.0, d0, n0)        # a wide depth range: many hypotheses project outside
+    O.lib().hcor_inside_rule_stats(C.byref(cols), C.byref(diff), 1)
+    print("inside rule: %d patch columns tested, %d where the end-tap rule and the every-tap rule differ" % (cols.value, diff.value))
+    assert cols.value > 5e6 and diff.value == 0
