@@ -66,7 +66,11 @@ size_t fuse_scan_temp_bytes(int n);
 void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,
                          float* onormal, uint8_t* obgr, uint32_t* onv, unsigned long long base, unsigned long long capacity, float* xyz,
                          float* normal, uint8_t* bgr, uint32_t* nviews, uint32_t* oviews, float* oweights, int vstride, uint32_t* voff,
-                         unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights, hipStream_t s);
+                         unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights, const unsigned long long* bases,
+                         const uint32_t* abort, hipStream_t s);
+// unsynchronised fusion: totals [0] points, [1] view entries, [2] depths so far; status[3] = 1 / 2 when the cloud / the view lists overflow
+void launch_fuse_advance(const unsigned long long* counters, unsigned long long* totals, unsigned long long capacity, unsigned long long viewCapacity,
+                         uint32_t* status, hipStream_t s);
 
 } // namespace hcmvs
 #endif

@@ -334,6 +334,15 @@ __global__ void fuse_status_kernel(const uint32_t* ctl, uint32_t* status) {
 	if (blockIdx.x != 0 || threadIdx.x != 0 || status[1] != 0u) return;
 	if (ctl[3] != 0u || ctl[2] != ctl[4]) status[0] = 1u;
 }
+// after an image's compaction: the image's counts (counters[0] depths, [3] points, [4] view entries) join the running totals the
+// next image's compaction starts from; status[3] says that the cloud (1) or the view lists (2) do not fit
+__global__ void fuse_advance_kernel(const unsigned long long* counters, unsigned long long* totals, unsigned long long capacity,
+                                    unsigned long long viewCapacity, uint32_t* status) {
+	if (blockIdx.x != 0 || threadIdx.x != 0 || status[1] != 0u) return;
+	if (capacity && totals[0] + counters[3] > capacity) status[3] = 1u;
+	if (viewCapacity && totals[1] + counters[4] > viewCapacity) status[3] = 2u;
+	totals[0] += counters[3]; totals[1] += counters[4]; totals[2] += counters[0];
+}
 // the end of a fusion: the claim marks (negative depths) come off every map
 __global__ void unclaim_kernel(const DevMap* maps, int nMaps) {
 	for (int m = blockIdx.y; m < nMaps; m += gridDim.y) {
@@ -520,7 +529,8 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 // estimates are claimed, so nobody has changed them since the pass looked at them.
 template <int MAXV>
 __global__ void fuse_points_kernel(DevMap A, const DevMap* maps, FuseTables tb, const uint32_t* merged, FuseOut out, const uint32_t* pending,
-                                   const uint32_t* roundCnt) {
+                                   const uint32_t* roundCnt, const uint32_t* abort) {
+	if (abort && abort[1] != 0u) return;
 	const int nNb = A.nNeighbors;
 	const int nPending = (int)roundCnt[1];
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nPending; i += gridDim.x * blockDim.x) {
@@ -576,9 +586,13 @@ __global__ void fuse_points_kernel(DevMap A, const DevMap* maps, FuseTables tb, 
 }
 
 // ordered compaction of the accepted pixels of one pass into the cloud
+// bases: null, or the running totals of an unsynchronised fusion on the device ([0] points, [1] view entries before this image)
 __global__ void fuse_gather_kernel(int n, const uint8_t* flag, const uint32_t* pos, FuseOut out, unsigned long long base,
                                    unsigned long long capacity, float* xyz, float* normal, uint8_t* bgr, uint32_t* nviews,
-                                   const uint32_t* voff, unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights) {
+                                   const uint32_t* voff, unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights,
+                                   const unsigned long long* bases, const uint32_t* abort) {
+	if (abort && abort[1] != 0u) return;
+	if (bases) { base = bases[0]; viewBase = bases[1]; }
 	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
 		if (!flag[idx]) continue;
 		const unsigned long long o = base + pos[idx];
@@ -793,8 +807,8 @@ void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb,
 	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_pass_kernel<16>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
 	else hipLaunchKernelGGL(fuse_pass_kernel<32>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
 	if (!wantPoints) return;
-	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_points_kernel<16>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + 3);
-	else hipLaunchKernelGGL(fuse_points_kernel<32>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + 3);
+	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_points_kernel<16>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + 3, abort);
+	else hipLaunchKernelGGL(fuse_points_kernel<32>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + 3, abort);
 }
 size_t fuse_scan_temp_bytes(int n) {
 	size_t bytes = 0;
@@ -804,7 +818,8 @@ size_t fuse_scan_temp_bytes(int n) {
 void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,
                          float* onormal, uint8_t* obgr, uint32_t* onv, unsigned long long base, unsigned long long capacity, float* xyz,
                          float* normal, uint8_t* bgr, uint32_t* nviews, uint32_t* oviews, float* oweights, int vstride, uint32_t* voff,
-                         unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights, hipStream_t s) {
+                         unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights, const unsigned long long* bases,
+                         const uint32_t* abort, hipStream_t s) {
 	hipLaunchKernelGGL(flag_to_u32_kernel, kGrid, kBlock, 0, s, flag, flag32, n);
 	(void)hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, flag32, pos, n, s);
 	if (cviews) { // offsets of the accepted pixels' view lists inside this image's part of the CSR arrays
@@ -813,7 +828,11 @@ void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t*
 	}
 	FuseOut out{oxyz, onormal, obgr, onv, const_cast<uint8_t*>(flag), oviews, oweights, vstride};
 	hipLaunchKernelGGL(fuse_gather_kernel, kGrid, kBlock, 0, s, n, flag, pos, out, base, capacity, xyz, normal, bgr, nviews, voff, viewBase, viewCapacity,
-	                   cviews, cweights);
+	                   cviews, cweights, bases, abort);
+}
+void launch_fuse_advance(const unsigned long long* counters, unsigned long long* totals, unsigned long long capacity, unsigned long long viewCapacity,
+                         uint32_t* status, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_advance_kernel, dim3(1), dim3(64), 0, s, counters, totals, capacity, viewCapacity, status);
 }
 
 } // namespace hcmvs

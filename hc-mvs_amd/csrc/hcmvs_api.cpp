@@ -93,6 +93,7 @@ struct hcmvs_ctx {
 	bool errPending = false; // an estimate was enqueued since the error word was last read
 	int nCU = 0;          // compute units of the device (fusion worker count)
 	hipEvent_t upEv[2] = {nullptr, nullptr};
+	char* snap = nullptr; size_t capSnap = 0; // unsynchronised fusion: status words, running totals, snapshot of the depth maps
 	char* pinned = nullptr; size_t capPinned = 0; // page-locked staging of the host-buffer uploads (a pageable hipMemcpy crawls at ~1.3 GB/s here)
 	int wavesPerRow = 0; // 0 = automatic: 3 waves per row for one image, 2 for two (latency), 1 when >= 3 images fill the chip
 };
@@ -235,6 +236,7 @@ void hcmvs_destroy(hcmvs_ctx* c) {
 	}
 	for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->pinned) (void)hipHostFree(c->pinned);
+	if (c->snap) (void)hipFree(c->snap);
 	for (auto& e : c->upEv) if (e) (void)hipEventDestroy(e);
 	if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
 	delete c;
@@ -1044,6 +1046,108 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	}
 	HIPCHK(c, hipStreamSynchronize(s)); // claims reset, tables uploaded: the lanes may start
 	const auto tPasses = std::chrono::steady_clock::now();
+	const bool debug = getenv("HCMVS_FUSE_DEBUG") != nullptr;
+	if (!getenv("HCMVS_FUSE_LANES") && !debug) {
+		// The default: every pass of the fusion enqueued on the context's stream, no host synchronisation between the images
+		// (stream order is the order of the sequential loop).  What the lanes below ask the host for is kept on the device: the
+		// size of a pass's link lists (checked there: when they do not fit every later kernel returns at once, the depth maps
+		// are put back from a snapshot, the lists grow and the fusion runs again) and the running point / view-entry totals an
+		// image's compaction starts from.  HCMVS_FUSE_LANES selects the lanes (passes of images that share no map side by side).
+		FuseLane& L = c->fuseLanes[0];
+		size_t allPx = 0;
+		for (const auto& m : host) if (m.depth) allPx += (size_t)m.w * m.h;
+		if (c->capSnap < allPx * 4 + 256) {
+			if (c->snap) (void)hipFree(c->snap);
+			c->snap = nullptr; c->capSnap = 0;
+			HIPCHK(c, hipMalloc(&c->snap, allPx * 4 + 256));
+			c->capSnap = allPx * 4 + 256;
+		}
+		if (!L.links) { // first size of the link lists; HCMVS_FUSE_LINKS_INIT (entries) lets a test start too small and exercise the undo-and-grow path
+			size_t first = (size_t)8 << 20;
+			if (getenv("HCMVS_FUSE_LINKS_INIT") && atol(getenv("HCMVS_FUSE_LINKS_INIT")) > 0) first = (size_t)atol(getenv("HCMVS_FUSE_LINKS_INIT"));
+			HIPCHK(c, hipMalloc(&L.links, first * 4));
+			L.capLinks = first;
+		}
+		uint32_t* status = (uint32_t*)c->snap;                               // 64 B
+		unsigned long long* totals = (unsigned long long*)(c->snap + 64);   // 64 B
+		float* snap = (float*)(c->snap + 256);
+		char* b = L.scratch;
+		uint32_t* pendingList = (uint32_t*)(b + oPending); uint32_t* queue = (uint32_t*)(b + oQueue); uint32_t* ctl = (uint32_t*)(b + oCtl);
+		unsigned long long* counters = (unsigned long long*)(b + oCounters);
+		int32_t* targets = (int32_t*)(b + oTgt);
+		uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders),
+		         *cntP = (uint32_t*)(b + oCntP), *offP = (uint32_t*)(b + oOffP);
+		uint8_t* flag = (uint8_t*)(b + oFlag);
+		uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos); uint32_t* merged = (uint32_t*)(b + oMerged);
+		float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
+		uint32_t* pviews = viewCapacity ? (uint32_t*)(b + oPV) : nullptr; float* pweights = viewCapacity ? (float*)(b + oPW) : nullptr;
+		uint32_t* voff = viewCapacity ? (uint32_t*)(b + oVoff) : nullptr;
+		unsigned long long tot[3] = {0, 0, 0};
+		for (int attempt = 0;; ++attempt) {
+			HIPCHK(c, hipMemsetAsync(c->snap, 0, 256, s));
+			{
+				size_t o = 0;
+				for (const auto& m : host) if (m.depth) { HIPCHK(c, hipMemcpyAsync(snap + o, m.depth, (size_t)m.w * m.h * 4, hipMemcpyDeviceToDevice, s)); o += (size_t)m.w * m.h; }
+			}
+			for (int oi = 0; oi < n_order; ++oi) {
+				const DevMap& A = host[order[oi]];
+				const int n = A.w * A.h;
+				HIPCHK(c, hipMemsetAsync(counters, 0, 64, s));
+				HIPCHK(c, hipMemsetAsync(ctl, 0, 64, s));
+				HIPCHK(c, hipMemsetAsync(queue, 0xFF, (size_t)n * 4, s));
+				HIPCHK(c, hipMemsetAsync(cntT, 0, (size_t)A.nNeighbors * stride * 4, s));
+				HIPCHK(c, hipMemsetAsync(fillT, 0, (size_t)A.nNeighbors * stride * 4, s));
+				HIPCHK(c, hipMemsetAsync(cntP, 0, stride * 8, s));
+				FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, cntP, offP, L.links, stride);
+				launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, c->fuseOrder, thDepth, normalError, status, s);
+				launch_fuse_links_check(tb, (unsigned long long)L.capLinks, status, s);
+				launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, status, s);
+				launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
+				                 merged, n_min_views_fuse, counters, blocks, nullptr, wantCloud, status, s);
+				launch_fuse_status(ctl, status, s);
+				if (wantCloud)
+					launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, 0, capacity, cX, cN, cB, cV, pviews, pweights, vstride,
+					                    voff, 0, viewCapacity, cVI, cVW, totals, status, s);
+				launch_fuse_advance(counters, totals, wantCloud ? capacity : 0, wantCloud ? viewCapacity : 0, status, s);
+			}
+			HIPCHK(c, hipGetLastError());
+			uint32_t st[4] = {0, 0, 0, 0};
+			HIPCHK(c, hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, s));
+			HIPCHK(c, hipMemcpyAsync(tot, totals, 24, hipMemcpyDeviceToHost, s));
+			HIPCHK(c, hipStreamSynchronize(s));
+			if (st[1] != 0) { // a link list did not fit: undo, grow, again
+				size_t o = 0;
+				for (const auto& m : host) if (m.depth) { HIPCHK(c, hipMemcpyAsync(m.depth, snap + o, (size_t)m.w * m.h * 4, hipMemcpyDeviceToDevice, s)); o += (size_t)m.w * m.h; }
+				HIPCHK(c, hipStreamSynchronize(s));
+				if (attempt >= 4) return fail(c, HCMVS_ERR_CAPACITY, "fuse: the link lists of a pass keep outgrowing their buffer (%u entries)", st[2]);
+				(void)hipFree(L.links);
+				L.links = nullptr; L.capLinks = 0;
+				const size_t want = (size_t)st[2] + (size_t)st[2] / 4 + ((size_t)1 << 20);
+				HIPCHK(c, hipMalloc(&L.links, want * 4));
+				L.capLinks = want;
+				continue;
+			}
+			launch_unclaim(c->dMaps, (int)host.size(), s);
+			if (st[0] != 0) { HIPCHK(c, hipStreamSynchronize(s)); return fail(c, HCMVS_ERR_TIMEOUT, "fuse: the pass of an image stalled; the registered depth maps are left partially fused"); }
+			if (st[3] == 1) { HIPCHK(c, hipStreamSynchronize(s)); return fail(c, HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity); }
+			if (st[3] == 2) { HIPCHK(c, hipStreamSynchronize(s)); return fail(c, HCMVS_ERR_CAPACITY, "fuse: view-list capacity %llu exceeded", (unsigned long long)viewCapacity); }
+			break;
+		}
+		const unsigned long long total = tot[0], viewTotal = viewCapacity && wantCloud ? tot[1] : 0;
+		if (wantCloud) HIPCHK(c, hipMemcpyAsync(xyz, cX, total * 12, hipMemcpyDeviceToHost, s));
+		if (normal) HIPCHK(c, hipMemcpyAsync(normal, cN, total * 12, hipMemcpyDeviceToHost, s));
+		if (bgr) HIPCHK(c, hipMemcpyAsync(bgr, cB, total * 3, hipMemcpyDeviceToHost, s));
+		if (n_views) HIPCHK(c, hipMemcpyAsync(n_views, cV, total * 4, hipMemcpyDeviceToHost, s));
+		if (viewCapacity && wantCloud) {
+			HIPCHK(c, hipMemcpyAsync(cloud->view_ids, cVI, viewTotal * 4, hipMemcpyDeviceToHost, s));
+			HIPCHK(c, hipMemcpyAsync(cloud->view_weights, cVW, viewTotal * 4, hipMemcpyDeviceToHost, s));
+		}
+		HIPCHK(c, hipStreamSynchronize(s));
+		*n_points = total;
+		if (n_depths) *n_depths = tot[2];
+		cloud->n_view_entries = viewTotal;
+		return HCMVS_OK;
+	}
 
 	struct Shared {
 		std::mutex mu; std::condition_variable cv;
@@ -1060,7 +1164,6 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 		if (!sh.rc) { sh.rc = code; sh.msg = buf; }
 		sh.cv.notify_all();
 	};
-	const bool debug = getenv("HCMVS_FUSE_DEBUG") != nullptr;
 	auto worker = [&](int k) {
 		FuseLane& L = c->fuseLanes[k];
 		hipStream_t ls = L.stream;
@@ -1163,7 +1266,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 			if (viewCapacity && viewTotal + cnt[4] > viewCapacity) { laneFail(HCMVS_ERR_CAPACITY, "fuse: view-list capacity %llu exceeded", (unsigned long long)viewCapacity); return; }
 			if (accepted && wantCloud) {
 				launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, total, capacity, cX, cN, cB, cV, pviews, pweights, vstride,
-				                    voff, viewTotal, viewCapacity, cVI, cVW, ls);
+				                    voff, viewTotal, viewCapacity, cVI, cVW, nullptr, nullptr, ls);
 				LANECHK(hipStreamSynchronize(ls));
 			}
 			{

@@ -272,6 +272,14 @@ def test_postfilter_sequence_equals_image_after_image(ctx):
     try:
         c2 = binding.Context(0)
         upload(c2, maps)
+        want = O.fuse_depthmaps(maps, order, 200000)
+        got = c2.fuse(order, 200000)                  # the unsynchronised fusion with a cloud goes through the same undo-and-grow path
+        assert got["n_points"] == want["n_points"] and np.array_equal(got["xyz"], want["xyz"]) and np.array_equal(got["bgr"], want["bgr"])
+        for i, d in enumerate(want["depths"]):
+            assert np.array_equal(c2.get_depthmap(i)[0], d)
+        c2.close()
+        c2 = binding.Context(0)
+        upload(c2, maps)
         assert c2.postfilter_sequence(seq, order) == total
         for i in range(len(maps)):
             d, n, c = c2.get_depthmap(i, with_normal=True)
