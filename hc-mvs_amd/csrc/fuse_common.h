@@ -46,7 +46,11 @@ struct FuseTables {
 
 FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_t* fillT, uint32_t* bidders, uint32_t* cntP, uint32_t* offP,
                        uint32_t* nbrList, size_t stride);
-// ctl: 8 words, zero before the pass: [0] queue tail, [1] queue head, [2] pixels decided, [3] error flag, [4] pending pixels
+// ctl: kCtlBytes, zero before the pass.  The words every wave of the pass hammers lie on lines of their own: the tail and the head
+// of ready queue q at kCtlTail + 32 q and kCtlHead + 32 q.
+constexpr int kFuseQueues = 16;
+constexpr int kCtlPending = 4, kCtlLevels = 5, kCtlDone = 32, kCtlErr = 64, kCtlTail = 128, kCtlHead = kCtlTail + 32 * kFuseQueues; // word indices
+constexpr size_t kCtlBytes = 4 * (size_t)(kCtlHead + 32 * kFuseQueues);
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
                        uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, float thDepth, float normalError, const uint32_t* abort, hipStream_t s);
 void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, const uint32_t* abort, hipStream_t s);
@@ -55,7 +59,8 @@ void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_
 void launch_fuse_links_check(const FuseTables& tb, unsigned long long capLinks, uint32_t* status, hipStream_t s);
 void launch_fuse_status(const uint32_t* ctl, uint32_t* status, hipStream_t s);
 void launch_unclaim(const DevMap* maps, int nMaps, hipStream_t s); // takes the claim marks (negative depths) off every map
-void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl,
+// queue: kFuseQueues x queueStride slots, all FS_EMPTY (0xFFFFFFFF) before the first pass of a call; a pass leaves them so
+void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, size_t queueStride, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
                       uint32_t* merged, int nMinViewsFuse, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, const uint32_t* abort,
                       hipStream_t s);

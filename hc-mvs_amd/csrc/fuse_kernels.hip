@@ -332,7 +332,7 @@ __global__ void fuse_links_check_kernel(FuseTables tb, unsigned long long capLin
 }
 __global__ void fuse_status_kernel(const uint32_t* ctl, uint32_t* status) {
 	if (blockIdx.x != 0 || threadIdx.x != 0 || status[1] != 0u) return;
-	if (ctl[3] != 0u || ctl[2] != ctl[4]) status[0] = 1u;
+	if (ctl[kCtlErr] != 0u || ctl[kCtlDone] != ctl[kCtlPending]) status[0] = 1u;
 }
 // after an image's compaction: the image's counts (counters[0] depths, [3] points, [4] view entries) join the running totals the
 // next image's compaction starts from; status[3] says that the cloud (1) or the view lists (2) do not fit
@@ -357,24 +357,38 @@ __global__ void unclaim_kernel(const DevMap* maps, int nMaps) {
 }
 struct FusePass {
 	FuseTables tb;
-	uint32_t* queue;         // [pending] append-only ready queue, FS_EMPTY until written
-	uint32_t* ctl;           // [0] queue tail, [1] queue head, [2] pixels decided, [3] error flag, [4] pending (set by fuse_begin)
+	uint32_t* queue;         // kFuseQueues append-only ready queues of queueStride slots each, FS_EMPTY until written: a worker takes its slots
+	size_t queueStride;      // from ONE of them (workgroup index mod kFuseQueues) and spreads what it appends over all of them, so that no
+	                         // head or tail word is hammered by more than a sixteenth of the workers
+	uint32_t* ctl;           // kCtl* words (fuse_common.h): queue tail, queue head, pixels decided, error flag -- each on a line of its own,
+	                         // they are hammered by every wave of the pass -- and the number of pending pixels (set by fuse_begin)
 	uint32_t* merged;        // [w*h] out: per point, which neighbours' estimates it merged (bit q = neighbour q)
-	uint32_t* levels;        // diagnostic (HCMVS_FUSE_DEBUG), else null: per-pixel depth in the dependence graph, maximum in ctl[5]
+	uint32_t* levels;        // diagnostic (HCMVS_FUSE_DEBUG), else null: per-pixel depth in the dependence graph, maximum in ctl[kCtlLevels]
 	const uint32_t* abort;   // null, or the status words of an unsynchronised fusion: [1] != 0 -> do nothing
 	int nMinViewsFuse;
+	int xcd;                 // diagnostic (HCMVS_FUSE_XCD): >= 0 -> only the workgroups that land on this XCD work
 };
 #define FS_EMPTY 0xFFFFFFFFu
 
 // seed of the pass: the pending pixels nobody blocks.  A launch of its own: the pass counts the countdowns down, and a
 // pixel that reaches zero there must not be taken for a seed as well.
-__global__ void fuse_seed_kernel(FuseTables tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl, const uint32_t* abort) {
+__global__ void fuse_seed_kernel(FuseTables tb, const uint32_t* pending, uint32_t* queue, size_t queueStride, uint32_t* ctl, const uint32_t* abort) {
 	if (abort && abort[1] != 0u) return;
-	const uint32_t nPending = ctl[4];
+	const uint32_t q = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) % (uint32_t)kFuseQueues; // a wave appends to one queue
+	const uint32_t nPending = ctl[kCtlPending];
 	const uint32_t nPad = (nPending + 63u) & ~63u; // whole waves take part in list_append (one atomic per wave, not per pixel)
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nPad; i += gridDim.x * blockDim.x) {
 		const uint32_t idx = i < nPending ? pending[i] : 0u;
-		list_append(i < nPending && tb.cntP[idx] == 0u, (int)idx, queue, ctl);
+		list_append(i < nPending && tb.cntP[idx] == 0u, (int)idx, queue + q * queueStride, ctl + kCtlTail + 32u * q);
+	}
+}
+
+// after the pass: the slots that were used are FS_EMPTY again (the queues are all-empty between passes)
+__global__ void fuse_queue_reset_kernel(uint32_t* queue, size_t queueStride, const uint32_t* ctl, const uint32_t* abort) {
+	if (abort && abort[1] != 0u) return;
+	for (int q = 0; q < kFuseQueues; ++q) {
+		const uint32_t used = ctl[kCtlTail + 32 * q] < (uint32_t)queueStride ? ctl[kCtlTail + 32 * q] : (uint32_t)queueStride;
+		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < used; i += gridDim.x * blockDim.x) queue[q * queueStride + i] = FS_EMPTY;
 	}
 }
 
@@ -391,6 +405,7 @@ __global__ void fuse_seed_kernel(FuseTables tb, const uint32_t* pending, uint32_
 // themselves (double-precision sums, colours, normals, view lists) are computed afterwards, in parallel, from the merge
 // masks the pass leaves (fuse_points_kernel).
 constexpr int kFuseRing = 256;
+constexpr int kRelBatch = 24; // dependants whose countdowns go out in one round trip
 
 // MAXV: the image itself + its neighbours; 16 covers the reference's cap of 12 neighbours (nMaxViews, DepthMap.cpp:73)
 template <int MAXV>
@@ -400,18 +415,22 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 	__shared__ uint32_t ring[kFuseRing];
 	__shared__ uint32_t ringCnt;
 	if (fp.abort && fp.abort[1] != 0u) return; // wave-uniform
+	if (fp.xcd >= 0 && (int)(__builtin_amdgcn_s_getreg(6164) & 7u) != fp.xcd) return; // HW_REG_XCC_ID[3:0]
 	const int nNb = A.nNeighbors;
 	const int lane = threadIdx.x;
 	if (lane < nNb) { const DevMap& B = maps[A.neighbors[lane]]; depthOf[lane] = B.depth; }
 	if (lane == 0) ringCnt = 0u;
 	__syncthreads();
 	const FuseTables& tb = fp.tb;
-	const uint32_t nPending = fp.ctl[4];
-	uint32_t* const qTail = fp.ctl, *const qHead = fp.ctl + 1, *const nDone = fp.ctl + 2, *const errFlag = fp.ctl + 3;
-	auto ring_push = [&](uint32_t v) { // a pixel that became ready: to this wave's ring, to the global queue when that is full
+	const uint32_t nPending = fp.ctl[kCtlPending];
+	const uint32_t myQ = blockIdx.x % (uint32_t)kFuseQueues; // the queue this wave takes its slots from
+	uint32_t* const myQueue = fp.queue + myQ * fp.queueStride;
+	uint32_t* const qHead = fp.ctl + kCtlHead + 32u * myQ, *const nDone = fp.ctl + kCtlDone, *const errFlag = fp.ctl + kCtlErr;
+	uint32_t rot = myQ; // the queue the next batch of this wave goes to
+	auto ring_push = [&](uint32_t v) { // a pixel that became ready: to this wave's ring, to a global queue when that is full
 		const uint32_t pos = atomicAdd(&ringCnt, 1u);
 		if (pos < (uint32_t)kFuseRing) ring[pos] = v;
-		else st_u32(&fp.queue[atomicAdd(qTail, 1u)], v);
+		else st_u32(&myQueue[atomicAdd(fp.ctl + kCtlTail + 32u * myQ, 1u)], v);
 	};
 	unsigned accepted = 0, decided = 0, viewEntries = 0;
 	// queue slots are taken by the wave, not by the lane: one atomic on the (single, hot) head word for all the lanes that need one
@@ -427,10 +446,12 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 	uint32_t item = FS_EMPTY, slot = FS_EMPTY; // the pixel I run next; the queue slot I wait on
 	take_slots(true, slot);
 	unsigned spins = 0;
+	unsigned dbgBusy = 0, dbgIdle = 0, dbgItems = 0; // diagnostic (fp.levels): iterations with / without a pixel to run, pixels run
 	for (;;) {
 		uint32_t polled = FS_EMPTY;
-		if (slot < nPending) polled = ld_u32(&fp.queue[slot]);
+		if (slot < nPending) polled = ld_u32(&myQueue[slot]);
 		const bool busy = __ballot(item != FS_EMPTY) != 0ull;
+		if (fp.levels) { if (busy) { ++dbgBusy; dbgItems += (unsigned)__builtin_popcountll(__ballot(item != FS_EMPTY)); } else ++dbgIdle; }
 		if (item != FS_EMPTY) {
 			const int idx = (int)item;
 			item = FS_EMPTY;
@@ -449,9 +470,9 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 				if (t[j] < 0) continue;
 				dB[j] = ld_f32(depthOf[j] + (t[j] & kTargetIndexMask)); // > 0 free, < 0 part of a point, 0 invalidated
 			}
-			uint32_t rel[8];
+			uint32_t rel[kRelBatch]; // the first batch of my dependants travels with round trip B
 #pragma unroll
-			for (int j = 0; j < 8; ++j) rel[j] = (uint32_t)j < relLen ? tb.nbrList[relOff + j] : FS_EMPTY;
+			for (int j = 0; j < kRelBatch; ++j) rel[j] = (uint32_t)j < relLen ? tb.nbrList[relOff + j] : FS_EMPTY;
 			// the decision (SceneDensify.cpp:3395-3449): targets still empty-handed merge or are invalidated
 			uint32_t merge = 0u, inFront = 0u;
 #pragma unroll
@@ -478,22 +499,22 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 			++decided;
 			if (fp.levels) {
 				const uint32_t lvl = ld_u32(&fp.levels[idx]) + 1u;
-				atomicMax(fp.ctl + 5, lvl);
+				atomicMax(fp.ctl + kCtlLevels, lvl);
 				uint32_t sink = 0;
 				for (uint32_t k = 0; k < relLen; ++k) sink += atomicMax(&fp.levels[tb.nbrList[relOff + k]], lvl);
 				asm volatile("" ::"v"(sink));
 			}
 			// round trip D: the countdowns of the pixels I block; whoever reaches zero is ready
-			for (uint32_t k0 = 0; k0 < relLen; k0 += 8) {
-				uint32_t was[8];
+			for (uint32_t k0 = 0; k0 < relLen; k0 += kRelBatch) { // a pixel with more than kRelBatch dependants pays two more round trips per batch
+				uint32_t was[kRelBatch];
 				if (k0) {
 #pragma unroll
-					for (int j = 0; j < 8; ++j) rel[j] = k0 + j < relLen ? tb.nbrList[relOff + k0 + j] : FS_EMPTY;
+					for (int j = 0; j < kRelBatch; ++j) rel[j] = k0 + j < relLen ? tb.nbrList[relOff + k0 + j] : FS_EMPTY;
 				}
 #pragma unroll
-				for (int j = 0; j < 8; ++j) was[j] = rel[j] != FS_EMPTY ? atomicSub(&tb.cntP[rel[j]], 1u) : 0u;
+				for (int j = 0; j < kRelBatch; ++j) was[j] = rel[j] != FS_EMPTY ? atomicSub(&tb.cntP[rel[j]], 1u) : 0u;
 #pragma unroll
-				for (int j = 0; j < 8; ++j)
+				for (int j = 0; j < kRelBatch; ++j)
 					if (was[j] == 1u) ring_push(rel[j]);
 			}
 		}
@@ -504,7 +525,14 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 		__syncthreads();
 		if (nReady) {
 			if ((uint32_t)lane < nReady) item = ring[lane];
-			for (uint32_t k = 64u + (uint32_t)lane; k < nReady; k += 64u) st_u32(&fp.queue[atomicAdd(qTail, 1u)], ring[k]);
+			if (nReady > 64u) { // what the lanes cannot take goes to a global queue (the next one in turn): one atomic on its tail word for the wave
+				rot = rot + 1u < (uint32_t)kFuseQueues ? rot + 1u : 0u;
+				uint32_t base = 0u;
+				if (lane == 0) base = atomicAdd(fp.ctl + kCtlTail + 32u * rot, nReady - 64u);
+				base = (uint32_t)__shfl((int)base, 0, 64);
+				uint32_t* const q = fp.queue + rot * fp.queueStride;
+				for (uint32_t k = 64u + (uint32_t)lane; k < nReady; k += 64u) st_u32(&q[base + k - 64u], ring[k]);
+			}
 			__syncthreads();
 			if (lane == 0) ringCnt = 0u;
 			__syncthreads();
@@ -513,14 +541,17 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 			// an idle wave: pixels handed on inside a wave never pass through the queue, so the end of the pass is "every
 			// pending pixel decided", not "my slot is past the end"
 			if (decided) { atomicAdd(nDone, decided); decided = 0; }
-			const bool over = ld_u32(nDone) >= nPending || ld_u32(errFlag) != 0u;
-			if (__ballot(over) != 0ull) break;
-			if (++spins > (1u << 22)) { st_u32(errFlag, 1u); break; } // bounded: never hang the device
+			if ((spins & 7u) == 0u) { // the queue slots are polled every time round, the (single, hot) end-of-pass word less often
+				const bool over = ld_u32(nDone) >= nPending; // a worker that gives up sets the top bit
+				if (__ballot(over) != 0ull) break;
+			}
+			if (++spins > (1u << 22)) { st_u32(errFlag, 1u); atomicOr(nDone, 0x80000000u); break; } // bounded: never hang the device
 			__builtin_amdgcn_s_sleep(8);
 		}
 		take_slots(item == FS_EMPTY && slot == FS_EMPTY, slot);
 	}
 	if (decided) atomicAdd(nDone, decided);
+	if (fp.levels && lane == 0) { atomicAdd(fp.ctl + 8, dbgBusy); atomicAdd(fp.ctl + 9, dbgIdle); atomicAdd(fp.ctl + 10, dbgItems); }
 	if (accepted) { atomicAdd(&counters[3], (unsigned long long)accepted); atomicAdd(&counters[4], (unsigned long long)viewEntries); }
 }
 
@@ -785,30 +816,34 @@ FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_
 // (cntT / fillT / cntP must be zero).  fuse_links_fill writes the link lists once the host has sized them.
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
                        uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, float thDepth, float normalError, const uint32_t* abort, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, ctl + 3, flag, counters, thDepth, normalError, abort); // roundCnt[1] == ctl[4]
+	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, ctl + kCtlPending - 1, flag, counters, thDepth, normalError, abort); // roundCnt[1] == ctl[kCtlPending]
 	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntT, tb.offT, (int)(tb.stride * (size_t)A.nNeighbors), s);
-	hipLaunchKernelGGL(fuse_fill_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3, abort);
-	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3, 0, order, abort);
+	hipLaunchKernelGGL(fuse_fill_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + kCtlPending - 1, abort);
+	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + kCtlPending - 1, 0, order, abort);
 	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntP, tb.offP, (int)(2 * tb.stride), s);
 }
 void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, const uint32_t* abort, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + 3, 1, order, abort);
+	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + kCtlPending - 1, 1, order, abort);
 }
 // the whole image pass in one launch of dataflow workers (one wave per workgroup; any grid size is correct), then the points
-void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, uint32_t* ctl,
+void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, size_t queueStride, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
                       uint32_t* merged, int nMinViewsFuse, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, const uint32_t* abort,
                       hipStream_t s) {
 	FuseOut out{oxyz, onormal, obgr, onv, oflag, oviews, oweights, vstride};
 	FusePass fp;
-	fp.tb = tb; fp.queue = queue; fp.ctl = ctl; fp.merged = merged; fp.levels = levels; fp.abort = abort;
+	fp.tb = tb; fp.queue = queue; fp.queueStride = queueStride; fp.ctl = ctl; fp.merged = merged; fp.levels = levels; fp.abort = abort;
 	fp.nMinViewsFuse = nMinViewsFuse;
-	hipLaunchKernelGGL(fuse_seed_kernel, kGrid, kBlock, 0, s, tb, pending, queue, ctl, abort);
+	static const int xcdOnly = getenv("HCMVS_FUSE_XCD") ? atoi(getenv("HCMVS_FUSE_XCD")) : -1;
+	fp.xcd = xcdOnly;
+	if (xcdOnly >= 0) blocks *= 8;
+	hipLaunchKernelGGL(fuse_seed_kernel, kGrid, kBlock, 0, s, tb, pending, queue, queueStride, ctl, abort);
 	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_pass_kernel<16>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
 	else hipLaunchKernelGGL(fuse_pass_kernel<32>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
+	hipLaunchKernelGGL(fuse_queue_reset_kernel, kGrid, kBlock, 0, s, queue, queueStride, ctl, abort);
 	if (!wantPoints) return;
-	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_points_kernel<16>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + 3, abort);
-	else hipLaunchKernelGGL(fuse_points_kernel<32>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + 3, abort);
+	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_points_kernel<16>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + kCtlPending - 1, abort);
+	else hipLaunchKernelGGL(fuse_points_kernel<32>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + kCtlPending - 1, abort);
 }
 size_t fuse_scan_temp_bytes(int n) {
 	size_t bytes = 0;

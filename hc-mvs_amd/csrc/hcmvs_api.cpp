@@ -992,9 +992,9 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	uint32_t* cVI = viewCapacity ? (uint32_t*)(cb + oCVI) : nullptr; float* cVW = viewCapacity ? (float*)(cb + oCVW) : nullptr;
 	// ... and the per-pass scratch of one lane (sized for the largest image)
 	off = 0;
-	const size_t oPending = carve(maxArea * 4), oQueue = carve(maxArea * 4), oTgt = carve(maxArea * 4 * (size_t)maxNb),
+	const size_t oPending = carve(maxArea * 4), oQueue = carve(maxArea * 4 * (size_t)kFuseQueues), oTgt = carve(maxArea * 4 * (size_t)maxNb),
 	             oCntT = carve(tblElems * 4), oFillT = carve(tblElems * 4), oCntP = carve(stride * 8), oOffT = carve(tblElems * 4), oOffP = carve(stride * 8),
-	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(64), oCounters = carve(64), oMerged = carve(maxArea * 4),
+	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(kCtlBytes), oCounters = carve(64), oMerged = carve(maxArea * 4),
 	             oFlag = carve(maxArea), oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
 	             oXyz = carve(maxArea * 12), oNrm = carve(maxArea * 12), oBgr = carve(maxArea * 3), oNv = carve(maxArea * 4),
 	             oPV = carve(viewCapacity ? maxArea * 4 * (size_t)(maxNb + 1) : 0), oPW = carve(viewCapacity ? maxArea * 4 * (size_t)(maxNb + 1) : 0),
@@ -1083,6 +1083,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 		uint32_t* pviews = viewCapacity ? (uint32_t*)(b + oPV) : nullptr; float* pweights = viewCapacity ? (float*)(b + oPW) : nullptr;
 		uint32_t* voff = viewCapacity ? (uint32_t*)(b + oVoff) : nullptr;
 		unsigned long long tot[3] = {0, 0, 0};
+		HIPCHK(c, hipMemsetAsync(queue, 0xFF, maxArea * 4 * (size_t)kFuseQueues, s)); // FS_EMPTY; every pass leaves the queues so
 		for (int attempt = 0;; ++attempt) {
 			HIPCHK(c, hipMemsetAsync(c->snap, 0, 256, s));
 			{
@@ -1093,8 +1094,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 				const DevMap& A = host[order[oi]];
 				const int n = A.w * A.h;
 				HIPCHK(c, hipMemsetAsync(counters, 0, 64, s));
-				HIPCHK(c, hipMemsetAsync(ctl, 0, 64, s));
-				HIPCHK(c, hipMemsetAsync(queue, 0xFF, (size_t)n * 4, s));
+				HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
 				HIPCHK(c, hipMemsetAsync(cntT, 0, (size_t)A.nNeighbors * stride * 4, s));
 				HIPCHK(c, hipMemsetAsync(fillT, 0, (size_t)A.nNeighbors * stride * 4, s));
 				HIPCHK(c, hipMemsetAsync(cntP, 0, stride * 8, s));
@@ -1102,7 +1102,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 				launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, c->fuseOrder, thDepth, normalError, status, s);
 				launch_fuse_links_check(tb, (unsigned long long)L.capLinks, status, s);
 				launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, status, s);
-				launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
+				launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, maxArea, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
 				                 merged, n_min_views_fuse, counters, blocks, nullptr, wantCloud, status, s);
 				launch_fuse_status(ctl, status, s);
 				if (wantCloud)
@@ -1172,6 +1172,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 		char* b = L.scratch;
 		uint32_t* pendingList = (uint32_t*)(b + oPending); uint32_t* queue = (uint32_t*)(b + oQueue);
 		uint32_t* ctl = (uint32_t*)(b + oCtl);
+		LANECHK(hipMemsetAsync(queue, 0xFF, maxArea * 4 * (size_t)kFuseQueues, ls)); // FS_EMPTY; every pass leaves the queues so
 		unsigned long long* counters = (unsigned long long*)(b + oCounters);
 		int32_t* targets = (int32_t*)(b + oTgt);
 		uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders),
@@ -1203,8 +1204,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 			const DevMap& A = host[order[oi]];
 			const int n = A.w * A.h;
 			LANECHK(hipMemsetAsync(counters, 0, 64, ls));
-			LANECHK(hipMemsetAsync(ctl, 0, 64, ls));
-			LANECHK(hipMemsetAsync(queue, 0xFF, (size_t)n * 4, ls));                             // FS_EMPTY
+			LANECHK(hipMemsetAsync(ctl, 0, kCtlBytes, ls));
 			LANECHK(hipMemsetAsync(cntT, 0, (oOffT - oCntT), ls));                               // per-target counts, fill cursors, per-pixel link counts
 			FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, cntP, offP, L.links, stride);
 			launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, c->fuseOrder, thDepth, normalError, nullptr, ls);
@@ -1227,24 +1227,25 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 			launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, nullptr, ls);
 			if (debug) LANECHK(hipMemsetAsync(flag32, 0, (size_t)n * 4, ls)); // diagnostic: dependence depth per pixel (the buffer is free until the compaction)
 			const auto tPass = std::chrono::steady_clock::now();
-			launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
+			launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, maxArea, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
 			                 merged, n_min_views_fuse, counters, blocks, debug ? flag32 : nullptr, wantCloud, nullptr, ls);
 			unsigned long long cnt[5] = {0, 0, 0, 0, 0};
-			uint32_t ctlWords[6] = {0, 0, 0, 0, 0, 0};
+			uint32_t ctlWords[kCtlBytes / 4];
 			LANECHK(hipMemcpyAsync(cnt, counters, 40, hipMemcpyDeviceToHost, ls));
-			LANECHK(hipMemcpyAsync(ctlWords, ctl, 24, hipMemcpyDeviceToHost, ls));
+			LANECHK(hipMemcpyAsync(ctlWords, ctl, kCtlBytes, hipMemcpyDeviceToHost, ls));
 			LANECHK(hipStreamSynchronize(ls));
-			if (ctlWords[3] != 0 || ctlWords[2] != ctlWords[4]) {
+			if (ctlWords[kCtlErr] != 0 || ctlWords[kCtlDone] != ctlWords[kCtlPending]) {
 				// a worker gave up waiting (never expected): the claim and depth maps are half updated -- say so, the caller must
 				// not reuse them
 				laneFail(HCMVS_ERR_TIMEOUT, "fuse: the pass of image %u stalled (%u of %u pixels decided); the registered depth maps are left partially fused",
-				         A.id, ctlWords[2], ctlWords[4]);
+				         A.id, ctlWords[kCtlDone], ctlWords[kCtlPending]);
 				return;
 			}
 			if (debug) {
 				const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tPass).count();
-				fprintf(stderr, "fuse: lane %d image %u: %u pending pixels, %u through the queue, %llu accepted; dependence depth %u, pass %.0f us = %.2f us per level\n",
-				        k, A.id, ctlWords[4], ctlWords[0], cnt[3], ctlWords[5], us, us / std::max(1u, ctlWords[5]));
+				fprintf(stderr, "fuse: lane %d image %u: %u pending pixels, %u through the queue, %llu accepted; dependence depth %u, pass %.0f us = %.2f us per level; worker iterations %u busy (%.1f pixels each) + %u idle\n",
+				        k, A.id, ctlWords[kCtlPending], [&] { uint32_t t = 0; for (int q = 0; q < kFuseQueues; ++q) t += ctlWords[kCtlTail + 32 * q]; return t; }(), cnt[3], ctlWords[kCtlLevels], us, us / std::max(1u, ctlWords[kCtlLevels]),
+				        ctlWords[8], ctlWords[10] / (double)std::max(1u, ctlWords[8]), ctlWords[9]);
 			}
 			unsigned long long total = 0, viewTotal = 0;
 			{ // publish the counts; wait until every earlier image has published its own -> this image's place in the cloud
@@ -1362,9 +1363,9 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 	const size_t scanBytes = (std::max({fuse_scan_temp_bytes((int)maxArea), fuse_scan_temp_bytes((int)tblElems), fuse_scan_temp_bytes((int)(2 * stride))}) + 255) & ~(size_t)255;
 	size_t off = 0;
 	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-	const size_t oPending = carve(maxArea * 4), oQueue = carve(maxArea * 4), oTgt = carve(maxArea * 4 * (size_t)maxNb),
+	const size_t oPending = carve(maxArea * 4), oQueue = carve(maxArea * 4 * (size_t)kFuseQueues), oTgt = carve(maxArea * 4 * (size_t)maxNb),
 	             oCntT = carve(tblElems * 4), oFillT = carve(tblElems * 4), oCntP = carve(stride * 8), oOffT = carve(tblElems * 4), oOffP = carve(stride * 8),
-	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(64), oCounters = carve(64), oStatus = carve(64), oMerged = carve(maxArea * 4),
+	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(kCtlBytes), oCounters = carve(64), oStatus = carve(64), oMerged = carve(maxArea * 4),
 	             oFlag = carve(maxArea), oNv = carve(maxArea * 4), oScan = carve(scanBytes), oDF = carve(maxIdArea * 4), oNF = carve(maxIdArea * 12),
 	             oSnap = carve(allPx * 4);
 	if (c->fuseLanes.empty()) c->fuseLanes.resize(1);
@@ -1401,6 +1402,7 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 	if (getenv("HCMVS_FUSE_BLOCKS")) blocks = std::min(c->nCU * 16, std::max(1, atoi(getenv("HCMVS_FUSE_BLOCKS"))));
 	hipStream_t s = c->stream;
 	unsigned long long filledAll = 0;
+	HIPCHK(c, hipMemsetAsync(queue, 0xFF, maxArea * 4 * (size_t)kFuseQueues, s)); // FS_EMPTY; every pass leaves the queues so
 	for (int k = 0; k < n_ids; ++k) {
 		View& v = c->views.find(ids[k])->second;
 		for (int attempt = 0;; ++attempt) {
@@ -1412,9 +1414,7 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 			}
 			for (int oi = 0; oi < n_order; ++oi) {
 				const DevMap& A = host[order[oi]];
-				const int n = A.w * A.h;
-				HIPCHK(c, hipMemsetAsync(ctl, 0, 64, s));
-				HIPCHK(c, hipMemsetAsync(queue, 0xFF, (size_t)n * 4, s));                  // FS_EMPTY
+				HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
 				HIPCHK(c, hipMemsetAsync(cntT, 0, (size_t)A.nNeighbors * stride * 4, s)); // per-target counts of this image's neighbours
 				HIPCHK(c, hipMemsetAsync(fillT, 0, (size_t)A.nNeighbors * stride * 4, s));
 				HIPCHK(c, hipMemsetAsync(cntP, 0, stride * 8, s));
@@ -1422,7 +1422,7 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 				launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, c->fuseOrder, thDepth, normalError, status, s);
 				launch_fuse_links_check(tb, (unsigned long long)L.capLinks, status, s);
 				launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, status, s);
-				launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, ctl, nullptr, nullptr, nullptr, pnv, flag, nullptr, nullptr, maxNb + 1, merged, n_min_views_fuse,
+				launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, maxArea, ctl, nullptr, nullptr, nullptr, pnv, flag, nullptr, nullptr, maxNb + 1, merged, n_min_views_fuse,
 				                 counters, blocks, nullptr, false, status, s);
 				launch_fuse_status(ctl, status, s);
 			}

@@ -1,7 +1,7 @@
 """diagnostic (not a test): what a fusion pass costs on the maps the post-filters see -- the UNFILTERED score maps between outer
 iterations (every pixel holds an estimate) -- against the final, end-filtered maps: pending pixels, depth of the dependence graph,
 time per pass (HCMVS_FUSE_DEBUG lines of the synchronous path), for several worker counts (HCMVS_FUSE_BLOCKS).
-  python tools/pf_depth.py [n_views=9]"""
+  python tools/pf_depth.py [n_views=9] [blocks,blocks,... ("" = default)]"""
 import importlib, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -48,7 +48,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     ctx.close()
     sys.exit(0)
 n = sys.argv[1] if len(sys.argv) > 1 else "9"
-for blocks in ("", "2048", "4096"):
+for blocks in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("", "2048", "4096")):
     env = dict(os.environ, HCMVS_FUSE_DEBUG="1", HCMVS_FUSE_LANES="1")
     if blocks:
         env["HCMVS_FUSE_BLOCKS"] = blocks
