@@ -49,6 +49,8 @@ FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_
 // ctl: kCtlBytes, zero before the pass.  The words every wave of the pass hammers lie on lines of their own: the tail and the head
 // of ready queue q at kCtlTail + 32 q and kCtlHead + 32 q.
 constexpr int kFuseQueues = 16;
+constexpr int kSettleSteps = 3; // full-grid steps of the settle iteration after step 0; a single workgroup finishes what they leave
+constexpr int kCtlSteps = 6, kCtlWork = 16; // steps the iteration took; kCtlWork + s: length of the work list step s wrote (s <= kSettleSteps)
 constexpr int kCtlPending = 4, kCtlLevels = 5, kCtlDone = 32, kCtlErr = 64, kCtlTail = 128, kCtlHead = kCtlTail + 32 * kFuseQueues; // word indices
 constexpr size_t kCtlBytes = 4 * (size_t)(kCtlHead + 32 * kFuseQueues);
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
@@ -62,7 +64,7 @@ void launch_unclaim(const DevMap* maps, int nMaps, hipStream_t s); // takes the 
 // queue: kFuseQueues x queueStride slots, all FS_EMPTY (0xFFFFFFFF) before the first pass of a call; a pass leaves them so
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, size_t queueStride, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
-                      uint32_t* merged, int nMinViewsFuse, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, const uint32_t* abort,
+                      uint32_t* merged, int nMinViewsFuse, int order, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, const uint32_t* abort,
                       hipStream_t s);
 void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const DevMap* maps, int nMaps, const uint8_t* gra, float* dF, float* nF,
                        int gap, float thr, unsigned long long* filled, const uint32_t* abort, hipStream_t s);

@@ -203,9 +203,16 @@ __device__ __forceinline__ void pixel_point(const DevMap& A, int idx, float dept
 typedef __attribute__((address_space(1))) uint32_t* g_u32p;
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t* p) { return __hip_atomic_load((g_u32p)p, __ATOMIC_RELAXED, FS_SCOPE); }
 __device__ __forceinline__ void st_u32(uint32_t* p, uint32_t v) { __hip_atomic_store((g_u32p)p, v, __ATOMIC_RELAXED, FS_SCOPE); }
+__device__ __forceinline__ uint8_t ld_u8(const uint8_t* p) { return __hip_atomic_load((__attribute__((address_space(1))) uint8_t*)p, __ATOMIC_RELAXED, FS_SCOPE); }
+__device__ __forceinline__ void st_u8(uint8_t* p, uint8_t v) { __hip_atomic_store((__attribute__((address_space(1))) uint8_t*)p, v, __ATOMIC_RELAXED, FS_SCOPE); }
 __device__ __forceinline__ float ld_f32(const float* p) { return __uint_as_float(ld_u32((const uint32_t*)p)); }
 __device__ __forceinline__ void st_f32(float* p, float v) { st_u32((uint32_t*)p, __float_as_uint(v)); }
 
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { // the maximum over the 64 lanes, in every lane
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64); v = v > w ? v : w; }
+	return v;
+}
 __device__ __forceinline__ void list_append(bool pred, int value, uint32_t* list, uint32_t* count) { // one atomic per wave
 	const unsigned long long m = __ballot(pred);
 	if (!pred) return;
@@ -379,7 +386,8 @@ __global__ void fuse_seed_kernel(FuseTables tb, const uint32_t* pending, uint32_
 	const uint32_t nPad = (nPending + 63u) & ~63u; // whole waves take part in list_append (one atomic per wave, not per pixel)
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nPad; i += gridDim.x * blockDim.x) {
 		const uint32_t idx = i < nPending ? pending[i] : 0u;
-		list_append(i < nPending && tb.cntP[idx] == 0u, (int)idx, queue + q * queueStride, ctl + kCtlTail + 32u * q);
+		const bool seed = i < nPending && tb.cntP[idx] == 0u;
+		list_append(seed, (int)idx, queue + q * queueStride, ctl + kCtlTail + 32u * q);
 	}
 }
 
@@ -404,73 +412,93 @@ __global__ void fuse_queue_reset_kernel(uint32_t* queue, size_t queueStride, con
 // iteration; only what exceeds the wave's 64 lanes goes to the global queue, whose slots idle lanes poll.  The points
 // themselves (double-precision sums, colours, normals, view lists) are computed afterwards, in parallel, from the merge
 // masks the pass leaves (fuse_points_kernel).
-constexpr int kFuseRing = 256;
-constexpr int kRelBatch = 24; // dependants whose countdowns go out in one round trip
+constexpr int kRelBatch = 8; // dependants whose countdowns go out in one round trip
 
 // MAXV: the image itself + its neighbours; 16 covers the reference's cap of 12 neighbours (nMaxViews, DepthMap.cpp:73)
+// A single wave per workgroup: no barriers, the ring of ready pixels is filled by ballot compaction (no LDS atomics), and the
+// wave-level atomics travel with the lanes' round trips (the head atomic that hands out queue slots with A, the tail atomic for
+// what the wave cannot run itself with D).
+constexpr int kPassRing = 64 * (kRelBatch + 1); // what one iteration can make ready at most
+constexpr int kPassOvf = 4096;                  // ready pixels on their way to a global queue (power of two)
 template <int MAXV>
 __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* maps, FusePass fp, FuseOut out, const uint32_t* pending,
                                                         unsigned long long* counters) {
 	__shared__ float* depthOf[MAXV - 1];
-	__shared__ uint32_t ring[kFuseRing];
-	__shared__ uint32_t ringCnt;
+	__shared__ uint32_t ring[kPassRing];
+	__shared__ uint32_t ovf[kPassOvf];
 	if (fp.abort && fp.abort[1] != 0u) return; // wave-uniform
 	if (fp.xcd >= 0 && (int)(__builtin_amdgcn_s_getreg(6164) & 7u) != fp.xcd) return; // HW_REG_XCC_ID[3:0]
 	const int nNb = A.nNeighbors;
 	const int lane = threadIdx.x;
+	const unsigned long long ltMask = (1ull << lane) - 1ull;
 	if (lane < nNb) { const DevMap& B = maps[A.neighbors[lane]]; depthOf[lane] = B.depth; }
-	if (lane == 0) ringCnt = 0u;
 	__syncthreads();
 	const FuseTables& tb = fp.tb;
 	const uint32_t nPending = fp.ctl[kCtlPending];
-	const uint32_t myQ = blockIdx.x % (uint32_t)kFuseQueues; // the queue this wave takes its slots from
+	const uint32_t myQ = (fp.xcd >= 0 ? blockIdx.x >> 3 : blockIdx.x) % (uint32_t)kFuseQueues; // the queue this wave takes its slots from
 	uint32_t* const myQueue = fp.queue + myQ * fp.queueStride;
 	uint32_t* const qHead = fp.ctl + kCtlHead + 32u * myQ, *const nDone = fp.ctl + kCtlDone, *const errFlag = fp.ctl + kCtlErr;
-	uint32_t rot = myQ; // the queue the next batch of this wave goes to
-	auto ring_push = [&](uint32_t v) { // a pixel that became ready: to this wave's ring, to a global queue when that is full
-		const uint32_t pos = atomicAdd(&ringCnt, 1u);
-		if (pos < (uint32_t)kFuseRing) ring[pos] = v;
-		else st_u32(&myQueue[atomicAdd(fp.ctl + kCtlTail + 32u * myQ, 1u)], v);
-	};
-	unsigned accepted = 0, decided = 0, viewEntries = 0;
-	// queue slots are taken by the wave, not by the lane: one atomic on the (single, hot) head word for all the lanes that need one
-	auto take_slots = [&](bool want, uint32_t& slot_) {
-		const unsigned long long wm = __ballot(want);
-		if (wm == 0ull) return;
-		const int leader = __builtin_ctzll(wm);
-		uint32_t base = 0u;
-		if (lane == leader) base = atomicAdd(qHead, (uint32_t)__builtin_popcountll(wm));
-		base = (uint32_t)__shfl((int)base, leader, 64);
-		if (want) slot_ = base + (uint32_t)__builtin_popcountll(wm & ((1ull << lane) - 1ull));
-	};
+	uint32_t rot = myQ; // the queue the next batch this wave hands on goes to
 	uint32_t item = FS_EMPTY, slot = FS_EMPTY; // the pixel I run next; the queue slot I wait on
-	take_slots(true, slot);
-	unsigned spins = 0;
-	unsigned dbgBusy = 0, dbgIdle = 0, dbgItems = 0; // diagnostic (fp.levels): iterations with / without a pixel to run, pixels run
+	uint32_t ringCnt = 0u, ovfHead = 0u, ovfTail = 0u; // wave-uniform
+	unsigned accepted = 0, decided = 0, viewEntries = 0, spins = 0;
+	unsigned dbgBusy = 0, dbgIdle = 0, dbgItems = 0; // diagnostic: iterations with / without a pixel to run, pixels run (ctl[8..10])
+	auto push = [&](bool pred, uint32_t v) { // wave-uniform call: the lanes with pred append v to the ring of ready pixels
+		const unsigned long long m = __ballot(pred);
+		if (m == 0ull) return;
+		if (pred) {
+			const uint32_t pos = ringCnt + (uint32_t)__builtin_popcountll(m & ltMask);
+			if (pos < (uint32_t)kPassRing) ring[pos] = v;
+			else st_u32(&myQueue[atomicAdd(fp.ctl + kCtlTail + 32u * myQ, 1u)], v); // cannot happen with the sizes above
+		}
+		ringCnt += (uint32_t)__builtin_popcountll(m);
+		if (ringCnt > (uint32_t)kPassRing) ringCnt = (uint32_t)kPassRing;
+	};
 	for (;;) {
-		uint32_t polled = FS_EMPTY;
-		if (slot < nPending) polled = ld_u32(&myQueue[slot]);
-		const bool busy = __ballot(item != FS_EMPTY) != 0ull;
-		if (fp.levels) { if (busy) { ++dbgBusy; dbgItems += (unsigned)__builtin_popcountll(__ballot(item != FS_EMPTY)); } else ++dbgIdle; }
-		if (item != FS_EMPTY) {
-			const int idx = (int)item;
-			item = FS_EMPTY;
-			// round trip A
-			const uint32_t relOff = tb.offP[tb.stride + idx], relLen = tb.cntP[tb.stride + idx];
-			const int32_t* tg = tb.targets + (size_t)idx * nNb;
+		const bool have = item != FS_EMPTY;
+		const unsigned long long haveMask = __ballot(have);
+		const bool busy = haveMask != 0ull;
+		if (busy) { ++dbgBusy; dbgItems += (unsigned)__builtin_popcountll(haveMask); } else ++dbgIdle;
+		// ---- round trip A: my tables; with it the poll of my queue slot, the head atomic for the lanes that need a slot and (idle
+		// waves) the end-of-pass word
+		uint32_t polled = FS_EMPTY, headBase = 0u, doneVal = 0u;
+		if (slot < nPending) polled = ld_u32(&myQueue[slot]); // a slot past the end can never be filled
+		const bool want = !have && slot == FS_EMPTY;
+		const unsigned long long wantMask = __ballot(want);
+		const int wantLeader = wantMask ? __builtin_ctzll(wantMask) : 0;
+		if (wantMask && lane == wantLeader) headBase = atomicAdd(qHead, (uint32_t)__builtin_popcountll(wantMask));
+		const uint32_t nFlush = ovfTail - ovfHead;
+		const bool pollDone = !busy && nFlush == 0u && (spins & 7u) == 0u;
+		if (pollDone) doneVal = ld_u32(nDone); // a worker that gives up sets the top bit
+		uint32_t tailBase = 0u;
+		if (!busy && nFlush) { // nothing to run: the tail atomic cannot ride with D
+			rot = rot + 1u < (uint32_t)kFuseQueues ? rot + 1u : 0u;
+			if (lane == 0) tailBase = atomicAdd(fp.ctl + kCtlTail + 32u * rot, nFlush);
+		}
+		ringCnt = 0u;
+		if (busy) {
+			const int idx = have ? (int)item : 0;
+			uint32_t relOff = 0u, relLen = 0u;
 			int32_t t[MAXV - 1];
+			float dA = 0.f;
+			if (have) {
+				relOff = tb.offP[tb.stride + idx]; relLen = tb.cntP[tb.stride + idx];
+				const int32_t* tg = tb.targets + (size_t)idx * nNb;
 #pragma unroll
-			for (int j = 0; j < MAXV - 1; ++j) t[j] = j < nNb ? tg[j] : -1;
-			const float dA = A.depth[idx]; // my own estimate: nobody else writes it during my image's pass
-			// round trip B
+				for (int j = 0; j < MAXV - 1; ++j) t[j] = j < nNb ? tg[j] : -1;
+				dA = A.depth[idx]; // my own estimate: nobody else writes it during my image's pass
+			} else {
+#pragma unroll
+				for (int j = 0; j < MAXV - 1; ++j) t[j] = -1;
+			}
+			// ---- round trip B: what my targets hold now (> 0 free, < 0 part of a point, 0 invalidated); my first dependants
 			float dB[MAXV - 1];
 #pragma unroll
 			for (int j = 0; j < MAXV - 1; ++j) {
 				dB[j] = 0.f;
-				if (t[j] < 0) continue;
-				dB[j] = ld_f32(depthOf[j] + (t[j] & kTargetIndexMask)); // > 0 free, < 0 part of a point, 0 invalidated
+				if (t[j] >= 0) dB[j] = ld_f32(depthOf[j] + (t[j] & kTargetIndexMask));
 			}
-			uint32_t rel[kRelBatch]; // the first batch of my dependants travels with round trip B
+			uint32_t rel[kRelBatch];
 #pragma unroll
 			for (int j = 0; j < kRelBatch; ++j) rel[j] = (uint32_t)j < relLen ? tb.nbrList[relOff + j] : FS_EMPTY;
 			// the decision (SceneDensify.cpp:3395-3449): targets still empty-handed merge or are invalidated
@@ -481,7 +509,7 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 				if ((t[j] >> kTargetShift) == kTargetMerge) merge |= 1u << j; else inFront |= 1u << j;
 			}
 			const int nv = 1 + __builtin_popcount(merge);
-			if (nv >= fp.nMinViewsFuse) { // a point: claim the merged estimates, remove the ones in front of it
+			if (have && nv >= fp.nMinViewsFuse) { // a point: claim the merged estimates, remove the ones in front of it
 				st_f32(&A.depth[idx], -dA);
 #pragma unroll
 				for (int j = 0; j < MAXV - 1; ++j) {
@@ -494,18 +522,24 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 				++accepted;
 				viewEntries += (unsigned)nv;
 			}
-			// round trip C -- decided: my stores must be out before anybody I release looks at them
+			// ---- round trip C -- decided: my stores must be out before anybody I release looks at them
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			++decided;
-			if (fp.levels) {
+			if (have) ++decided;
+			if (fp.levels && have) { // diagnostic (HCMVS_FUSE_DEBUG=2): my depth in the dependence graph -> my dependants
 				const uint32_t lvl = ld_u32(&fp.levels[idx]) + 1u;
 				atomicMax(fp.ctl + kCtlLevels, lvl);
 				uint32_t sink = 0;
 				for (uint32_t k = 0; k < relLen; ++k) sink += atomicMax(&fp.levels[tb.nbrList[relOff + k]], lvl);
 				asm volatile("" ::"v"(sink));
 			}
-			// round trip D: the countdowns of the pixels I block; whoever reaches zero is ready
-			for (uint32_t k0 = 0; k0 < relLen; k0 += kRelBatch) { // a pixel with more than kRelBatch dependants pays two more round trips per batch
+			// ---- round trip D: the countdowns of the pixels I block (whoever reaches zero is ready); with it the tail atomic for what
+			// waits in the overflow buffer
+			if (nFlush) {
+				rot = rot + 1u < (uint32_t)kFuseQueues ? rot + 1u : 0u;
+				if (lane == 0) tailBase = atomicAdd(fp.ctl + kCtlTail + 32u * rot, nFlush);
+			}
+			const uint32_t maxLen = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(relLen));
+			for (uint32_t k0 = 0; k0 < maxLen; k0 += kRelBatch) { // more than kRelBatch dependants: two more round trips per batch
 				uint32_t was[kRelBatch];
 				if (k0) {
 #pragma unroll
@@ -514,44 +548,161 @@ __global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* m
 #pragma unroll
 				for (int j = 0; j < kRelBatch; ++j) was[j] = rel[j] != FS_EMPTY ? atomicSub(&tb.cntP[rel[j]], 1u) : 0u;
 #pragma unroll
-				for (int j = 0; j < kRelBatch; ++j)
-					if (was[j] == 1u) ring_push(rel[j]);
+				for (int j = 0; j < kRelBatch; ++j) push(was[j] == 1u, rel[j]);
+			}
+			item = FS_EMPTY;
+		}
+		// ---- the wave-level results
+		if (nFlush) { // the tail atomic is back: what waited in the overflow buffer goes to its queue
+			const uint32_t base = (uint32_t)__shfl((int)tailBase, 0, 64);
+			uint32_t* const q = fp.queue + rot * fp.queueStride;
+			for (uint32_t i = (uint32_t)lane; i < nFlush; i += 64u) st_u32(&q[base + i], ovf[(ovfHead + i) & (uint32_t)(kPassOvf - 1)]);
+			ovfHead += nFlush;
+		}
+		push(polled != FS_EMPTY, polled); // what arrived through the queue joins the ring
+		if (polled != FS_EMPTY) slot = FS_EMPTY;
+		if (wantMask) {
+			const uint32_t base = (uint32_t)__shfl((int)headBase, wantLeader, 64);
+			if (want) slot = base + (uint32_t)__builtin_popcountll(wantMask & ltMask);
+		}
+		// the ring feeds the lanes (all idle here); what they cannot take goes to a global queue with the next iteration's tail atomic
+		if ((uint32_t)lane < ringCnt) item = ring[lane];
+		if (ringCnt > 64u) {
+			const uint32_t extra = ringCnt - 64u;
+			if (ovfTail - ovfHead + extra <= (uint32_t)kPassOvf) {
+				for (uint32_t i = (uint32_t)lane; i < extra; i += 64u) ovf[(ovfTail + i) & (uint32_t)(kPassOvf - 1)] = ring[64u + i];
+				ovfTail += extra;
+			} else { // cannot happen with the sizes above: straight to my own queue
+				for (uint32_t i = (uint32_t)lane; i < extra; i += 64u) st_u32(&myQueue[atomicAdd(fp.ctl + kCtlTail + 32u * myQ, 1u)], ring[64u + i]);
 			}
 		}
-		// what arrived through the queue joins the ring; then the ring feeds the lanes (all idle here)
-		if (polled != FS_EMPTY) { ring_push(polled); slot = FS_EMPTY; }
-		__syncthreads();
-		const uint32_t nReady = ringCnt < (uint32_t)kFuseRing ? ringCnt : (uint32_t)kFuseRing;
-		__syncthreads();
-		if (nReady) {
-			if ((uint32_t)lane < nReady) item = ring[lane];
-			if (nReady > 64u) { // what the lanes cannot take goes to a global queue (the next one in turn): one atomic on its tail word for the wave
-				rot = rot + 1u < (uint32_t)kFuseQueues ? rot + 1u : 0u;
-				uint32_t base = 0u;
-				if (lane == 0) base = atomicAdd(fp.ctl + kCtlTail + 32u * rot, nReady - 64u);
-				base = (uint32_t)__shfl((int)base, 0, 64);
-				uint32_t* const q = fp.queue + rot * fp.queueStride;
-				for (uint32_t k = 64u + (uint32_t)lane; k < nReady; k += 64u) st_u32(&q[base + k - 64u], ring[k]);
-			}
-			__syncthreads();
-			if (lane == 0) ringCnt = 0u;
-			__syncthreads();
-			spins = 0;
-		} else if (!busy) {
-			// an idle wave: pixels handed on inside a wave never pass through the queue, so the end of the pass is "every
-			// pending pixel decided", not "my slot is past the end"
+		if (ringCnt == 0u && !busy && ovfTail == ovfHead) {
+			// an idle wave: pixels handed on inside a wave never pass through a queue, so the end of the pass is "every pending pixel
+			// decided", not "my slot is past the end"
 			if (decided) { atomicAdd(nDone, decided); decided = 0; }
-			if ((spins & 7u) == 0u) { // the queue slots are polled every time round, the (single, hot) end-of-pass word less often
-				const bool over = ld_u32(nDone) >= nPending; // a worker that gives up sets the top bit
-				if (__ballot(over) != 0ull) break;
-			}
+			if (pollDone && __ballot(doneVal >= nPending) != 0ull) break;
 			if (++spins > (1u << 22)) { st_u32(errFlag, 1u); atomicOr(nDone, 0x80000000u); break; } // bounded: never hang the device
 			__builtin_amdgcn_s_sleep(8);
-		}
-		take_slots(item == FS_EMPTY && slot == FS_EMPTY, slot);
+		} else spins = 0;
 	}
 	if (decided) atomicAdd(nDone, decided);
-	if (fp.levels && lane == 0) { atomicAdd(fp.ctl + 8, dbgBusy); atomicAdd(fp.ctl + 9, dbgIdle); atomicAdd(fp.ctl + 10, dbgItems); }
+	if (lane == 0) { atomicAdd(fp.ctl + 8, dbgBusy); atomicAdd(fp.ctl + 9, dbgIdle); atomicAdd(fp.ctl + 10, dbgItems); }
+	if (accepted) { atomicAdd(&counters[3], (unsigned long long)accepted); atomicAdd(&counters[4], (unsigned long long)viewEntries); }
+}
+
+// ---- the image pass without a dependence chain -----------------------------------------------------------------------------
+// The sequential rule (SceneDensify.cpp:3395-3449) in closed form: pixel p becomes a point iff 1 + the number of its merge-class
+// targets that are still AVAILABLE reaches nMinViewsFuse, and a target is available to p iff no bidder of that target that comes
+// before p in the order of the pass has become a point (such a pixel has claimed the target or, lying in front of it, removed it).
+// That is a well-founded recursion over the order of the pass, so it has exactly one solution, and any iteration that keeps
+// re-evaluating the pixels whose inputs changed arrives at it: start from "every pixel is a point" (true for > 99 % of the pixels
+// of an estimated map), evaluate everybody in parallel, and then only the later bidders of the targets of whoever changed, until
+// nothing changes.  The steps are ordinary parallel kernels; their number is the length of the longest chain of CHANGES (a handful),
+// not of the dependence graph (hundreds to thousands of hops, which is what the dataflow pass above walks through one hop at a time).
+struct FuseSettle {
+	FuseTables tb;
+	uint8_t* acc;       // [w*h] 1: the pixel is a point (as far as the iteration knows)
+	uint32_t* stamp;    // [w*h] last step a pixel was put on a work list in (one entry per pixel and step)
+	uint32_t* work[2];  // work lists: step s reads work[(s - 1) & 1] and writes work[s & 1]
+	uint32_t* ctl;      // kCtlWork + s: length of the list step s wrote
+	const uint32_t* abort;
+	int nNb, nMinViewsFuse, order;
+};
+// is p a point, given what acc says about the pixels before it?  (the targets' bidder lists are short: a handful of pixels)
+__device__ __forceinline__ bool settle_eval(const FuseSettle& S, uint32_t p, uint32_t* mergeOut, uint32_t* inFrontOut) {
+	const uint32_t pp = fuse_prio(p, S.order);
+	uint32_t merge = 0u, inFront = 0u;
+	for (int q = 0; q < S.nNb; ++q) {
+		const int32_t tg = S.tb.targets[(size_t)p * S.nNb + q];
+		if (tg < 0) continue;
+		const size_t t = q * S.tb.stride + (size_t)(tg & kTargetIndexMask);
+		const uint32_t o = S.tb.offT[t], len = S.tb.cntT[t];
+		bool avail = true;
+		for (uint32_t k = 0; k < len && avail; ++k) {
+			const uint32_t b = S.tb.bidders[o + k];
+			if (b != p && fuse_prio(b, S.order) < pp && ld_u8(&S.acc[b]) != 0) avail = false;
+		}
+		if (!avail) continue;
+		if ((tg >> kTargetShift) == kTargetMerge) merge |= 1u << q; else inFront |= 1u << q;
+	}
+	if (mergeOut) { *mergeOut = merge; *inFrontOut = inFront; }
+	return 1 + __builtin_popcount(merge) >= S.nMinViewsFuse;
+}
+// one pixel of a step: re-evaluate; when the answer changed, the later bidders of its targets go on the next list (once per step)
+template <class APPEND>
+__device__ __forceinline__ void settle_pixel(const FuseSettle& S, uint32_t p, uint32_t step, APPEND append) {
+	const bool now = settle_eval(S, p, nullptr, nullptr);
+	if ((ld_u8(&S.acc[p]) != 0) == now) return;
+	st_u8(&S.acc[p], now ? 1 : 0);
+	const uint32_t pp = fuse_prio(p, S.order);
+	for (int q = 0; q < S.nNb; ++q) {
+		const int32_t tg = S.tb.targets[(size_t)p * S.nNb + q];
+		if (tg < 0) continue;
+		const size_t t = q * S.tb.stride + (size_t)(tg & kTargetIndexMask);
+		const uint32_t o = S.tb.offT[t], len = S.tb.cntT[t];
+		for (uint32_t k = 0; k < len; ++k) {
+			const uint32_t b = S.tb.bidders[o + k];
+			if (fuse_prio(b, S.order) > pp && atomicExch(&S.stamp[b], step + 1u) != step + 1u) append(b);
+		}
+	}
+}
+// step 0 evaluates every pending pixel, step s > 0 the list step s - 1 left; an empty list costs an empty launch
+__global__ void fuse_settle_step_kernel(FuseSettle S, const uint32_t* pending, uint32_t step) {
+	if (S.abort && S.abort[1] != 0u) return;
+	const uint32_t n = step == 0u ? S.ctl[kCtlPending] : S.ctl[kCtlWork + step - 1u];
+	if (n == 0u) return;
+	const uint32_t* list = step == 0u ? pending : S.work[(step - 1u) & 1u];
+	uint32_t* next = S.work[step & 1u];
+	uint32_t* cnt = S.ctl + kCtlWork + step;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+		settle_pixel(S, list[i], step, [&](uint32_t b) { next[atomicAdd(cnt, 1u)] = b; });
+}
+// whatever the kSettleSteps launches left: one workgroup goes on until the list is empty (no host in the loop, no bound on the
+// number of steps other than the safety limit)
+__global__ __launch_bounds__(1024) void fuse_settle_rest_kernel(FuseSettle S) {
+	if (S.abort && S.abort[1] != 0u) return;
+	__shared__ uint32_t nNext;
+	uint32_t n = S.ctl[kCtlWork + kSettleSteps];
+	uint32_t step = (uint32_t)kSettleSteps + 1u;
+	for (; n != 0u; ++step) {
+		if (step > (1u << 20)) { if (threadIdx.x == 0) S.ctl[kCtlErr] = 1u; break; } // never expected: bounded all the same
+		if (threadIdx.x == 0) nNext = 0u;
+		__syncthreads();
+		const uint32_t* list = S.work[(step - 1u) & 1u];
+		uint32_t* next = S.work[step & 1u];
+		for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+			settle_pixel(S, ld_u32(&list[i]), step, [&](uint32_t b) { st_u32(&next[atomicAdd(&nNext, 1u)], b); });
+		__syncthreads(); // also drains every wave's stores (s_waitcnt vmcnt(0) precedes the barrier)
+		n = nNext;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) { S.ctl[kCtlSteps] = step - 1u; if (S.ctl[kCtlErr] == 0u) S.ctl[kCtlDone] = S.ctl[kCtlPending]; }
+}
+// the decisions are final: the points claim the estimates they merge and remove the ones they lie in front of.  No two points
+// touch the same estimate (the earlier one made it unavailable to the later one).
+__global__ void fuse_settle_apply_kernel(DevMap A, const DevMap* maps, FuseSettle S, const uint32_t* pending, uint32_t* merged, FuseOut out,
+                                         unsigned long long* counters) {
+	if (S.abort && S.abort[1] != 0u) return;
+	const uint32_t n = S.ctl[kCtlPending];
+	unsigned accepted = 0, viewEntries = 0;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t p = pending[i];
+		if (!S.acc[p]) continue;
+		uint32_t merge = 0u, inFront = 0u;
+		settle_eval(S, p, &merge, &inFront);
+		A.depth[p] = -A.depth[p]; // the claim mark (launch_unclaim restores the sign)
+		for (int q = 0; q < S.nNb; ++q) {
+			if (!((merge | inFront) >> q & 1u)) continue;
+			float* d = maps[A.neighbors[q]].depth + (S.tb.targets[(size_t)p * S.nNb + q] & kTargetIndexMask);
+			*d = (merge >> q & 1u) ? -*d : 0.f;
+		}
+		const int nv = 1 + __builtin_popcount(merge);
+		out.nviews[p] = (uint32_t)nv;
+		merged[p] = merge;
+		out.flag[p] = 1;
+		++accepted;
+		viewEntries += (unsigned)nv;
+	}
 	if (accepted) { atomicAdd(&counters[3], (unsigned long long)accepted); atomicAdd(&counters[4], (unsigned long long)viewEntries); }
 }
 
@@ -828,7 +979,7 @@ void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_
 // the whole image pass in one launch of dataflow workers (one wave per workgroup; any grid size is correct), then the points
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, size_t queueStride, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
-                      uint32_t* merged, int nMinViewsFuse, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, const uint32_t* abort,
+                      uint32_t* merged, int nMinViewsFuse, int order, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, const uint32_t* abort,
                       hipStream_t s) {
 	FuseOut out{oxyz, onormal, obgr, onv, oflag, oviews, oweights, vstride};
 	FusePass fp;
@@ -837,10 +988,25 @@ void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb,
 	static const int xcdOnly = getenv("HCMVS_FUSE_XCD") ? atoi(getenv("HCMVS_FUSE_XCD")) : -1;
 	fp.xcd = xcdOnly;
 	if (xcdOnly >= 0) blocks *= 8;
-	hipLaunchKernelGGL(fuse_seed_kernel, kGrid, kBlock, 0, s, tb, pending, queue, queueStride, ctl, abort);
-	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_pass_kernel<16>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
-	else hipLaunchKernelGGL(fuse_pass_kernel<32>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
-	hipLaunchKernelGGL(fuse_queue_reset_kernel, kGrid, kBlock, 0, s, queue, queueStride, ctl, abort);
+	static const bool dataflow = getenv("HCMVS_FUSE_DATAFLOW") != nullptr; // diagnostic: the hop-by-hop pass instead of the settle iteration
+	if (dataflow) {
+		hipLaunchKernelGGL(fuse_seed_kernel, kGrid, kBlock, 0, s, tb, pending, queue, queueStride, ctl, abort);
+		if (A.nNeighbors <= 8) hipLaunchKernelGGL(fuse_pass_kernel<9>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
+		else if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_pass_kernel<16>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
+		else hipLaunchKernelGGL(fuse_pass_kernel<32>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
+		hipLaunchKernelGGL(fuse_queue_reset_kernel, kGrid, kBlock, 0, s, queue, queueStride, ctl, abort);
+	} else {
+		// scratch of the iteration inside the (otherwise unused) queue area: two work lists, the stamps, the flags
+		const size_t n = (size_t)A.w * A.h;
+		FuseSettle S;
+		S.tb = tb; S.work[0] = queue; S.work[1] = queue + queueStride; S.stamp = queue + 2 * queueStride; S.acc = (uint8_t*)(queue + 3 * queueStride);
+		S.ctl = ctl; S.abort = abort; S.nNb = A.nNeighbors; S.nMinViewsFuse = nMinViewsFuse; S.order = order;
+		(void)hipMemsetAsync(S.stamp, 0, n * 4, s);
+		(void)hipMemsetAsync(S.acc, 1, n, s);
+		for (int step = 0; step <= kSettleSteps; ++step) hipLaunchKernelGGL(fuse_settle_step_kernel, kGrid, kBlock, 0, s, S, pending, (uint32_t)step);
+		hipLaunchKernelGGL(fuse_settle_rest_kernel, dim3(1), dim3(1024), 0, s, S);
+		hipLaunchKernelGGL(fuse_settle_apply_kernel, kGrid, kBlock, 0, s, A, maps, S, pending, merged, out, counters);
+	}
 	if (!wantPoints) return;
 	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_points_kernel<16>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + kCtlPending - 1, abort);
 	else hipLaunchKernelGGL(fuse_points_kernel<32>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + kCtlPending - 1, abort);

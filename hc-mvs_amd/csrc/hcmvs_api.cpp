@@ -1047,6 +1047,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	HIPCHK(c, hipStreamSynchronize(s)); // claims reset, tables uploaded: the lanes may start
 	const auto tPasses = std::chrono::steady_clock::now();
 	const bool debug = getenv("HCMVS_FUSE_DEBUG") != nullptr;
+	const bool debugDepth = debug && atoi(getenv("HCMVS_FUSE_DEBUG")) >= 2; // also the depth of the dependence graph (slows the pass down)
 	if (!getenv("HCMVS_FUSE_LANES") && !debug) {
 		// The default: every pass of the fusion enqueued on the context's stream, no host synchronisation between the images
 		// (stream order is the order of the sequential loop).  What the lanes below ask the host for is kept on the device: the
@@ -1103,7 +1104,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 				launch_fuse_links_check(tb, (unsigned long long)L.capLinks, status, s);
 				launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, status, s);
 				launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, maxArea, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
-				                 merged, n_min_views_fuse, counters, blocks, nullptr, wantCloud, status, s);
+				                 merged, n_min_views_fuse, c->fuseOrder, counters, blocks, nullptr, wantCloud, status, s);
 				launch_fuse_status(ctl, status, s);
 				if (wantCloud)
 					launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, 0, capacity, cX, cN, cB, cV, pviews, pweights, vstride,
@@ -1225,10 +1226,10 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 				tb.nbrList = L.links;
 			}
 			launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, nullptr, ls);
-			if (debug) LANECHK(hipMemsetAsync(flag32, 0, (size_t)n * 4, ls)); // diagnostic: dependence depth per pixel (the buffer is free until the compaction)
+			if (debugDepth) LANECHK(hipMemsetAsync(flag32, 0, (size_t)n * 4, ls)); // diagnostic: dependence depth per pixel (the buffer is free until the compaction)
 			const auto tPass = std::chrono::steady_clock::now();
 			launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, maxArea, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
-			                 merged, n_min_views_fuse, counters, blocks, debug ? flag32 : nullptr, wantCloud, nullptr, ls);
+			                 merged, n_min_views_fuse, c->fuseOrder, counters, blocks, debugDepth ? flag32 : nullptr, wantCloud, nullptr, ls);
 			unsigned long long cnt[5] = {0, 0, 0, 0, 0};
 			uint32_t ctlWords[kCtlBytes / 4];
 			LANECHK(hipMemcpyAsync(cnt, counters, 40, hipMemcpyDeviceToHost, ls));
@@ -1243,9 +1244,10 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 			}
 			if (debug) {
 				const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tPass).count();
-				fprintf(stderr, "fuse: lane %d image %u: %u pending pixels, %u through the queue, %llu accepted; dependence depth %u, pass %.0f us = %.2f us per level; worker iterations %u busy (%.1f pixels each) + %u idle\n",
+				fprintf(stderr, "fuse: lane %d image %u: %u pending pixels, %u through the queues, %llu accepted; dependence depth %u, pass %.0f us = %.2f us per level; worker iterations %u busy (%.1f pixels each) + %u idle; settle steps %u, work lists %u %u %u %u %u %u %u\n",
 				        k, A.id, ctlWords[kCtlPending], [&] { uint32_t t = 0; for (int q = 0; q < kFuseQueues; ++q) t += ctlWords[kCtlTail + 32 * q]; return t; }(), cnt[3], ctlWords[kCtlLevels], us, us / std::max(1u, ctlWords[kCtlLevels]),
-				        ctlWords[8], ctlWords[10] / (double)std::max(1u, ctlWords[8]), ctlWords[9]);
+				        ctlWords[8], ctlWords[10] / (double)std::max(1u, ctlWords[8]), ctlWords[9], ctlWords[kCtlSteps], ctlWords[kCtlWork], ctlWords[kCtlWork + 1],
+				        ctlWords[kCtlWork + 2], ctlWords[kCtlWork + 3], ctlWords[kCtlWork + 4], ctlWords[kCtlWork + 5], ctlWords[kCtlWork + 6]);
 			}
 			unsigned long long total = 0, viewTotal = 0;
 			{ // publish the counts; wait until every earlier image has published its own -> this image's place in the cloud
@@ -1423,7 +1425,7 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 				launch_fuse_links_check(tb, (unsigned long long)L.capLinks, status, s);
 				launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, status, s);
 				launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, maxArea, ctl, nullptr, nullptr, nullptr, pnv, flag, nullptr, nullptr, maxNb + 1, merged, n_min_views_fuse,
-				                 counters, blocks, nullptr, false, status, s);
+				                 c->fuseOrder, counters, blocks, nullptr, false, status, s);
 				launch_fuse_status(ctl, status, s);
 			}
 			launch_postfilter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, c->dMaps, (int)host.size(), v.gra, dF, nF, gap_size, depth_diff_threshold * 2.5f, counters + 5, status, s);

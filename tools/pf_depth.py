@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT)
 if len(sys.argv) > 2 and sys.argv[2] == "child":
     import numpy as np, torch
     binding = importlib.import_module("hc-mvs_amd.binding")
+    if os.environ.get("HCMVS_LIB"):   # a diagnostic build of the library
+        binding.LIB_PATH = binding.LIB_PATH.replace("libhcmvs_hip.so", os.environ["HCMVS_LIB"])
     synth = importlib.import_module("hc-mvs_amd.synth")
     W, H, F = 1920, 1080, 1600.0
     n = int(sys.argv[1])
@@ -49,11 +51,11 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     sys.exit(0)
 n = sys.argv[1] if len(sys.argv) > 1 else "9"
 for blocks in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("", "2048", "4096")):
-    env = dict(os.environ, HCMVS_FUSE_DEBUG="1", HCMVS_FUSE_LANES="1")
+    env = dict(os.environ, HCMVS_FUSE_DEBUG=os.environ.get("HCMVS_FUSE_DEBUG", "2"), HCMVS_FUSE_LANES="1")  # 1: times without the depth instrumentation
     if blocks:
         env["HCMVS_FUSE_BLOCKS"] = blocks
     r = subprocess.run([sys.executable, os.path.abspath(__file__), n, "child"], env=env, capture_output=True, text=True)
     print("== HCMVS_FUSE_BLOCKS", blocks or "default (4 per CU)")
     for ln in (r.stdout + r.stderr).splitlines():
         if ln.startswith(("MAPS", "POINTS", "fuse:")):
-            print(ln[:230])
+            print(ln)
