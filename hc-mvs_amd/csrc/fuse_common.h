@@ -34,48 +34,40 @@ void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsig
 struct FuseTables {
 	int32_t* targets;    // [w*h][nNeighbors]: pixel index A's pixel projects onto in neighbour q (SceneDensify.cpp:3387-3393) + what it can do there
 	                     // (bits 29-30: merge / in front); -1 when it can do nothing
-	uint32_t* cntT;      // [nNeighbors][stride]: number of pending pixels of A that project onto each neighbour pixel
+	uint32_t* cntT;      // [nNeighbors][stride]: number of pending pixels of A that project onto each neighbour pixel ("bidders" of that target)
 	uint32_t* offT;      // exclusive scan of cntT: start of that neighbour pixel's list in `bidders`
 	uint32_t* fillT;     // fill cursors while the lists are written
 	uint32_t* bidders;   // the lists: raster indices of A's pending pixels, per target
-	uint32_t* cntP;      // [2][stride]: per pixel of A, how many pixels share a target with it -- lower / higher raster index
-	uint32_t* offP;      // exclusive scan of cntP: start of the pixel's lower / higher list in `nbrList`
-	uint32_t* nbrList;   // those pixels (a pixel may appear more than once); the lower half of cntP is the countdown of the pass
 	size_t stride;       // pixels reserved per neighbour map in cntT / offT / fillT
 };
 
-FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_t* fillT, uint32_t* bidders, uint32_t* cntP, uint32_t* offP,
-                       uint32_t* nbrList, size_t stride);
-// ctl: kCtlBytes, zero before the pass.  The words every wave of the pass hammers lie on lines of their own: the tail and the head
-// of ready queue q at kCtlTail + 32 q and kCtlHead + 32 q.
-constexpr int kFuseQueues = 16;
+FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_t* fillT, uint32_t* bidders, size_t stride);
+// ctl: kCtlBytes, zero before the pass: [kCtlPending] pending pixels, [kCtlErr] the settle iteration gave up (never expected),
+// [kCtlSteps] steps it took, [kCtlWork + s] length of the work list step s wrote (diagnostics)
 constexpr int kSettleSteps = 3; // full-grid steps of the settle iteration after step 0; a single workgroup finishes what they leave
-constexpr int kCtlSteps = 6, kCtlWork = 16; // steps the iteration took; kCtlWork + s: length of the work list step s wrote (s <= kSettleSteps)
-constexpr int kCtlPending = 4, kCtlLevels = 5, kCtlDone = 32, kCtlErr = 64, kCtlTail = 128, kCtlHead = kCtlTail + 32 * kFuseQueues; // word indices
-constexpr size_t kCtlBytes = 4 * (size_t)(kCtlHead + 32 * kFuseQueues);
+constexpr int kCtlPending = 4, kCtlSteps = 6, kCtlWork = 16, kCtlErr = 32; // word indices
+constexpr size_t kCtlBytes = 256;
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
-                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, float thDepth, float normalError, const uint32_t* abort, hipStream_t s);
-void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, const uint32_t* abort, hipStream_t s);
-// a fusion enqueued without host synchronisation (hcmvs_postfilter_sequence): abort = its status words ([0] stall, [1] link lists too
-// small -> every later kernel of the fusion returns at once, [2] the size needed), null for the synchronous path
-void launch_fuse_links_check(const FuseTables& tb, unsigned long long capLinks, uint32_t* status, hipStream_t s);
+                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, float thDepth, float normalError, hipStream_t s);
+// status words of a fusion enqueued without host synchronisation: [0] a pass gave up (never expected), [3] = 1 / 2: the cloud / the view
+// lists overflowed their capacity
 void launch_fuse_status(const uint32_t* ctl, uint32_t* status, hipStream_t s);
 void launch_unclaim(const DevMap* maps, int nMaps, hipStream_t s); // takes the claim marks (negative depths) off every map
-// queue: kFuseQueues x queueStride slots, all FS_EMPTY (0xFFFFFFFF) before the first pass of a call; a pass leaves them so
-void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, size_t queueStride, uint32_t* ctl,
+size_t fuse_settle_bytes(size_t pixels); // scratch of launch_fuse_pass for an image of that many pixels
+void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, void* settle, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
-                      uint32_t* merged, int nMinViewsFuse, int order, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, const uint32_t* abort,
-                      hipStream_t s);
+                      uint32_t* merged, int nMinViewsFuse, int order, unsigned long long* counters, bool wantPoints, hipStream_t s);
 void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const DevMap* maps, int nMaps, const uint8_t* gra, float* dF, float* nF,
-                       int gap, float thr, unsigned long long* filled, const uint32_t* abort, hipStream_t s);
+                       int gap, float thr, unsigned long long* filled, hipStream_t s);
 void launch_point_colors(unsigned long long n, const float* xyz, const unsigned long long* voff, const uint32_t* views, const DevMap* maps, uint8_t* bgr, hipStream_t s);
 size_t fuse_scan_temp_bytes(int n);
+// bases: device words [0] points, [1] view entries written by the images before this one (null: base / viewBase)
 void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,
                          float* onormal, uint8_t* obgr, uint32_t* onv, unsigned long long base, unsigned long long capacity, float* xyz,
                          float* normal, uint8_t* bgr, uint32_t* nviews, uint32_t* oviews, float* oweights, int vstride, uint32_t* voff,
                          unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights, const unsigned long long* bases,
-                         const uint32_t* abort, hipStream_t s);
-// unsynchronised fusion: totals [0] points, [1] view entries, [2] depths so far; status[3] = 1 / 2 when the cloud / the view lists overflow
+                         hipStream_t s);
+// after an image's compaction: totals [0] points, [1] view entries, [2] depths so far; status[3] = 1 / 2 when the cloud / the view lists overflow
 void launch_fuse_advance(const unsigned long long* counters, unsigned long long* totals, unsigned long long capacity, unsigned long long viewCapacity,
                          uint32_t* status, hipStream_t s);
 

@@ -208,11 +208,6 @@ __device__ __forceinline__ void st_u8(uint8_t* p, uint8_t v) { __hip_atomic_stor
 __device__ __forceinline__ float ld_f32(const float* p) { return __uint_as_float(ld_u32((const uint32_t*)p)); }
 __device__ __forceinline__ void st_f32(float* p, float v) { st_u32((uint32_t*)p, __float_as_uint(v)); }
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { // the maximum over the 64 lanes, in every lane
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) { const uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64); v = v > w ? v : w; }
-	return v;
-}
 __device__ __forceinline__ void list_append(bool pred, int value, uint32_t* list, uint32_t* count) { // one atomic per wave
 	const unsigned long long m = __ballot(pred);
 	if (!pred) return;
@@ -241,8 +236,7 @@ __device__ __forceinline__ void rotate_normal(const DevMap& M, const float* nm, 
 // depth and normal, SceneDensify.cpp:3400-3404) or lies in front of it (:3418).  The pass itself only has to look at what
 // is left of the target when the pixel's turn comes.
 __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, uint32_t* pending, uint32_t* roundCnt, uint8_t* flag,
-                                  unsigned long long* counters, float thDepth, float normalError, const uint32_t* abort) {
-	if (abort && abort[1] != 0u) return;
+                                  unsigned long long* counters, float thDepth, float normalError) {
 	const int n = A.w * A.h;
 	unsigned nd = 0;
 	const int nPad = (n + 63) & ~63; // whole waves take part in list_append
@@ -285,8 +279,7 @@ __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, u
 	if (nd) atomicAdd(&counters[0], (unsigned long long)nd); // valid depths visited (SceneDensify.cpp:3359)
 }
 // write the per-target lists (any order inside a list)
-__global__ void fuse_fill_kernel(int nNb, FuseTables tb, const uint32_t* pending, const uint32_t* roundCnt, const uint32_t* abort) {
-	if (abort && abort[1] != 0u) return;
+__global__ void fuse_fill_kernel(int nNb, FuseTables tb, const uint32_t* pending, const uint32_t* roundCnt) {
 	const int n = (int)roundCnt[1];
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint32_t idx = pending[i];
@@ -299,32 +292,8 @@ __global__ void fuse_fill_kernel(int nNb, FuseTables tb, const uint32_t* pending
 	}
 }
 
-// per pending pixel: the pixels sharing a target with it, split into lower (they block it) and higher raster indices
-// (it wakes them); pass 0 counts, pass 1 writes the lists at the scanned offsets
 // order: 0 = raster order (the reference's), 1 = a fixed pseudo-random order (a bijective hash of the raster index)
 __device__ __forceinline__ uint32_t fuse_prio(uint32_t idx, int order) { return order ? idx * 0x9E3779B1u : idx; }
-__global__ void fuse_links_kernel(int nNb, FuseTables tb, const uint32_t* pending, const uint32_t* roundCnt, int write, int order, const uint32_t* abort) {
-	if (abort && abort[1] != 0u) return; // the link lists do not fit (fuse_links_check_kernel): the host grows them and runs the fusion again
-	const int n = (int)roundCnt[1];
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const uint32_t idx = pending[i];
-		uint32_t nLow = 0, nHigh = 0;
-		const uint32_t oLow = write ? tb.offP[idx] : 0u, oHigh = write ? tb.offP[tb.stride + idx] : 0u;
-		for (int q = 0; q < nNb; ++q) {
-			const int32_t tg = tb.targets[(size_t)idx * nNb + q];
-			if (tg < 0) continue;
-			const size_t t = q * tb.stride + (size_t)(tg & kTargetIndexMask);
-			const uint32_t o = tb.offT[t], len = tb.cntT[t];
-			for (uint32_t k = 0; k < len; ++k) {
-				const uint32_t b = tb.bidders[o + k];
-				if (b == idx) continue;
-				if (fuse_prio(b, order) < fuse_prio(idx, order)) { if (write) tb.nbrList[oLow + nLow] = b; ++nLow; }
-				else { if (write) tb.nbrList[oHigh + nHigh] = b; ++nHigh; }
-			}
-		}
-		if (!write) { tb.cntP[idx] = nLow; tb.cntP[tb.stride + idx] = nHigh; }
-	}
-}
 
 struct FuseOut { // per pixel of the current image, compacted in raster order afterwards
 	float* xyz; float* normal; uint8_t* bgr; uint32_t* nviews; uint8_t* flag;
@@ -332,14 +301,9 @@ struct FuseOut { // per pixel of the current image, compacted in raster order af
 };
 // status words of a fusion enqueued without host synchronisation (hcmvs_postfilter_sequence): [0] a pass stalled or timed out,
 // [1] the link lists of a pass do not fit (nothing after that point has touched the maps), [2] the size they need
-__global__ void fuse_links_check_kernel(FuseTables tb, unsigned long long capLinks, uint32_t* status) {
-	if (blockIdx.x != 0 || threadIdx.x != 0) return;
-	const unsigned long long need = (unsigned long long)tb.offP[2 * tb.stride - 1] + tb.cntP[2 * tb.stride - 1];
-	if (need > capLinks) { status[1] = 1u; atomicMax(&status[2], (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need)); }
-}
 __global__ void fuse_status_kernel(const uint32_t* ctl, uint32_t* status) {
-	if (blockIdx.x != 0 || threadIdx.x != 0 || status[1] != 0u) return;
-	if (ctl[kCtlErr] != 0u || ctl[kCtlDone] != ctl[kCtlPending]) status[0] = 1u;
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	if (ctl[kCtlErr] != 0u) status[0] = 1u;
 }
 // after an image's compaction: the image's counts (counters[0] depths, [3] points, [4] view entries) join the running totals the
 // next image's compaction starts from; status[3] says that the cloud (1) or the view lists (2) do not fit
@@ -362,234 +326,6 @@ __global__ void unclaim_kernel(const DevMap* maps, int nMaps) {
 		}
 	}
 }
-struct FusePass {
-	FuseTables tb;
-	uint32_t* queue;         // kFuseQueues append-only ready queues of queueStride slots each, FS_EMPTY until written: a worker takes its slots
-	size_t queueStride;      // from ONE of them (workgroup index mod kFuseQueues) and spreads what it appends over all of them, so that no
-	                         // head or tail word is hammered by more than a sixteenth of the workers
-	uint32_t* ctl;           // kCtl* words (fuse_common.h): queue tail, queue head, pixels decided, error flag -- each on a line of its own,
-	                         // they are hammered by every wave of the pass -- and the number of pending pixels (set by fuse_begin)
-	uint32_t* merged;        // [w*h] out: per point, which neighbours' estimates it merged (bit q = neighbour q)
-	uint32_t* levels;        // diagnostic (HCMVS_FUSE_DEBUG), else null: per-pixel depth in the dependence graph, maximum in ctl[kCtlLevels]
-	const uint32_t* abort;   // null, or the status words of an unsynchronised fusion: [1] != 0 -> do nothing
-	int nMinViewsFuse;
-	int xcd;                 // diagnostic (HCMVS_FUSE_XCD): >= 0 -> only the workgroups that land on this XCD work
-};
-#define FS_EMPTY 0xFFFFFFFFu
-
-// seed of the pass: the pending pixels nobody blocks.  A launch of its own: the pass counts the countdowns down, and a
-// pixel that reaches zero there must not be taken for a seed as well.
-__global__ void fuse_seed_kernel(FuseTables tb, const uint32_t* pending, uint32_t* queue, size_t queueStride, uint32_t* ctl, const uint32_t* abort) {
-	if (abort && abort[1] != 0u) return;
-	const uint32_t q = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) % (uint32_t)kFuseQueues; // a wave appends to one queue
-	const uint32_t nPending = ctl[kCtlPending];
-	const uint32_t nPad = (nPending + 63u) & ~63u; // whole waves take part in list_append (one atomic per wave, not per pixel)
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nPad; i += gridDim.x * blockDim.x) {
-		const uint32_t idx = i < nPending ? pending[i] : 0u;
-		const bool seed = i < nPending && tb.cntP[idx] == 0u;
-		list_append(seed, (int)idx, queue + q * queueStride, ctl + kCtlTail + 32u * q);
-	}
-}
-
-// after the pass: the slots that were used are FS_EMPTY again (the queues are all-empty between passes)
-__global__ void fuse_queue_reset_kernel(uint32_t* queue, size_t queueStride, const uint32_t* ctl, const uint32_t* abort) {
-	if (abort && abort[1] != 0u) return;
-	for (int q = 0; q < kFuseQueues; ++q) {
-		const uint32_t used = ctl[kCtlTail + 32 * q] < (uint32_t)queueStride ? ctl[kCtlTail + 32 * q] : (uint32_t)queueStride;
-		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < used; i += gridDim.x * blockDim.x) queue[q * queueStride + i] = FS_EMPTY;
-	}
-}
-
-// The dataflow pass.  Its run time on estimated maps is the length of the longest dependence chain (a few hundred to a few
-// thousand pixels) times the time of one hop, so a hop carries the order-dependent decision and nothing else -- which of
-// its targets a pixel still finds untouched, hence how many views agree, hence whether it becomes a point and claims /
-// invalidates them (SceneDensify.cpp:3395-3449) -- in four memory round trips:
-//   A  the pixel's stored targets and where its list of dependants lies -- together with the poll of this lane's queue slot;
-//   B  what the targets hold now (agent-scope loads) and the dependants' indices;
-//   C  the drain of my stores (claims, invalidated depths), which the dependants must see;
-//   D  the dependants' countdowns (returning atomics).
-// A pixel whose countdown I bring to zero goes to a ring in LDS and is run by a lane of this wave in the very next
-// iteration; only what exceeds the wave's 64 lanes goes to the global queue, whose slots idle lanes poll.  The points
-// themselves (double-precision sums, colours, normals, view lists) are computed afterwards, in parallel, from the merge
-// masks the pass leaves (fuse_points_kernel).
-constexpr int kRelBatch = 8; // dependants whose countdowns go out in one round trip
-
-// MAXV: the image itself + its neighbours; 16 covers the reference's cap of 12 neighbours (nMaxViews, DepthMap.cpp:73)
-// A single wave per workgroup: no barriers, the ring of ready pixels is filled by ballot compaction (no LDS atomics), and the
-// wave-level atomics travel with the lanes' round trips (the head atomic that hands out queue slots with A, the tail atomic for
-// what the wave cannot run itself with D).
-constexpr int kPassRing = 64 * (kRelBatch + 1); // what one iteration can make ready at most
-constexpr int kPassOvf = 4096;                  // ready pixels on their way to a global queue (power of two)
-template <int MAXV>
-__global__ __launch_bounds__(64) void fuse_pass_kernel(DevMap A, const DevMap* maps, FusePass fp, FuseOut out, const uint32_t* pending,
-                                                        unsigned long long* counters) {
-	__shared__ float* depthOf[MAXV - 1];
-	__shared__ uint32_t ring[kPassRing];
-	__shared__ uint32_t ovf[kPassOvf];
-	if (fp.abort && fp.abort[1] != 0u) return; // wave-uniform
-	if (fp.xcd >= 0 && (int)(__builtin_amdgcn_s_getreg(6164) & 7u) != fp.xcd) return; // HW_REG_XCC_ID[3:0]
-	const int nNb = A.nNeighbors;
-	const int lane = threadIdx.x;
-	const unsigned long long ltMask = (1ull << lane) - 1ull;
-	if (lane < nNb) { const DevMap& B = maps[A.neighbors[lane]]; depthOf[lane] = B.depth; }
-	__syncthreads();
-	const FuseTables& tb = fp.tb;
-	const uint32_t nPending = fp.ctl[kCtlPending];
-	const uint32_t myQ = (fp.xcd >= 0 ? blockIdx.x >> 3 : blockIdx.x) % (uint32_t)kFuseQueues; // the queue this wave takes its slots from
-	uint32_t* const myQueue = fp.queue + myQ * fp.queueStride;
-	uint32_t* const qHead = fp.ctl + kCtlHead + 32u * myQ, *const nDone = fp.ctl + kCtlDone, *const errFlag = fp.ctl + kCtlErr;
-	uint32_t rot = myQ; // the queue the next batch this wave hands on goes to
-	uint32_t item = FS_EMPTY, slot = FS_EMPTY; // the pixel I run next; the queue slot I wait on
-	uint32_t ringCnt = 0u, ovfHead = 0u, ovfTail = 0u; // wave-uniform
-	unsigned accepted = 0, decided = 0, viewEntries = 0, spins = 0;
-	unsigned dbgBusy = 0, dbgIdle = 0, dbgItems = 0; // diagnostic: iterations with / without a pixel to run, pixels run (ctl[8..10])
-	auto push = [&](bool pred, uint32_t v) { // wave-uniform call: the lanes with pred append v to the ring of ready pixels
-		const unsigned long long m = __ballot(pred);
-		if (m == 0ull) return;
-		if (pred) {
-			const uint32_t pos = ringCnt + (uint32_t)__builtin_popcountll(m & ltMask);
-			if (pos < (uint32_t)kPassRing) ring[pos] = v;
-			else st_u32(&myQueue[atomicAdd(fp.ctl + kCtlTail + 32u * myQ, 1u)], v); // cannot happen with the sizes above
-		}
-		ringCnt += (uint32_t)__builtin_popcountll(m);
-		if (ringCnt > (uint32_t)kPassRing) ringCnt = (uint32_t)kPassRing;
-	};
-	for (;;) {
-		const bool have = item != FS_EMPTY;
-		const unsigned long long haveMask = __ballot(have);
-		const bool busy = haveMask != 0ull;
-		if (busy) { ++dbgBusy; dbgItems += (unsigned)__builtin_popcountll(haveMask); } else ++dbgIdle;
-		// ---- round trip A: my tables; with it the poll of my queue slot, the head atomic for the lanes that need a slot and (idle
-		// waves) the end-of-pass word
-		uint32_t polled = FS_EMPTY, headBase = 0u, doneVal = 0u;
-		if (slot < nPending) polled = ld_u32(&myQueue[slot]); // a slot past the end can never be filled
-		const bool want = !have && slot == FS_EMPTY;
-		const unsigned long long wantMask = __ballot(want);
-		const int wantLeader = wantMask ? __builtin_ctzll(wantMask) : 0;
-		if (wantMask && lane == wantLeader) headBase = atomicAdd(qHead, (uint32_t)__builtin_popcountll(wantMask));
-		const uint32_t nFlush = ovfTail - ovfHead;
-		const bool pollDone = !busy && nFlush == 0u && (spins & 7u) == 0u;
-		if (pollDone) doneVal = ld_u32(nDone); // a worker that gives up sets the top bit
-		uint32_t tailBase = 0u;
-		if (!busy && nFlush) { // nothing to run: the tail atomic cannot ride with D
-			rot = rot + 1u < (uint32_t)kFuseQueues ? rot + 1u : 0u;
-			if (lane == 0) tailBase = atomicAdd(fp.ctl + kCtlTail + 32u * rot, nFlush);
-		}
-		ringCnt = 0u;
-		if (busy) {
-			const int idx = have ? (int)item : 0;
-			uint32_t relOff = 0u, relLen = 0u;
-			int32_t t[MAXV - 1];
-			float dA = 0.f;
-			if (have) {
-				relOff = tb.offP[tb.stride + idx]; relLen = tb.cntP[tb.stride + idx];
-				const int32_t* tg = tb.targets + (size_t)idx * nNb;
-#pragma unroll
-				for (int j = 0; j < MAXV - 1; ++j) t[j] = j < nNb ? tg[j] : -1;
-				dA = A.depth[idx]; // my own estimate: nobody else writes it during my image's pass
-			} else {
-#pragma unroll
-				for (int j = 0; j < MAXV - 1; ++j) t[j] = -1;
-			}
-			// ---- round trip B: what my targets hold now (> 0 free, < 0 part of a point, 0 invalidated); my first dependants
-			float dB[MAXV - 1];
-#pragma unroll
-			for (int j = 0; j < MAXV - 1; ++j) {
-				dB[j] = 0.f;
-				if (t[j] >= 0) dB[j] = ld_f32(depthOf[j] + (t[j] & kTargetIndexMask));
-			}
-			uint32_t rel[kRelBatch];
-#pragma unroll
-			for (int j = 0; j < kRelBatch; ++j) rel[j] = (uint32_t)j < relLen ? tb.nbrList[relOff + j] : FS_EMPTY;
-			// the decision (SceneDensify.cpp:3395-3449): targets still empty-handed merge or are invalidated
-			uint32_t merge = 0u, inFront = 0u;
-#pragma unroll
-			for (int j = 0; j < MAXV - 1; ++j) {
-				if (t[j] < 0 || !(dB[j] > 0.f)) continue;
-				if ((t[j] >> kTargetShift) == kTargetMerge) merge |= 1u << j; else inFront |= 1u << j;
-			}
-			const int nv = 1 + __builtin_popcount(merge);
-			if (have && nv >= fp.nMinViewsFuse) { // a point: claim the merged estimates, remove the ones in front of it
-				st_f32(&A.depth[idx], -dA);
-#pragma unroll
-				for (int j = 0; j < MAXV - 1; ++j) {
-					if (merge >> j & 1u) st_f32(depthOf[j] + (t[j] & kTargetIndexMask), -dB[j]);
-					if (inFront >> j & 1u) st_f32(depthOf[j] + (t[j] & kTargetIndexMask), 0.f);
-				}
-				out.nviews[idx] = (uint32_t)nv;
-				fp.merged[idx] = merge;
-				out.flag[idx] = 1;
-				++accepted;
-				viewEntries += (unsigned)nv;
-			}
-			// ---- round trip C -- decided: my stores must be out before anybody I release looks at them
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (have) ++decided;
-			if (fp.levels && have) { // diagnostic (HCMVS_FUSE_DEBUG=2): my depth in the dependence graph -> my dependants
-				const uint32_t lvl = ld_u32(&fp.levels[idx]) + 1u;
-				atomicMax(fp.ctl + kCtlLevels, lvl);
-				uint32_t sink = 0;
-				for (uint32_t k = 0; k < relLen; ++k) sink += atomicMax(&fp.levels[tb.nbrList[relOff + k]], lvl);
-				asm volatile("" ::"v"(sink));
-			}
-			// ---- round trip D: the countdowns of the pixels I block (whoever reaches zero is ready); with it the tail atomic for what
-			// waits in the overflow buffer
-			if (nFlush) {
-				rot = rot + 1u < (uint32_t)kFuseQueues ? rot + 1u : 0u;
-				if (lane == 0) tailBase = atomicAdd(fp.ctl + kCtlTail + 32u * rot, nFlush);
-			}
-			const uint32_t maxLen = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(relLen));
-			for (uint32_t k0 = 0; k0 < maxLen; k0 += kRelBatch) { // more than kRelBatch dependants: two more round trips per batch
-				uint32_t was[kRelBatch];
-				if (k0) {
-#pragma unroll
-					for (int j = 0; j < kRelBatch; ++j) rel[j] = k0 + j < relLen ? tb.nbrList[relOff + k0 + j] : FS_EMPTY;
-				}
-#pragma unroll
-				for (int j = 0; j < kRelBatch; ++j) was[j] = rel[j] != FS_EMPTY ? atomicSub(&tb.cntP[rel[j]], 1u) : 0u;
-#pragma unroll
-				for (int j = 0; j < kRelBatch; ++j) push(was[j] == 1u, rel[j]);
-			}
-			item = FS_EMPTY;
-		}
-		// ---- the wave-level results
-		if (nFlush) { // the tail atomic is back: what waited in the overflow buffer goes to its queue
-			const uint32_t base = (uint32_t)__shfl((int)tailBase, 0, 64);
-			uint32_t* const q = fp.queue + rot * fp.queueStride;
-			for (uint32_t i = (uint32_t)lane; i < nFlush; i += 64u) st_u32(&q[base + i], ovf[(ovfHead + i) & (uint32_t)(kPassOvf - 1)]);
-			ovfHead += nFlush;
-		}
-		push(polled != FS_EMPTY, polled); // what arrived through the queue joins the ring
-		if (polled != FS_EMPTY) slot = FS_EMPTY;
-		if (wantMask) {
-			const uint32_t base = (uint32_t)__shfl((int)headBase, wantLeader, 64);
-			if (want) slot = base + (uint32_t)__builtin_popcountll(wantMask & ltMask);
-		}
-		// the ring feeds the lanes (all idle here); what they cannot take goes to a global queue with the next iteration's tail atomic
-		if ((uint32_t)lane < ringCnt) item = ring[lane];
-		if (ringCnt > 64u) {
-			const uint32_t extra = ringCnt - 64u;
-			if (ovfTail - ovfHead + extra <= (uint32_t)kPassOvf) {
-				for (uint32_t i = (uint32_t)lane; i < extra; i += 64u) ovf[(ovfTail + i) & (uint32_t)(kPassOvf - 1)] = ring[64u + i];
-				ovfTail += extra;
-			} else { // cannot happen with the sizes above: straight to my own queue
-				for (uint32_t i = (uint32_t)lane; i < extra; i += 64u) st_u32(&myQueue[atomicAdd(fp.ctl + kCtlTail + 32u * myQ, 1u)], ring[64u + i]);
-			}
-		}
-		if (ringCnt == 0u && !busy && ovfTail == ovfHead) {
-			// an idle wave: pixels handed on inside a wave never pass through a queue, so the end of the pass is "every pending pixel
-			// decided", not "my slot is past the end"
-			if (decided) { atomicAdd(nDone, decided); decided = 0; }
-			if (pollDone && __ballot(doneVal >= nPending) != 0ull) break;
-			if (++spins > (1u << 22)) { st_u32(errFlag, 1u); atomicOr(nDone, 0x80000000u); break; } // bounded: never hang the device
-			__builtin_amdgcn_s_sleep(8);
-		} else spins = 0;
-	}
-	if (decided) atomicAdd(nDone, decided);
-	if (lane == 0) { atomicAdd(fp.ctl + 8, dbgBusy); atomicAdd(fp.ctl + 9, dbgIdle); atomicAdd(fp.ctl + 10, dbgItems); }
-	if (accepted) { atomicAdd(&counters[3], (unsigned long long)accepted); atomicAdd(&counters[4], (unsigned long long)viewEntries); }
-}
-
 // ---- the image pass without a dependence chain -----------------------------------------------------------------------------
 // The sequential rule (SceneDensify.cpp:3395-3449) in closed form: pixel p becomes a point iff 1 + the number of its merge-class
 // targets that are still AVAILABLE reaches nMinViewsFuse, and a target is available to p iff no bidder of that target that comes
@@ -605,7 +341,6 @@ struct FuseSettle {
 	uint32_t* stamp;    // [w*h] last step a pixel was put on a work list in (one entry per pixel and step)
 	uint32_t* work[2];  // work lists: step s reads work[(s - 1) & 1] and writes work[s & 1]
 	uint32_t* ctl;      // kCtlWork + s: length of the list step s wrote
-	const uint32_t* abort;
 	int nNb, nMinViewsFuse, order;
 };
 // is p a point, given what acc says about the pixels before it?  (the targets' bidder lists are short: a handful of pixels)
@@ -648,7 +383,6 @@ __device__ __forceinline__ void settle_pixel(const FuseSettle& S, uint32_t p, ui
 }
 // step 0 evaluates every pending pixel, step s > 0 the list step s - 1 left; an empty list costs an empty launch
 __global__ void fuse_settle_step_kernel(FuseSettle S, const uint32_t* pending, uint32_t step) {
-	if (S.abort && S.abort[1] != 0u) return;
 	const uint32_t n = step == 0u ? S.ctl[kCtlPending] : S.ctl[kCtlWork + step - 1u];
 	if (n == 0u) return;
 	const uint32_t* list = step == 0u ? pending : S.work[(step - 1u) & 1u];
@@ -660,7 +394,6 @@ __global__ void fuse_settle_step_kernel(FuseSettle S, const uint32_t* pending, u
 // whatever the kSettleSteps launches left: one workgroup goes on until the list is empty (no host in the loop, no bound on the
 // number of steps other than the safety limit)
 __global__ __launch_bounds__(1024) void fuse_settle_rest_kernel(FuseSettle S) {
-	if (S.abort && S.abort[1] != 0u) return;
 	__shared__ uint32_t nNext;
 	uint32_t n = S.ctl[kCtlWork + kSettleSteps];
 	uint32_t step = (uint32_t)kSettleSteps + 1u;
@@ -676,13 +409,12 @@ __global__ __launch_bounds__(1024) void fuse_settle_rest_kernel(FuseSettle S) {
 		n = nNext;
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) { S.ctl[kCtlSteps] = step - 1u; if (S.ctl[kCtlErr] == 0u) S.ctl[kCtlDone] = S.ctl[kCtlPending]; }
+	if (threadIdx.x == 0) S.ctl[kCtlSteps] = step - 1u; // diagnostic
 }
 // the decisions are final: the points claim the estimates they merge and remove the ones they lie in front of.  No two points
 // touch the same estimate (the earlier one made it unavailable to the later one).
 __global__ void fuse_settle_apply_kernel(DevMap A, const DevMap* maps, FuseSettle S, const uint32_t* pending, uint32_t* merged, FuseOut out,
                                          unsigned long long* counters) {
-	if (S.abort && S.abort[1] != 0u) return;
 	const uint32_t n = S.ctl[kCtlPending];
 	unsigned accepted = 0, viewEntries = 0;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -711,8 +443,7 @@ __global__ void fuse_settle_apply_kernel(DevMap A, const DevMap* maps, FuseSettl
 // estimates are claimed, so nobody has changed them since the pass looked at them.
 template <int MAXV>
 __global__ void fuse_points_kernel(DevMap A, const DevMap* maps, FuseTables tb, const uint32_t* merged, FuseOut out, const uint32_t* pending,
-                                   const uint32_t* roundCnt, const uint32_t* abort) {
-	if (abort && abort[1] != 0u) return;
+                                   const uint32_t* roundCnt) {
 	const int nNb = A.nNeighbors;
 	const int nPending = (int)roundCnt[1];
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nPending; i += gridDim.x * blockDim.x) {
@@ -772,8 +503,7 @@ __global__ void fuse_points_kernel(DevMap A, const DevMap* maps, FuseTables tb, 
 __global__ void fuse_gather_kernel(int n, const uint8_t* flag, const uint32_t* pos, FuseOut out, unsigned long long base,
                                    unsigned long long capacity, float* xyz, float* normal, uint8_t* bgr, uint32_t* nviews,
                                    const uint32_t* voff, unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights,
-                                   const unsigned long long* bases, const uint32_t* abort) {
-	if (abort && abort[1] != 0u) return;
+                                   const unsigned long long* bases) {
 	if (bases) { base = bases[0]; viewBase = bases[1]; }
 	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
 		if (!flag[idx]) continue;
@@ -852,8 +582,7 @@ __global__ void point_colors_kernel(unsigned long long n, const float* xyz, cons
 // reference (SceneDensify.cpp:2717-2983) reads uninitialised variables and is not reproduced.
 
 // runs BEFORE the claim marks come off: a negative depth = the pixel ended up in a fused point
-__global__ void postfilter_mask_kernel(int n, const float* depth, const float* normal, float* dF, float* nF, const uint32_t* abort) {
-	if (abort && abort[1] != 0u) return;
+__global__ void postfilter_mask_kernel(int n, const float* depth, const float* normal, float* dF, float* nF) {
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const bool on = depth[i] < 0.f;
 		dF[i] = on ? -depth[i] : 0.f;
@@ -861,8 +590,7 @@ __global__ void postfilter_mask_kernel(int n, const float* depth, const float* n
 	}
 }
 __global__ void gap_lines_kernel(float* dF, float* nF, float* conf, const uint8_t* gra, int nLines, int len, size_t lineStride, size_t stride, int gap,
-                                 float thr, unsigned long long* filledOut, const uint32_t* abort) {
-	if (abort && abort[1] != 0u) return;
+                                 float thr, unsigned long long* filledOut) {
 	const int line = blockIdx.x * blockDim.x + threadIdx.x;
 	if (line >= nLines) return;
 	const size_t base = (size_t)line * lineStride;
@@ -910,8 +638,7 @@ __global__ void gap_lines_kernel(float* dF, float* nF, float* conf, const uint8_
 	}
 	if (filled) atomicAdd(filledOut, filled);
 }
-__global__ void postfilter_merge_kernel(int n, float* depth, float* normal, const float* dF, const float* nF, const uint32_t* abort) {
-	if (abort && abort[1] != 0u) return;
+__global__ void postfilter_merge_kernel(int n, float* depth, float* normal, const float* dF, const float* nF) {
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		if (dF[i] > 0.f) depth[i] = dF[i];
 		const float a = nF[3 * i], b = nF[3 * i + 1], c = nF[3 * i + 2];
@@ -920,19 +647,16 @@ __global__ void postfilter_merge_kernel(int n, float* depth, float* normal, cons
 }
 // the image's own maps still carry the claim marks of the fusion that has just run; `maps` = all maps, unmarked after the mask is taken
 void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const DevMap* maps, int nMaps, const uint8_t* gra, float* dF, float* nF,
-                       int gap, float thr, unsigned long long* filled, const uint32_t* abort, hipStream_t s) {
+                       int gap, float thr, unsigned long long* filled, hipStream_t s) {
 	const int n = w * h;
-	hipLaunchKernelGGL(postfilter_mask_kernel, kGrid, kBlock, 0, s, n, depth, normal, dF, nF, abort);
+	hipLaunchKernelGGL(postfilter_mask_kernel, kGrid, kBlock, 0, s, n, depth, normal, dF, nF);
 	launch_unclaim(maps, nMaps, s);
-	hipLaunchKernelGGL(gap_lines_kernel, dim3((h + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, h, w, (size_t)w, (size_t)1, gap, thr, filled, abort);   // rows
-	hipLaunchKernelGGL(gap_lines_kernel, dim3((w + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, w, h, (size_t)1, (size_t)w, gap, thr, filled, abort);   // columns
-	hipLaunchKernelGGL(postfilter_merge_kernel, kGrid, kBlock, 0, s, n, depth, normal, dF, nF, abort);
+	hipLaunchKernelGGL(gap_lines_kernel, dim3((h + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, h, w, (size_t)w, (size_t)1, gap, thr, filled);   // rows
+	hipLaunchKernelGGL(gap_lines_kernel, dim3((w + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, w, h, (size_t)1, (size_t)w, gap, thr, filled);   // columns
+	hipLaunchKernelGGL(postfilter_merge_kernel, kGrid, kBlock, 0, s, n, depth, normal, dF, nF);
 }
 void launch_unclaim(const DevMap* maps, int nMaps, hipStream_t s) {
 	hipLaunchKernelGGL(unclaim_kernel, dim3(256, nMaps < 1024 ? (nMaps > 0 ? nMaps : 1) : 1024), dim3(256), 0, s, maps, nMaps);
-}
-void launch_fuse_links_check(const FuseTables& tb, unsigned long long capLinks, uint32_t* status, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_links_check_kernel, dim3(1), dim3(64), 0, s, tb, capLinks, status);
 }
 void launch_fuse_status(const uint32_t* ctl, uint32_t* status, hipStream_t s) {
 	hipLaunchKernelGGL(fuse_status_kernel, dim3(1), dim3(64), 0, s, ctl, status);
@@ -956,60 +680,38 @@ void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsig
                         int nMinViewsAdjust, float thr, float* newDepth, float* newConf, unsigned long long* counters, hipStream_t s) {
 	hipLaunchKernelGGL(filter_vote_kernel, kGrid, kBlock, 0, s, ref, nbs, N, keys, adjust, nMinViews, nMinViewsAdjust, thr, newDepth, newConf, counters);
 }
-FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_t* fillT, uint32_t* bidders, uint32_t* cntP, uint32_t* offP,
-                       uint32_t* nbrList, size_t stride) {
+FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_t* fillT, uint32_t* bidders, size_t stride) {
 	FuseTables tb;
-	tb.targets = targets; tb.cntT = cntT; tb.offT = offT; tb.fillT = fillT; tb.bidders = bidders; tb.cntP = cntP; tb.offP = offP; tb.nbrList = nbrList;
-	tb.stride = stride;
+	tb.targets = targets; tb.cntT = cntT; tb.offT = offT; tb.fillT = fillT; tb.bidders = bidders; tb.stride = stride;
 	return tb;
 }
-// begin of an image pass: the pending list (its length in ctl[4]), targets, per-target lists, per-pixel link counts + offsets
-// (cntT / fillT / cntP must be zero).  fuse_links_fill writes the link lists once the host has sized them.
+// begin of an image pass: the pending list (its length in ctl[kCtlPending]), the pixels' targets and the per-target bidder lists
+// (cntT / fillT must be zero)
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
-                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, int order, float thDepth, float normalError, const uint32_t* abort, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, ctl + kCtlPending - 1, flag, counters, thDepth, normalError, abort); // roundCnt[1] == ctl[kCtlPending]
+                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, float thDepth, float normalError, hipStream_t s) {
+	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, ctl + kCtlPending - 1, flag, counters, thDepth, normalError); // roundCnt[1] == ctl[kCtlPending]
 	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntT, tb.offT, (int)(tb.stride * (size_t)A.nNeighbors), s);
-	hipLaunchKernelGGL(fuse_fill_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + kCtlPending - 1, abort);
-	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + kCtlPending - 1, 0, order, abort);
-	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntP, tb.offP, (int)(2 * tb.stride), s);
+	hipLaunchKernelGGL(fuse_fill_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + kCtlPending - 1);
 }
-void launch_fuse_links_fill(const DevMap& A, const FuseTables& tb, const uint32_t* pending, const uint32_t* ctl, int order, const uint32_t* abort, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_links_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + kCtlPending - 1, 1, order, abort);
-}
-// the whole image pass in one launch of dataflow workers (one wave per workgroup; any grid size is correct), then the points
-void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, uint32_t* queue, size_t queueStride, uint32_t* ctl,
+// the image pass: which pending pixels become points (the settle iteration), their claims, then the points themselves.
+// settle: scratch of fuse_settle_bytes(pixels of A)
+size_t fuse_settle_bytes(size_t pixels) { return ((pixels * 4 + 255) & ~(size_t)255) * 3 + pixels; }
+void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, void* settle, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
-                      uint32_t* merged, int nMinViewsFuse, int order, unsigned long long* counters, int blocks, uint32_t* levels, bool wantPoints, const uint32_t* abort,
-                      hipStream_t s) {
+                      uint32_t* merged, int nMinViewsFuse, int order, unsigned long long* counters, bool wantPoints, hipStream_t s) {
 	FuseOut out{oxyz, onormal, obgr, onv, oflag, oviews, oweights, vstride};
-	FusePass fp;
-	fp.tb = tb; fp.queue = queue; fp.queueStride = queueStride; fp.ctl = ctl; fp.merged = merged; fp.levels = levels; fp.abort = abort;
-	fp.nMinViewsFuse = nMinViewsFuse;
-	static const int xcdOnly = getenv("HCMVS_FUSE_XCD") ? atoi(getenv("HCMVS_FUSE_XCD")) : -1;
-	fp.xcd = xcdOnly;
-	if (xcdOnly >= 0) blocks *= 8;
-	static const bool dataflow = getenv("HCMVS_FUSE_DATAFLOW") != nullptr; // diagnostic: the hop-by-hop pass instead of the settle iteration
-	if (dataflow) {
-		hipLaunchKernelGGL(fuse_seed_kernel, kGrid, kBlock, 0, s, tb, pending, queue, queueStride, ctl, abort);
-		if (A.nNeighbors <= 8) hipLaunchKernelGGL(fuse_pass_kernel<9>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
-		else if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_pass_kernel<16>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
-		else hipLaunchKernelGGL(fuse_pass_kernel<32>, dim3(blocks), dim3(64), 0, s, A, maps, fp, out, pending, counters);
-		hipLaunchKernelGGL(fuse_queue_reset_kernel, kGrid, kBlock, 0, s, queue, queueStride, ctl, abort);
-	} else {
-		// scratch of the iteration inside the (otherwise unused) queue area: two work lists, the stamps, the flags
-		const size_t n = (size_t)A.w * A.h;
-		FuseSettle S;
-		S.tb = tb; S.work[0] = queue; S.work[1] = queue + queueStride; S.stamp = queue + 2 * queueStride; S.acc = (uint8_t*)(queue + 3 * queueStride);
-		S.ctl = ctl; S.abort = abort; S.nNb = A.nNeighbors; S.nMinViewsFuse = nMinViewsFuse; S.order = order;
-		(void)hipMemsetAsync(S.stamp, 0, n * 4, s);
-		(void)hipMemsetAsync(S.acc, 1, n, s);
-		for (int step = 0; step <= kSettleSteps; ++step) hipLaunchKernelGGL(fuse_settle_step_kernel, kGrid, kBlock, 0, s, S, pending, (uint32_t)step);
-		hipLaunchKernelGGL(fuse_settle_rest_kernel, dim3(1), dim3(1024), 0, s, S);
-		hipLaunchKernelGGL(fuse_settle_apply_kernel, kGrid, kBlock, 0, s, A, maps, S, pending, merged, out, counters);
-	}
+	const size_t n = (size_t)A.w * A.h, words = ((n * 4 + 255) & ~(size_t)255) / 4;
+	FuseSettle S;
+	S.tb = tb; S.work[0] = (uint32_t*)settle; S.work[1] = S.work[0] + words; S.stamp = S.work[1] + words; S.acc = (uint8_t*)(S.stamp + words);
+	S.ctl = ctl; S.nNb = A.nNeighbors; S.nMinViewsFuse = nMinViewsFuse; S.order = order;
+	(void)hipMemsetAsync(S.stamp, 0, n * 4, s);
+	(void)hipMemsetAsync(S.acc, 1, n, s);
+	for (int step = 0; step <= kSettleSteps; ++step) hipLaunchKernelGGL(fuse_settle_step_kernel, kGrid, kBlock, 0, s, S, pending, (uint32_t)step);
+	hipLaunchKernelGGL(fuse_settle_rest_kernel, dim3(1), dim3(1024), 0, s, S);
+	hipLaunchKernelGGL(fuse_settle_apply_kernel, kGrid, kBlock, 0, s, A, maps, S, pending, merged, out, counters);
 	if (!wantPoints) return;
-	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_points_kernel<16>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + kCtlPending - 1, abort);
-	else hipLaunchKernelGGL(fuse_points_kernel<32>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + kCtlPending - 1, abort);
+	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_points_kernel<16>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + kCtlPending - 1);
+	else hipLaunchKernelGGL(fuse_points_kernel<32>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + kCtlPending - 1);
 }
 size_t fuse_scan_temp_bytes(int n) {
 	size_t bytes = 0;
@@ -1019,8 +721,7 @@ size_t fuse_scan_temp_bytes(int n) {
 void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t* pos, void* temp, size_t tempBytes, float* oxyz,
                          float* onormal, uint8_t* obgr, uint32_t* onv, unsigned long long base, unsigned long long capacity, float* xyz,
                          float* normal, uint8_t* bgr, uint32_t* nviews, uint32_t* oviews, float* oweights, int vstride, uint32_t* voff,
-                         unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights, const unsigned long long* bases,
-                         const uint32_t* abort, hipStream_t s) {
+                         unsigned long long viewBase, unsigned long long viewCapacity, uint32_t* cviews, float* cweights, const unsigned long long* bases, hipStream_t s) {
 	hipLaunchKernelGGL(flag_to_u32_kernel, kGrid, kBlock, 0, s, flag, flag32, n);
 	(void)hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, flag32, pos, n, s);
 	if (cviews) { // offsets of the accepted pixels' view lists inside this image's part of the CSR arrays
@@ -1029,7 +730,7 @@ void launch_fuse_compact(int n, const uint8_t* flag, uint32_t* flag32, uint32_t*
 	}
 	FuseOut out{oxyz, onormal, obgr, onv, const_cast<uint8_t*>(flag), oviews, oweights, vstride};
 	hipLaunchKernelGGL(fuse_gather_kernel, kGrid, kBlock, 0, s, n, flag, pos, out, base, capacity, xyz, normal, bgr, nviews, voff, viewBase, viewCapacity,
-	                   cviews, cweights, bases, abort);
+	                   cviews, cweights, bases);
 }
 void launch_fuse_advance(const unsigned long long* counters, unsigned long long* totals, unsigned long long capacity, unsigned long long viewCapacity,
                          uint32_t* status, hipStream_t s) {

@@ -49,11 +49,6 @@ struct View {
 
 } // namespace
 
-struct FuseLane { // one concurrent fusion pass: its stream, per-pass tables and link lists (hcmvs_fuse_cloud)
-	hipStream_t stream = nullptr;
-	char* scratch = nullptr; size_t cap = 0;
-	uint32_t* links = nullptr; size_t capLinks = 0;
-};
 
 struct hcmvs_ctx {
 	int device = 0;
@@ -89,11 +84,10 @@ struct hcmvs_ctx {
 	DevMap* dMaps = nullptr; size_t capMaps = 0;
 	unsigned long long* counters = nullptr;
 	void* fuseScratch = nullptr; size_t capFuseScratch = 0;
-	std::vector<FuseLane> fuseLanes; // per-pass scratch of the concurrent fusion passes
+	char* passScratch = nullptr; size_t capPass = 0; // per-pass tables of the fusion (hcmvs_fuse_cloud, hcmvs_postfilter_sequence)
 	bool errPending = false; // an estimate was enqueued since the error word was last read
 	int nCU = 0;          // compute units of the device (fusion worker count)
 	hipEvent_t upEv[2] = {nullptr, nullptr};
-	char* snap = nullptr; size_t capSnap = 0; // unsynchronised fusion: status words, running totals, snapshot of the depth maps
 	char* pinned = nullptr; size_t capPinned = 0; // page-locked staging of the host-buffer uploads (a pageable hipMemcpy crawls at ~1.3 GB/s here)
 	int wavesPerRow = 0; // 0 = automatic: 3 waves per row for one image, 2 for two (latency), 1 when >= 3 images fill the chip
 };
@@ -229,14 +223,9 @@ void hcmvs_destroy(hcmvs_ctx* c) {
 	for (void* p : {(void*)c->tmpU8, (void*)c->sDepth, (void*)c->sNormal, (void*)c->sConf, (void*)c->dViews, (void*)c->dItems, (void*)c->sync,
 	                (void*)c->evals, (void*)c->dMaps, (void*)c->counters, c->fuseScratch})
 		if (p) (void)hipFree(p);
-	for (auto& L : c->fuseLanes) {
-		if (L.scratch) (void)hipFree(L.scratch);
-		if (L.links) (void)hipFree(L.links);
-		if (L.stream) (void)hipStreamDestroy(L.stream);
-	}
+	if (c->passScratch) (void)hipFree(c->passScratch);
 	for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->pinned) (void)hipHostFree(c->pinned);
-	if (c->snap) (void)hipFree(c->snap);
 	for (auto& e : c->upEv) if (e) (void)hipEventDestroy(e);
 	if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
 	delete c;
@@ -978,7 +967,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	const size_t tblElems = stride * (size_t)maxNb;
 	if (stride >= ((size_t)1 << 29)) return fail(c, HCMVS_ERR_CAPACITY, "fuse: maps of %zu pixels exceed the target tables (2^29 pixels)", stride);
 	if (tblElems > 0x7FFFFFFFull) return fail(c, HCMVS_ERR_CAPACITY, "fuse: %d neighbours of %zu pixels exceed the per-pass tables", maxNb, stride);
-	const size_t scanBytes = (std::max({fuse_scan_temp_bytes((int)maxArea), fuse_scan_temp_bytes((int)tblElems), fuse_scan_temp_bytes((int)(2 * stride))}) + 255) & ~(size_t)255;
+	const size_t scanBytes = (std::max(fuse_scan_temp_bytes((int)maxArea), fuse_scan_temp_bytes((int)tblElems)) + 255) & ~(size_t)255;
 	size_t off = 0;
 	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
 	// the device cloud (context scratch) ...
@@ -990,315 +979,90 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	float* cX = (float*)(cb + oCX); float* cN = normal ? (float*)(cb + oCN) : nullptr; uint8_t* cB = bgr ? (uint8_t*)(cb + oCB) : nullptr;
 	uint32_t* cV = n_views || viewCapacity ? (uint32_t*)(cb + oCV) : nullptr;
 	uint32_t* cVI = viewCapacity ? (uint32_t*)(cb + oCVI) : nullptr; float* cVW = viewCapacity ? (float*)(cb + oCVW) : nullptr;
-	// ... and the per-pass scratch of one lane (sized for the largest image)
+	// ... and the per-pass tables (sized for the largest image)
 	off = 0;
-	const size_t oPending = carve(maxArea * 4), oQueue = carve(maxArea * 4 * (size_t)kFuseQueues), oTgt = carve(maxArea * 4 * (size_t)maxNb),
-	             oCntT = carve(tblElems * 4), oFillT = carve(tblElems * 4), oCntP = carve(stride * 8), oOffT = carve(tblElems * 4), oOffP = carve(stride * 8),
-	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(kCtlBytes), oCounters = carve(64), oMerged = carve(maxArea * 4),
-	             oFlag = carve(maxArea), oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
+	const size_t oPending = carve(maxArea * 4), oSettle = carve(fuse_settle_bytes(maxArea)), oTgt = carve(maxArea * 4 * (size_t)maxNb),
+	             oCntT = carve(tblElems * 4), oFillT = carve(tblElems * 4), oOffT = carve(tblElems * 4),
+	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(kCtlBytes), oCounters = carve(64), oStatus = carve(64), oTotals = carve(64),
+	             oMerged = carve(maxArea * 4), oFlag = carve(maxArea), oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
 	             oXyz = carve(maxArea * 12), oNrm = carve(maxArea * 12), oBgr = carve(maxArea * 3), oNv = carve(maxArea * 4),
 	             oPV = carve(viewCapacity ? maxArea * 4 * (size_t)(maxNb + 1) : 0), oPW = carve(viewCapacity ? maxArea * 4 * (size_t)(maxNb + 1) : 0),
 	             oVoff = carve(viewCapacity ? maxArea * 4 : 0);
-	const size_t laneBytes = off;
+	if (c->capPass < off) {
+		if (c->passScratch) (void)hipFree(c->passScratch);
+		c->passScratch = nullptr; c->capPass = 0;
+		HIPCHK(c, hipMalloc(&c->passScratch, off));
+		c->capPass = off;
+	}
 	const int vstride = maxNb + 1;
 	const float normalError = cosf(normal_diff_deg * normalweight * (3.14159274101257324f / 180.f)); // SceneDensify.cpp:3310
 	const float thDepth = depth_diff_threshold * depthweight;                                       // SceneDensify.cpp:3400
-	// dataflow workers: one wave per workgroup, a few per CU; any number is correct (no co-residency assumption)
-	hipDeviceProp_t prop;
-	HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
-	const int nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
-	int blocks = nCU * 4;
-	if (getenv("HCMVS_FUSE_BLOCKS")) blocks = std::min(nCU * 16, std::max(1, atoi(getenv("HCMVS_FUSE_BLOCKS"))));
+	const bool debug = getenv("HCMVS_FUSE_DEBUG") != nullptr; // per image: a synchronisation and a line on stderr
 
-	// The pass of an image reads and writes its own maps and those of its neighbours, nothing else.  Two images whose
-	// touched sets are disjoint commute, so their passes run side by side on separate streams ("lanes"); an image waits
-	// only for the earlier images of the fusion order it shares a map with, and the cloud keeps the order of the
-	// sequential loop (SceneDensify.cpp:3302): a pass reports its point count, and its compaction writes at the
-	// offset the counts of all earlier images add up to.
-	std::vector<std::vector<uint32_t>> touched((size_t)n_order);
-	for (int i = 0; i < n_order; ++i) {
-		auto& t = touched[i];
-		t.push_back(order[i]);
-		for (uint32_t nb : c->views.find(order[i])->second.neighbors) t.push_back(nb);
-		std::sort(t.begin(), t.end());
-		t.erase(std::unique(t.begin(), t.end()), t.end());
-	}
-	std::vector<std::vector<int>> deps((size_t)n_order);
-	for (int i = 0; i < n_order; ++i)
-		for (int j = 0; j < i; ++j) {
-			const auto &ti = touched[i], &tj = touched[j];
-			size_t a = 0, b2 = 0; bool hit = false;
-			while (a < ti.size() && b2 < tj.size()) { if (ti[a] == tj[b2]) { hit = true; break; } if (ti[a] < tj[b2]) ++a; else ++b2; }
-			if (hit) deps[i].push_back(j);
-		}
-	int nLanes = std::min(n_order, 4);
-	if (getenv("HCMVS_FUSE_LANES")) nLanes = std::min(n_order, std::min(16, std::max(1, atoi(getenv("HCMVS_FUSE_LANES")))));
-	if (c->fuseLanes.size() < (size_t)nLanes) c->fuseLanes.resize((size_t)nLanes);
-	for (int k = 0; k < nLanes; ++k) {
-		FuseLane& L = c->fuseLanes[k];
-		if (!L.stream) HIPCHK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-		if (L.cap < laneBytes) {
-			if (L.scratch) (void)hipFree(L.scratch);
-			L.scratch = nullptr; L.cap = 0;
-			HIPCHK(c, hipMalloc(&L.scratch, laneBytes));
-			L.cap = laneBytes;
-		}
-	}
-	HIPCHK(c, hipStreamSynchronize(s)); // claims reset, tables uploaded: the lanes may start
+	// Every pass of the fusion is enqueued on the context's stream, no host synchronisation between the images (stream order is the
+	// order of the sequential loop, SceneDensify.cpp:3302).  What the host would have to know in between stays on the device: the
+	// running point / view-entry totals an image's compaction starts from (fuse_advance_kernel), and the word that says a cloud or
+	// view-list capacity was exceeded.
+	char* b = c->passScratch;
+	uint32_t* pendingList = (uint32_t*)(b + oPending); uint32_t* ctl = (uint32_t*)(b + oCtl);
+	unsigned long long* counters = (unsigned long long*)(b + oCounters);
+	uint32_t* status = (uint32_t*)(b + oStatus);
+	unsigned long long* totals = (unsigned long long*)(b + oTotals);
+	int32_t* targets = (int32_t*)(b + oTgt);
+	uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders);
+	uint8_t* flag = (uint8_t*)(b + oFlag);
+	uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos); uint32_t* merged = (uint32_t*)(b + oMerged);
+	float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
+	uint32_t* pviews = viewCapacity ? (uint32_t*)(b + oPV) : nullptr; float* pweights = viewCapacity ? (float*)(b + oPW) : nullptr;
+	uint32_t* voff = viewCapacity ? (uint32_t*)(b + oVoff) : nullptr;
+	const FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, stride);
 	const auto tPasses = std::chrono::steady_clock::now();
-	const bool debug = getenv("HCMVS_FUSE_DEBUG") != nullptr;
-	const bool debugDepth = debug && atoi(getenv("HCMVS_FUSE_DEBUG")) >= 2; // also the depth of the dependence graph (slows the pass down)
-	if (!getenv("HCMVS_FUSE_LANES") && !debug) {
-		// The default: every pass of the fusion enqueued on the context's stream, no host synchronisation between the images
-		// (stream order is the order of the sequential loop).  What the lanes below ask the host for is kept on the device: the
-		// size of a pass's link lists (checked there: when they do not fit every later kernel returns at once, the depth maps
-		// are put back from a snapshot, the lists grow and the fusion runs again) and the running point / view-entry totals an
-		// image's compaction starts from.  HCMVS_FUSE_LANES selects the lanes (passes of images that share no map side by side).
-		FuseLane& L = c->fuseLanes[0];
-		size_t allPx = 0;
-		for (const auto& m : host) if (m.depth) allPx += (size_t)m.w * m.h;
-		if (c->capSnap < allPx * 4 + 256) {
-			if (c->snap) (void)hipFree(c->snap);
-			c->snap = nullptr; c->capSnap = 0;
-			HIPCHK(c, hipMalloc(&c->snap, allPx * 4 + 256));
-			c->capSnap = allPx * 4 + 256;
-		}
-		if (!L.links) { // first size of the link lists; HCMVS_FUSE_LINKS_INIT (entries) lets a test start too small and exercise the undo-and-grow path
-			size_t first = (size_t)8 << 20;
-			if (getenv("HCMVS_FUSE_LINKS_INIT") && atol(getenv("HCMVS_FUSE_LINKS_INIT")) > 0) first = (size_t)atol(getenv("HCMVS_FUSE_LINKS_INIT"));
-			HIPCHK(c, hipMalloc(&L.links, first * 4));
-			L.capLinks = first;
-		}
-		uint32_t* status = (uint32_t*)c->snap;                               // 64 B
-		unsigned long long* totals = (unsigned long long*)(c->snap + 64);   // 64 B
-		float* snap = (float*)(c->snap + 256);
-		char* b = L.scratch;
-		uint32_t* pendingList = (uint32_t*)(b + oPending); uint32_t* queue = (uint32_t*)(b + oQueue); uint32_t* ctl = (uint32_t*)(b + oCtl);
-		unsigned long long* counters = (unsigned long long*)(b + oCounters);
-		int32_t* targets = (int32_t*)(b + oTgt);
-		uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders),
-		         *cntP = (uint32_t*)(b + oCntP), *offP = (uint32_t*)(b + oOffP);
-		uint8_t* flag = (uint8_t*)(b + oFlag);
-		uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos); uint32_t* merged = (uint32_t*)(b + oMerged);
-		float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
-		uint32_t* pviews = viewCapacity ? (uint32_t*)(b + oPV) : nullptr; float* pweights = viewCapacity ? (float*)(b + oPW) : nullptr;
-		uint32_t* voff = viewCapacity ? (uint32_t*)(b + oVoff) : nullptr;
-		unsigned long long tot[3] = {0, 0, 0};
-		HIPCHK(c, hipMemsetAsync(queue, 0xFF, maxArea * 4 * (size_t)kFuseQueues, s)); // FS_EMPTY; every pass leaves the queues so
-		for (int attempt = 0;; ++attempt) {
-			HIPCHK(c, hipMemsetAsync(c->snap, 0, 256, s));
-			{
-				size_t o = 0;
-				for (const auto& m : host) if (m.depth) { HIPCHK(c, hipMemcpyAsync(snap + o, m.depth, (size_t)m.w * m.h * 4, hipMemcpyDeviceToDevice, s)); o += (size_t)m.w * m.h; }
-			}
-			for (int oi = 0; oi < n_order; ++oi) {
-				const DevMap& A = host[order[oi]];
-				const int n = A.w * A.h;
-				HIPCHK(c, hipMemsetAsync(counters, 0, 64, s));
-				HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
-				HIPCHK(c, hipMemsetAsync(cntT, 0, (size_t)A.nNeighbors * stride * 4, s));
-				HIPCHK(c, hipMemsetAsync(fillT, 0, (size_t)A.nNeighbors * stride * 4, s));
-				HIPCHK(c, hipMemsetAsync(cntP, 0, stride * 8, s));
-				FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, cntP, offP, L.links, stride);
-				launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, c->fuseOrder, thDepth, normalError, status, s);
-				launch_fuse_links_check(tb, (unsigned long long)L.capLinks, status, s);
-				launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, status, s);
-				launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, maxArea, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
-				                 merged, n_min_views_fuse, c->fuseOrder, counters, blocks, nullptr, wantCloud, status, s);
-				launch_fuse_status(ctl, status, s);
-				if (wantCloud)
-					launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, 0, capacity, cX, cN, cB, cV, pviews, pweights, vstride,
-					                    voff, 0, viewCapacity, cVI, cVW, totals, status, s);
-				launch_fuse_advance(counters, totals, wantCloud ? capacity : 0, wantCloud ? viewCapacity : 0, status, s);
-			}
-			HIPCHK(c, hipGetLastError());
-			uint32_t st[4] = {0, 0, 0, 0};
-			HIPCHK(c, hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, s));
-			HIPCHK(c, hipMemcpyAsync(tot, totals, 24, hipMemcpyDeviceToHost, s));
-			HIPCHK(c, hipStreamSynchronize(s));
-			if (st[1] != 0) { // a link list did not fit: undo, grow, again
-				size_t o = 0;
-				for (const auto& m : host) if (m.depth) { HIPCHK(c, hipMemcpyAsync(m.depth, snap + o, (size_t)m.w * m.h * 4, hipMemcpyDeviceToDevice, s)); o += (size_t)m.w * m.h; }
-				HIPCHK(c, hipStreamSynchronize(s));
-				if (attempt >= 4) return fail(c, HCMVS_ERR_CAPACITY, "fuse: the link lists of a pass keep outgrowing their buffer (%u entries)", st[2]);
-				(void)hipFree(L.links);
-				L.links = nullptr; L.capLinks = 0;
-				const size_t want = (size_t)st[2] + (size_t)st[2] / 4 + ((size_t)1 << 20);
-				HIPCHK(c, hipMalloc(&L.links, want * 4));
-				L.capLinks = want;
-				continue;
-			}
-			launch_unclaim(c->dMaps, (int)host.size(), s);
-			if (st[0] != 0) { HIPCHK(c, hipStreamSynchronize(s)); return fail(c, HCMVS_ERR_TIMEOUT, "fuse: the pass of an image stalled; the registered depth maps are left partially fused"); }
-			if (st[3] == 1) { HIPCHK(c, hipStreamSynchronize(s)); return fail(c, HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity); }
-			if (st[3] == 2) { HIPCHK(c, hipStreamSynchronize(s)); return fail(c, HCMVS_ERR_CAPACITY, "fuse: view-list capacity %llu exceeded", (unsigned long long)viewCapacity); }
-			break;
-		}
-		const unsigned long long total = tot[0], viewTotal = viewCapacity && wantCloud ? tot[1] : 0;
-		if (wantCloud) HIPCHK(c, hipMemcpyAsync(xyz, cX, total * 12, hipMemcpyDeviceToHost, s));
-		if (normal) HIPCHK(c, hipMemcpyAsync(normal, cN, total * 12, hipMemcpyDeviceToHost, s));
-		if (bgr) HIPCHK(c, hipMemcpyAsync(bgr, cB, total * 3, hipMemcpyDeviceToHost, s));
-		if (n_views) HIPCHK(c, hipMemcpyAsync(n_views, cV, total * 4, hipMemcpyDeviceToHost, s));
-		if (viewCapacity && wantCloud) {
-			HIPCHK(c, hipMemcpyAsync(cloud->view_ids, cVI, viewTotal * 4, hipMemcpyDeviceToHost, s));
-			HIPCHK(c, hipMemcpyAsync(cloud->view_weights, cVW, viewTotal * 4, hipMemcpyDeviceToHost, s));
-		}
-		HIPCHK(c, hipStreamSynchronize(s));
-		*n_points = total;
-		if (n_depths) *n_depths = tot[2];
-		cloud->n_view_entries = viewTotal;
-		return HCMVS_OK;
-	}
-
-	struct Shared {
-		std::mutex mu; std::condition_variable cv;
-		std::vector<int> state;                       // 0 waiting, 1 running, 2 pass finished (counts known), 3 compacted
-		std::vector<unsigned long long> accepted, entries;
-		unsigned long long depths = 0;
-		int rc = 0; std::string msg;
-	} sh;
-	sh.state.assign((size_t)n_order, 0); sh.accepted.assign((size_t)n_order, 0); sh.entries.assign((size_t)n_order, 0);
-	auto laneFail = [&](int code, const char* fmt, ...) {
-		char buf[512];
-		va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-		std::lock_guard<std::mutex> g(sh.mu);
-		if (!sh.rc) { sh.rc = code; sh.msg = buf; }
-		sh.cv.notify_all();
-	};
-	auto worker = [&](int k) {
-		FuseLane& L = c->fuseLanes[k];
-		hipStream_t ls = L.stream;
-		if (hipSetDevice(c->device) != hipSuccess) { laneFail(HCMVS_ERR_HIP, "fuse: hipSetDevice failed in a lane"); return; }
-#define LANECHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { laneFail(HCMVS_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); return; } } while (0)
-		char* b = L.scratch;
-		uint32_t* pendingList = (uint32_t*)(b + oPending); uint32_t* queue = (uint32_t*)(b + oQueue);
-		uint32_t* ctl = (uint32_t*)(b + oCtl);
-		LANECHK(hipMemsetAsync(queue, 0xFF, maxArea * 4 * (size_t)kFuseQueues, ls)); // FS_EMPTY; every pass leaves the queues so
-		unsigned long long* counters = (unsigned long long*)(b + oCounters);
-		int32_t* targets = (int32_t*)(b + oTgt);
-		uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders),
-		         *cntP = (uint32_t*)(b + oCntP), *offP = (uint32_t*)(b + oOffP);
-		uint8_t* flag = (uint8_t*)(b + oFlag);
-		uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos); uint32_t* merged = (uint32_t*)(b + oMerged);
-		float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
-		uint32_t* pviews = viewCapacity ? (uint32_t*)(b + oPV) : nullptr; float* pweights = viewCapacity ? (float*)(b + oPW) : nullptr;
-		uint32_t* voff = viewCapacity ? (uint32_t*)(b + oVoff) : nullptr;
-		for (;;) {
-			int oi = -1;
-			{ // the first image of the order that has not started and whose earlier conflicting images have finished their passes
-				std::unique_lock<std::mutex> g(sh.mu);
-				for (;;) {
-					if (sh.rc) return;
-					bool anyLeft = false;
-					for (int i = 0; i < n_order && oi < 0; ++i) {
-						if (sh.state[i] != 0) continue;
-						anyLeft = true;
-						bool ready = true;
-						for (int j : deps[i]) if (sh.state[j] < 2) { ready = false; break; }
-						if (ready) oi = i;
-					}
-					if (oi >= 0) { sh.state[oi] = 1; break; }
-					if (!anyLeft) return;
-					sh.cv.wait(g);
-				}
-			}
-			const DevMap& A = host[order[oi]];
-			const int n = A.w * A.h;
-			LANECHK(hipMemsetAsync(counters, 0, 64, ls));
-			LANECHK(hipMemsetAsync(ctl, 0, kCtlBytes, ls));
-			LANECHK(hipMemsetAsync(cntT, 0, (oOffT - oCntT), ls));                               // per-target counts, fill cursors, per-pixel link counts
-			FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, cntP, offP, L.links, stride);
-			launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, c->fuseOrder, thDepth, normalError, nullptr, ls);
-			uint32_t lastOff = 0, lastCnt = 0; // total size of the link lists = last offset + last count
-			LANECHK(hipMemcpyAsync(&lastOff, offP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, ls));
-			LANECHK(hipMemcpyAsync(&lastCnt, cntP + 2 * stride - 1, 4, hipMemcpyDeviceToHost, ls));
-			LANECHK(hipStreamSynchronize(ls));
-			// the link lists hold, per pending pixel, every other pending pixel that shares a target with it: their total is
-			// only known now (a neighbour seen at a much coarser scale collects many pixels per target), so the buffer grows
-			// to the exact size instead of failing (the reference's FuseDepthMaps has no such limit)
-			const size_t links = (size_t)lastOff + lastCnt;
-			if (links > L.capLinks) {
-				if (L.links) (void)hipFree(L.links);
-				L.links = nullptr; L.capLinks = 0;
-				const size_t want = std::max(links + links / 4, (size_t)1 << 20);
-				LANECHK(hipMalloc(&L.links, want * 4));
-				L.capLinks = want;
-				tb.nbrList = L.links;
-			}
-			launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, nullptr, ls);
-			if (debugDepth) LANECHK(hipMemsetAsync(flag32, 0, (size_t)n * 4, ls)); // diagnostic: dependence depth per pixel (the buffer is free until the compaction)
-			const auto tPass = std::chrono::steady_clock::now();
-			launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, maxArea, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
-			                 merged, n_min_views_fuse, c->fuseOrder, counters, blocks, debugDepth ? flag32 : nullptr, wantCloud, nullptr, ls);
+	HIPCHK(c, hipMemsetAsync(status, 0, 64, s));
+	HIPCHK(c, hipMemsetAsync(totals, 0, 64, s));
+	for (int oi = 0; oi < n_order; ++oi) {
+		const DevMap& A = host[order[oi]];
+		const int n = A.w * A.h;
+		const auto tPass = std::chrono::steady_clock::now();
+		HIPCHK(c, hipMemsetAsync(counters, 0, 64, s));
+		HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
+		HIPCHK(c, hipMemsetAsync(cntT, 0, (size_t)A.nNeighbors * stride * 4, s));
+		HIPCHK(c, hipMemsetAsync(fillT, 0, (size_t)A.nNeighbors * stride * 4, s));
+		launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, thDepth, normalError, s);
+		launch_fuse_pass(A, c->dMaps, tb, pendingList, b + oSettle, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
+		                 merged, n_min_views_fuse, c->fuseOrder, counters, wantCloud, s);
+		launch_fuse_status(ctl, status, s);
+		if (wantCloud)
+			launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, 0, capacity, cX, cN, cB, cV, pviews, pweights, vstride,
+			                    voff, 0, viewCapacity, cVI, cVW, totals, s);
+		launch_fuse_advance(counters, totals, wantCloud ? capacity : 0, wantCloud ? viewCapacity : 0, status, s);
+		if (debug) {
 			unsigned long long cnt[5] = {0, 0, 0, 0, 0};
 			uint32_t ctlWords[kCtlBytes / 4];
-			LANECHK(hipMemcpyAsync(cnt, counters, 40, hipMemcpyDeviceToHost, ls));
-			LANECHK(hipMemcpyAsync(ctlWords, ctl, kCtlBytes, hipMemcpyDeviceToHost, ls));
-			LANECHK(hipStreamSynchronize(ls));
-			if (ctlWords[kCtlErr] != 0 || ctlWords[kCtlDone] != ctlWords[kCtlPending]) {
-				// a worker gave up waiting (never expected): the claim and depth maps are half updated -- say so, the caller must
-				// not reuse them
-				laneFail(HCMVS_ERR_TIMEOUT, "fuse: the pass of image %u stalled (%u of %u pixels decided); the registered depth maps are left partially fused",
-				         A.id, ctlWords[kCtlDone], ctlWords[kCtlPending]);
-				return;
-			}
-			if (debug) {
-				const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tPass).count();
-				fprintf(stderr, "fuse: lane %d image %u: %u pending pixels, %u through the queues, %llu accepted; dependence depth %u, pass %.0f us = %.2f us per level; worker iterations %u busy (%.1f pixels each) + %u idle; settle steps %u, work lists %u %u %u %u %u %u %u\n",
-				        k, A.id, ctlWords[kCtlPending], [&] { uint32_t t = 0; for (int q = 0; q < kFuseQueues; ++q) t += ctlWords[kCtlTail + 32 * q]; return t; }(), cnt[3], ctlWords[kCtlLevels], us, us / std::max(1u, ctlWords[kCtlLevels]),
-				        ctlWords[8], ctlWords[10] / (double)std::max(1u, ctlWords[8]), ctlWords[9], ctlWords[kCtlSteps], ctlWords[kCtlWork], ctlWords[kCtlWork + 1],
-				        ctlWords[kCtlWork + 2], ctlWords[kCtlWork + 3], ctlWords[kCtlWork + 4], ctlWords[kCtlWork + 5], ctlWords[kCtlWork + 6]);
-			}
-			unsigned long long total = 0, viewTotal = 0;
-			{ // publish the counts; wait until every earlier image has published its own -> this image's place in the cloud
-				std::unique_lock<std::mutex> g(sh.mu);
-				sh.accepted[oi] = cnt[3]; sh.entries[oi] = cnt[4]; sh.depths += cnt[0];
-				sh.state[oi] = 2;
-				sh.cv.notify_all();
-				for (;;) {
-					if (sh.rc) return;
-					bool known = true;
-					for (int j = 0; j < oi; ++j) if (sh.state[j] < 2) { known = false; break; }
-					if (known) break;
-					sh.cv.wait(g);
-				}
-				for (int j = 0; j < oi; ++j) { total += sh.accepted[j]; viewTotal += sh.entries[j]; }
-			}
-			const unsigned long long accepted = cnt[3];
-			if (wantCloud && total + accepted > capacity) { laneFail(HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity); return; }
-			if (viewCapacity && viewTotal + cnt[4] > viewCapacity) { laneFail(HCMVS_ERR_CAPACITY, "fuse: view-list capacity %llu exceeded", (unsigned long long)viewCapacity); return; }
-			if (accepted && wantCloud) {
-				launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, total, capacity, cX, cN, cB, cV, pviews, pweights, vstride,
-				                    voff, viewTotal, viewCapacity, cVI, cVW, nullptr, nullptr, ls);
-				LANECHK(hipStreamSynchronize(ls));
-			}
-			{
-				std::lock_guard<std::mutex> g(sh.mu);
-				sh.state[oi] = 3;
-				sh.cv.notify_all();
-			}
+			HIPCHK(c, hipMemcpyAsync(cnt, counters, 40, hipMemcpyDeviceToHost, s));
+			HIPCHK(c, hipMemcpyAsync(ctlWords, ctl, kCtlBytes, hipMemcpyDeviceToHost, s));
+			HIPCHK(c, hipStreamSynchronize(s));
+			fprintf(stderr, "fuse: image %u: %u pending pixels, %llu become points; settle iteration: %u steps, work lists", A.id, ctlWords[kCtlPending], cnt[3], ctlWords[kCtlSteps]);
+			for (int k = 0; k <= kSettleSteps; ++k) fprintf(stderr, " %u", ctlWords[kCtlWork + k]);
+			fprintf(stderr, "; %.0f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tPass).count());
 		}
-#undef LANECHK
-	};
-	if (nLanes == 1) worker(0);
-	else {
-		std::vector<std::thread> th;
-		for (int k = 0; k < nLanes; ++k) th.emplace_back(worker, k);
-		for (auto& t : th) t.join();
 	}
-	if (sh.rc) return fail(c, sh.rc, "%s", sh.msg.c_str());
-	unsigned long long total = 0, viewTotal = 0;
-	for (int i = 0; i < n_order; ++i) { total += sh.accepted[i]; viewTotal += wantCloud ? sh.entries[i] : 0; }
-	if (!viewCapacity) viewTotal = 0;
-	const unsigned long long depths = sh.depths;
-	launch_unclaim(c->dMaps, (int)host.size(), s); // every lane has synchronised its stream: the claim marks come off the depth maps
+	launch_unclaim(c->dMaps, (int)host.size(), s); // the claim marks come off the depth maps
 	HIPCHK(c, hipGetLastError());
+	uint32_t st[4] = {0, 0, 0, 0};
+	unsigned long long tot[3] = {0, 0, 0};
+	HIPCHK(c, hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipMemcpyAsync(tot, totals, 24, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipStreamSynchronize(s));
+	if (st[0] != 0) return fail(c, HCMVS_ERR_TIMEOUT, "fuse: the settle iteration of a pass gave up; the registered depth maps are left partially fused");
+	if (st[3] == 1) return fail(c, HCMVS_ERR_CAPACITY, "fuse: cloud capacity %llu exceeded", (unsigned long long)capacity);
+	if (st[3] == 2) return fail(c, HCMVS_ERR_CAPACITY, "fuse: view-list capacity %llu exceeded", (unsigned long long)viewCapacity);
 	const auto tCopy = std::chrono::steady_clock::now();
+	const unsigned long long total = tot[0], viewTotal = viewCapacity && wantCloud ? tot[1] : 0;
 	if (wantCloud) HIPCHK(c, hipMemcpyAsync(xyz, cX, total * 12, hipMemcpyDeviceToHost, s));
 	if (normal) HIPCHK(c, hipMemcpyAsync(normal, cN, total * 12, hipMemcpyDeviceToHost, s));
 	if (bgr) HIPCHK(c, hipMemcpyAsync(bgr, cB, total * 3, hipMemcpyDeviceToHost, s));
 	if (n_views) HIPCHK(c, hipMemcpyAsync(n_views, cV, total * 4, hipMemcpyDeviceToHost, s));
-	if (viewCapacity) {
+	if (viewCapacity && wantCloud) {
 		HIPCHK(c, hipMemcpyAsync(cloud->view_ids, cVI, viewTotal * 4, hipMemcpyDeviceToHost, s));
 		HIPCHK(c, hipMemcpyAsync(cloud->view_weights, cVW, viewTotal * 4, hipMemcpyDeviceToHost, s));
 	}
@@ -1310,7 +1074,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 		        std::chrono::duration<double, std::milli>(now - tCopy).count());
 	}
 	*n_points = total;
-	if (n_depths) *n_depths = depths;
+	if (n_depths) *n_depths = tot[2];
 	cloud->n_view_entries = viewTotal;
 	return HCMVS_OK;
 }
@@ -1332,10 +1096,7 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 // The post-filters of one outer iteration, image after image.  Every image costs a complete fusion over all maps (that IS the
 // fork's RemoveSmallSegments, SceneDensify.cpp:2048-2275), so the fusion here is the one thing that must be cheap: it produces no
 // cloud, and all its passes are enqueued on the context's stream WITHOUT host synchronisation -- stream order is the image order
-// of the sequential algorithm.  The one thing the synchronous path asks the host for, the size of a pass's link lists, is checked
-// on the device instead (fuse_links_check_kernel): when the lists do not fit, every later kernel of that fusion returns at once,
-// the depth maps are put back from a snapshot taken before it, the lists grow and the fusion runs again.  One synchronisation
-// per image.
+// of the sequential algorithm.  One synchronisation at the end of the sequence.
 int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse,
                               float depth_diff_threshold, float normal_diff_deg, int32_t gap_size, uint64_t* n_filled) {
 	if (!c) return HCMVS_ERR_INVALID;
@@ -1349,7 +1110,7 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 	std::vector<DevMap> host;
 	int rc = build_map_table(c, host);
 	if (rc) return rc;
-	size_t maxArea = 0, stride = 0, allPx = 0, maxIdArea = 0;
+	size_t maxArea = 0, stride = 0, maxIdArea = 0;
 	int maxNb = 1;
 	for (int i = 0; i < n_order; ++i) {
 		if (order[i] >= host.size() || !host[order[i]].depth) return fail(c, HCMVS_ERR_INVALID, "postfilter: view %u has no maps", order[i]);
@@ -1358,101 +1119,59 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 		maxNb = std::max(maxNb, (int)host[order[i]].nNeighbors);
 	}
 	stride = maxArea;
-	for (const auto& m : host) if (m.depth) { stride = std::max(stride, (size_t)m.w * m.h); allPx += (size_t)m.w * m.h; }
+	for (const auto& m : host) if (m.depth) stride = std::max(stride, (size_t)m.w * m.h);
 	for (int k = 0; k < n_ids; ++k) { View& v = c->views.find(ids[k])->second; maxIdArea = std::max(maxIdArea, (size_t)v.w * v.h); rc = ensure_gradient(c, v); if (rc) return rc; }
 	const size_t tblElems = stride * (size_t)maxNb;
 	if (stride >= ((size_t)1 << 29) || tblElems > 0x7FFFFFFFull) return fail(c, HCMVS_ERR_CAPACITY, "postfilter: %d neighbours of %zu pixels exceed the per-pass tables", maxNb, stride);
-	const size_t scanBytes = (std::max({fuse_scan_temp_bytes((int)maxArea), fuse_scan_temp_bytes((int)tblElems), fuse_scan_temp_bytes((int)(2 * stride))}) + 255) & ~(size_t)255;
+	const size_t scanBytes = (std::max(fuse_scan_temp_bytes((int)maxArea), fuse_scan_temp_bytes((int)tblElems)) + 255) & ~(size_t)255;
 	size_t off = 0;
 	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-	const size_t oPending = carve(maxArea * 4), oQueue = carve(maxArea * 4 * (size_t)kFuseQueues), oTgt = carve(maxArea * 4 * (size_t)maxNb),
-	             oCntT = carve(tblElems * 4), oFillT = carve(tblElems * 4), oCntP = carve(stride * 8), oOffT = carve(tblElems * 4), oOffP = carve(stride * 8),
+	const size_t oPending = carve(maxArea * 4), oSettle = carve(fuse_settle_bytes(maxArea)), oTgt = carve(maxArea * 4 * (size_t)maxNb),
+	             oCntT = carve(tblElems * 4), oFillT = carve(tblElems * 4), oOffT = carve(tblElems * 4),
 	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(kCtlBytes), oCounters = carve(64), oStatus = carve(64), oMerged = carve(maxArea * 4),
-	             oFlag = carve(maxArea), oNv = carve(maxArea * 4), oScan = carve(scanBytes), oDF = carve(maxIdArea * 4), oNF = carve(maxIdArea * 12),
-	             oSnap = carve(allPx * 4);
-	if (c->fuseLanes.empty()) c->fuseLanes.resize(1);
-	FuseLane& L = c->fuseLanes[0];
-	if (L.cap < off) {
-		if (L.scratch) (void)hipFree(L.scratch);
-		L.scratch = nullptr; L.cap = 0;
-		HIPCHK(c, hipMalloc(&L.scratch, off));
-		L.cap = off;
+	             oFlag = carve(maxArea), oNv = carve(maxArea * 4), oScan = carve(scanBytes), oDF = carve(maxIdArea * 4), oNF = carve(maxIdArea * 12);
+	if (c->capPass < off) {
+		if (c->passScratch) (void)hipFree(c->passScratch);
+		c->passScratch = nullptr; c->capPass = 0;
+		HIPCHK(c, hipMalloc(&c->passScratch, off));
+		c->capPass = off;
 	}
-	if (!L.links) { // first size of the link lists; HCMVS_FUSE_LINKS_INIT (entries) lets a test start too small and exercise the undo-and-grow path
-		size_t first = (size_t)8 << 20;
-		if (getenv("HCMVS_FUSE_LINKS_INIT") && atol(getenv("HCMVS_FUSE_LINKS_INIT")) > 0) first = (size_t)atol(getenv("HCMVS_FUSE_LINKS_INIT"));
-		HIPCHK(c, hipMalloc(&L.links, first * 4));
-		L.capLinks = first;
-	}
-	char* b = L.scratch;
-	uint32_t* pendingList = (uint32_t*)(b + oPending); uint32_t* queue = (uint32_t*)(b + oQueue); uint32_t* ctl = (uint32_t*)(b + oCtl);
+	char* b = c->passScratch;
+	uint32_t* pendingList = (uint32_t*)(b + oPending); uint32_t* ctl = (uint32_t*)(b + oCtl);
 	unsigned long long* counters = (unsigned long long*)(b + oCounters);
 	uint32_t* status = (uint32_t*)(b + oStatus);
 	int32_t* targets = (int32_t*)(b + oTgt);
-	uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders),
-	         *cntP = (uint32_t*)(b + oCntP), *offP = (uint32_t*)(b + oOffP);
+	uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders);
 	uint8_t* flag = (uint8_t*)(b + oFlag); uint32_t* merged = (uint32_t*)(b + oMerged); uint32_t* pnv = (uint32_t*)(b + oNv);
-	float* dF = (float*)(b + oDF); float* nF = (float*)(b + oNF); float* snap = (float*)(b + oSnap);
+	float* dF = (float*)(b + oDF); float* nF = (float*)(b + oNF);
 	const float normalError = cosf(normal_diff_deg * (3.14159274101257324f / 180.f)); // plain thresholds (SceneDensify.cpp:2083, 2177)
 	const float thDepth = depth_diff_threshold;
-	if (c->nCU <= 0) {
-		hipDeviceProp_t prop;
-		HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
-		c->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
-	}
-	int blocks = c->nCU * 4;
-	if (getenv("HCMVS_FUSE_BLOCKS")) blocks = std::min(c->nCU * 16, std::max(1, atoi(getenv("HCMVS_FUSE_BLOCKS"))));
+	const FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, stride);
 	hipStream_t s = c->stream;
-	unsigned long long filledAll = 0;
-	HIPCHK(c, hipMemsetAsync(queue, 0xFF, maxArea * 4 * (size_t)kFuseQueues, s)); // FS_EMPTY; every pass leaves the queues so
+	HIPCHK(c, hipMemsetAsync(status, 0, 64, s));
+	HIPCHK(c, hipMemsetAsync(counters, 0, 64, s)); // counters[5]: pixels filled, summed over the sequence
 	for (int k = 0; k < n_ids; ++k) {
 		View& v = c->views.find(ids[k])->second;
-		for (int attempt = 0;; ++attempt) {
-			HIPCHK(c, hipMemsetAsync(status, 0, 64, s));
-			HIPCHK(c, hipMemsetAsync(counters, 0, 64, s));
-			{ // the snapshot the fusion is undone from when a link list turns out too small
-				size_t o = 0;
-				for (const auto& m : host) if (m.depth) { HIPCHK(c, hipMemcpyAsync(snap + o, m.depth, (size_t)m.w * m.h * 4, hipMemcpyDeviceToDevice, s)); o += (size_t)m.w * m.h; }
-			}
-			for (int oi = 0; oi < n_order; ++oi) {
-				const DevMap& A = host[order[oi]];
-				HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
-				HIPCHK(c, hipMemsetAsync(cntT, 0, (size_t)A.nNeighbors * stride * 4, s)); // per-target counts of this image's neighbours
-				HIPCHK(c, hipMemsetAsync(fillT, 0, (size_t)A.nNeighbors * stride * 4, s));
-				HIPCHK(c, hipMemsetAsync(cntP, 0, stride * 8, s));
-				FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, cntP, offP, L.links, stride);
-				launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, c->fuseOrder, thDepth, normalError, status, s);
-				launch_fuse_links_check(tb, (unsigned long long)L.capLinks, status, s);
-				launch_fuse_links_fill(A, tb, pendingList, ctl, c->fuseOrder, status, s);
-				launch_fuse_pass(A, c->dMaps, tb, pendingList, queue, maxArea, ctl, nullptr, nullptr, nullptr, pnv, flag, nullptr, nullptr, maxNb + 1, merged, n_min_views_fuse,
-				                 c->fuseOrder, counters, blocks, nullptr, false, status, s);
-				launch_fuse_status(ctl, status, s);
-			}
-			launch_postfilter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, c->dMaps, (int)host.size(), v.gra, dF, nF, gap_size, depth_diff_threshold * 2.5f, counters + 5, status, s);
-			HIPCHK(c, hipGetLastError());
-			uint32_t st[4] = {0, 0, 0, 0};
-			unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};
-			HIPCHK(c, hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, s));
-			HIPCHK(c, hipMemcpyAsync(cnt, counters, 48, hipMemcpyDeviceToHost, s));
-			HIPCHK(c, hipStreamSynchronize(s));
-			if (st[1] != 0) { // a link list did not fit: undo, grow, again
-				size_t o = 0;
-				for (const auto& m : host) if (m.depth) { HIPCHK(c, hipMemcpyAsync(m.depth, snap + o, (size_t)m.w * m.h * 4, hipMemcpyDeviceToDevice, s)); o += (size_t)m.w * m.h; }
-				HIPCHK(c, hipStreamSynchronize(s));
-				if (attempt >= 4) return fail(c, HCMVS_ERR_CAPACITY, "postfilter: the link lists of a pass keep outgrowing their buffer (%u entries)", st[2]);
-				(void)hipFree(L.links);
-				L.links = nullptr; L.capLinks = 0;
-				const size_t want = (size_t)st[2] + (size_t)st[2] / 4 + ((size_t)1 << 20);
-				HIPCHK(c, hipMalloc(&L.links, want * 4));
-				L.capLinks = want;
-				continue;
-			}
-			if (st[0] != 0) return fail(c, HCMVS_ERR_TIMEOUT, "postfilter: a fusion pass stalled; the registered depth maps are left partially fused");
-			filledAll += cnt[5];
-			break;
+		for (int oi = 0; oi < n_order; ++oi) {
+			const DevMap& A = host[order[oi]];
+			HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
+			HIPCHK(c, hipMemsetAsync(cntT, 0, (size_t)A.nNeighbors * stride * 4, s)); // per-target counts of this image's neighbours
+			HIPCHK(c, hipMemsetAsync(fillT, 0, (size_t)A.nNeighbors * stride * 4, s));
+			launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, thDepth, normalError, s);
+			launch_fuse_pass(A, c->dMaps, tb, pendingList, b + oSettle, ctl, nullptr, nullptr, nullptr, pnv, flag, nullptr, nullptr, maxNb + 1, merged, n_min_views_fuse,
+			                 c->fuseOrder, counters, false, s);
+			launch_fuse_status(ctl, status, s);
 		}
+		launch_postfilter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, c->dMaps, (int)host.size(), v.gra, dF, nF, gap_size, depth_diff_threshold * 2.5f, counters + 5, s);
 	}
-	if (n_filled) *n_filled = filledAll;
+	HIPCHK(c, hipGetLastError());
+	uint32_t st[4] = {0, 0, 0, 0};
+	unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};
+	HIPCHK(c, hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipMemcpyAsync(cnt, counters, 48, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipStreamSynchronize(s));
+	if (st[0] != 0) return fail(c, HCMVS_ERR_TIMEOUT, "postfilter: the settle iteration of a fusion pass gave up; the registered depth maps are left partially fused");
+	if (n_filled) *n_filled = cnt[5];
 	return HCMVS_OK;
 }
 

@@ -1,7 +1,7 @@
 """diagnostic (not a test): what a fusion pass costs on the maps the post-filters see -- the UNFILTERED score maps between outer
-iterations (every pixel holds an estimate) -- against the final, end-filtered maps: pending pixels, depth of the dependence graph,
-time per pass (HCMVS_FUSE_DEBUG lines of the synchronous path), for several worker counts (HCMVS_FUSE_BLOCKS).
-  python tools/pf_depth.py [n_views=9] [blocks,blocks,... ("" = default)]"""
+iterations (every pixel holds an estimate) -- against the final, end-filtered maps: pending pixels, points, steps and work-list sizes
+of the settle iteration, time per image (the HCMVS_FUSE_DEBUG lines: one host synchronisation per image).
+  python tools/pf_depth.py [n_views=9]"""
 import importlib, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -50,12 +50,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     ctx.close()
     sys.exit(0)
 n = sys.argv[1] if len(sys.argv) > 1 else "9"
-for blocks in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("", "2048", "4096")):
-    env = dict(os.environ, HCMVS_FUSE_DEBUG=os.environ.get("HCMVS_FUSE_DEBUG", "2"), HCMVS_FUSE_LANES="1")  # 1: times without the depth instrumentation
-    if blocks:
-        env["HCMVS_FUSE_BLOCKS"] = blocks
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), n, "child"], env=env, capture_output=True, text=True)
-    print("== HCMVS_FUSE_BLOCKS", blocks or "default (4 per CU)")
-    for ln in (r.stdout + r.stderr).splitlines():
-        if ln.startswith(("MAPS", "POINTS", "fuse:")):
-            print(ln)
+r = subprocess.run([sys.executable, os.path.abspath(__file__), n, "child"], env=dict(os.environ, HCMVS_FUSE_DEBUG="1"), capture_output=True, text=True)
+for ln in (r.stdout + r.stderr).splitlines():
+    if ln.startswith(("MAPS", "POINTS", "fuse:")):
+        print(ln)
