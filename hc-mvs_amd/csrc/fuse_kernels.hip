@@ -14,18 +14,16 @@
  *     parallel.  HBM-bound integer/float work, one thread per pixel, coalesced over the reference map.
  *   - Fuse: a pixel of image A interacts with other pixels of A only through the neighbour pixels it
  *     projects onto (its targets).  The pixels that project onto one neighbour pixel are listed per target
- *     (CSR, built once per image pass); a pixel may run once every lower raster index on all its targets has
- *     been decided.  The image pass is a DATAFLOW over that dependence graph: every pixel carries a countdown
- *     of its undecided blockers; a worker that decides a pixel runs the reference's body, drains its stores,
- *     decrements the countdowns of the higher indices on its targets and hands the ones that reach zero on --
- *     the first to itself, the others through an append-only queue the idle lanes poll.  No grid barrier and
- *     no co-residency assumption: one dependent hop costs a body plus one atomic instead of a whole round.
- *     Pixels sharing a target are decided in raster order, so the cloud is identical to the sequential one,
- *     point order included (ordered compaction).
+ *     (CSR, built once per image pass).  Whether a pixel becomes a point depends on which of its targets the
+ *     pixels BEFORE it (raster order) have left available -- a well-founded recursion with exactly one
+ *     solution, which is found by iteration: every pixel evaluated in parallel under the assumption that all
+ *     the others become points, then only the pixels whose inputs changed, until nothing changes (the settle
+ *     iteration below; a handful of parallel steps where a walk of the dependence graph takes hundreds to
+ *     thousands of sequential hops).  The decisions are the sequential algorithm's, so the cloud is identical
+ *     to the sequential one, point order included (ordered compaction).
  *     "Claimed" (SceneDensify.cpp:3313 arrDepthIdx != NO_ID) is the SIGN of the depth while a fusion runs: an estimate that became
  *     part of a point holds -depth, an invalidated one 0, a free one +depth -- one 4-byte load tells a pixel everything about a
- *     target (depth and claim were two scattered loads from two maps; the pass is bound by exactly those), and there are no claim
- *     maps to allocate and reset.  launch_unclaim() takes the signs off again when the fusion is over.
+ *     target, and there are no claim maps to allocate and reset.  launch_unclaim() takes the signs off again when the fusion is over.
  *
  * Double precision follows the reference (Point3 = double); no contraction (-ffp-contract=off).
  */
@@ -299,8 +297,7 @@ struct FuseOut { // per pixel of the current image, compacted in raster order af
 	float* xyz; float* normal; uint8_t* bgr; uint32_t* nviews; uint8_t* flag;
 	uint32_t* views; float* weights; int vstride; // optional: the point's view list (image ids ascending) and weights, vstride per pixel
 };
-// status words of a fusion enqueued without host synchronisation (hcmvs_postfilter_sequence): [0] a pass stalled or timed out,
-// [1] the link lists of a pass do not fit (nothing after that point has touched the maps), [2] the size they need
+// status words of a fusion enqueued without host synchronisation: [0] the settle iteration of a pass gave up (never expected)
 __global__ void fuse_status_kernel(const uint32_t* ctl, uint32_t* status) {
 	if (blockIdx.x != 0 || threadIdx.x != 0) return;
 	if (ctl[kCtlErr] != 0u) status[0] = 1u;
@@ -309,7 +306,7 @@ __global__ void fuse_status_kernel(const uint32_t* ctl, uint32_t* status) {
 // next image's compaction starts from; status[3] says that the cloud (1) or the view lists (2) do not fit
 __global__ void fuse_advance_kernel(const unsigned long long* counters, unsigned long long* totals, unsigned long long capacity,
                                     unsigned long long viewCapacity, uint32_t* status) {
-	if (blockIdx.x != 0 || threadIdx.x != 0 || status[1] != 0u) return;
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
 	if (capacity && totals[0] + counters[3] > capacity) status[3] = 1u;
 	if (viewCapacity && totals[1] + counters[4] > viewCapacity) status[3] = 2u;
 	totals[0] += counters[3]; totals[1] += counters[4]; totals[2] += counters[0];
@@ -334,7 +331,7 @@ __global__ void unclaim_kernel(const DevMap* maps, int nMaps) {
 // re-evaluating the pixels whose inputs changed arrives at it: start from "every pixel is a point" (true for > 99 % of the pixels
 // of an estimated map), evaluate everybody in parallel, and then only the later bidders of the targets of whoever changed, until
 // nothing changes.  The steps are ordinary parallel kernels; their number is the length of the longest chain of CHANGES (a handful),
-// not of the dependence graph (hundreds to thousands of hops, which is what the dataflow pass above walks through one hop at a time).
+// not of the dependence graph (hundreds to thousands of hops when it is walked one hop at a time, as rounds 1-3 did).
 struct FuseSettle {
 	FuseTables tb;
 	uint8_t* acc;       // [w*h] 1: the pixel is a point (as far as the iteration knows)

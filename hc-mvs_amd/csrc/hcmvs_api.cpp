@@ -20,9 +20,6 @@
 #include <string>
 #include <algorithm>
 #include <chrono>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
 #include <vector>
 
 using namespace hcmvs;
