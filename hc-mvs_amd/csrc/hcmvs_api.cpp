@@ -599,7 +599,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 		HIPCHK(c, hipMemsetAsync(c->sync + 16, 0, sizeof(int32_t) * kMaxBatch, s)); // the tickets; the error word stays sticky
 		for (int i = 0; i < n_items; ++i)
 			HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * c->hItems[i].border) * kProgressStride * sizeof(int32_t), s));
-		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : (n_items == 2 ? 2 : 3)); // measured: profiles/r02_knobs.txt
+		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : 2); // measured: profiles/r03_small_batches.txt
 		{
 			// the launcher picks the kernel variant by view count: an item whose count leaves two or more view groups idle wants the
 			// pair-packing variant, which is correct for the other items of its layout class too

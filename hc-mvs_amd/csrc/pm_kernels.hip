@@ -1121,7 +1121,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 				// wait is free) and refresh the progress of the row above with an asynchronous poll
 				hooked = true;
 				STAMP(5)
-				if (wv == 0 && pp.pendingPub > 0) {
+				if (pp.pendingPub > 0) { // NW == 1 only (see the end of process_pixel)
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 					if (lane == 0) __hip_atomic_store(pp.myWord, pp.pendingPub, __ATOMIC_RELAXED, HC_SCOPE);
 					pp.pendingPub = 0;
@@ -1286,12 +1286,20 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 	if (lane == 0) {
 		float* hrec = sh.hist[q & (kHist - 1)];
 		hrec[0] = depth; hrec[1] = n0; hrec[2] = n1; hrec[3] = n2; hrec[4] = conf;
-		if (wv == 0) {
+		if (wv == NW - 1) { // every wave holds the result; the last one stores it
 			store_dn(&c.dn[idx], depth, n0, n1, n2);
 			store_f(&c.conf[idx], conf);
 		}
 	}
-	pp.pendingPub = q + 1;
+	if constexpr (NW == 1) {
+		pp.pendingPub = q + 1; // published by the hook of the next pixel, a scoring round later: the drain of the stores is then free
+	} else if (wv == NW - 1) {
+		// several waves per row (one or two images alone on the chip: the row wavefront's critical path is what counts): the column is
+		// published at once.  The last wave has no share of the next pixel's propagation round when there are at most NW - 1
+		// candidates (it_external 0: two), so the drain of its stores delays nobody there.
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (lane == 0) __hip_atomic_store(pp.myWord, q + 1, __ATOMIC_RELAXED, HC_SCOPE);
+	}
 	STAMP(9)
 
 }
@@ -1422,7 +1430,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			taps += (unsigned long long)(evals - e0) * (unsigned)((P.a + 1) * (P.a + 1));
 		}
 		if (pp.fail) break;
-		if (wv == 0 && pp.pendingPub > 0) { // last column of the row
+		if (pp.pendingPub > 0) { // last column of the row (NW == 1)
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			if ((threadIdx.x & 63) == 0) __hip_atomic_store(pp.myWord, pp.pendingPub, __ATOMIC_RELAXED, HC_SCOPE);
 			pp.pendingPub = 0;
