@@ -270,3 +270,44 @@ def test_postfilter_sequence_equals_image_after_image(ctx):
         d, n, c = c2.get_depthmap(i, with_normal=True)
         assert np.array_equal(d, cur[i]["depth"]) and np.array_equal(n, cur[i]["normal"]) and np.array_equal(c, cur[i]["conf"]), i
     c2.close()
+
+
+def chain_maps(w=512, h=24, depth=5.0):
+    """three views of a fronto-parallel plane from ONE camera position: A at full horizontal resolution, B and C at half of it, their
+    pixel grids shifted by a quarter pixel either way, so that A's pixels 2j, 2j+1 land on B's pixel j and 2j-1, 2j on C's pixel j.
+    With nMinViewsFuse = 3 a pixel of A becomes a point only when BOTH its targets are still free: x = 0 is one (it claims B0 and
+    C0), so x = 1 (shares B0) is not, so C1 stays free and x = 2 is one ... -- the answer of every pixel of a row hangs on the answer
+    of the pixel before it, over the whole row, and it ALTERNATES: the worst case for an iteration that starts from "every pixel is a
+    point" (its changes travel one pixel per step)."""
+    f = 300.0
+    def view(width, fx, cx):
+        K = np.array([[fx, 0, cx], [0, f, (h - 1) / 2.0], [0, 0, 1]], np.float64)
+        d = np.full((h, width), depth, np.float32)
+        n = np.zeros((h, width, 3), np.float32); n[..., 2] = -1
+        g = np.full((h, width), 0.5, np.float32)
+        g8 = np.full((h, width), 128, np.uint8)
+        return dict(K=K, R=np.eye(3), C=np.zeros(3), gray=g, depth=d, normal=n, conf=np.full((h, width), 0.8, np.float32),
+                    bgr=np.stack([g8, g8, g8], -1).copy(), d_min=1.0, d_max=10.0, neighbors=[])
+    cxA = (w - 1) / 2.0
+    A = view(w, f, cxA)
+    B = view(w // 2 + 1, f / 2, cxA / 2 - 0.25)
+    Cm = view(w // 2 + 1, f / 2, cxA / 2 + 0.25)
+    A["neighbors"] = [1, 2]
+    return [A, B, Cm], [0, 1, 2]
+
+
+def test_fuse_alternating_chain_through_the_settle_loop(ctx):
+    """the settle iteration (fuse_kernels.hip) converges in two or three steps on estimated maps; here it needs about as many steps as a
+    row has pixels, far beyond the full-grid steps that are enqueued, so the single-workgroup loop that finishes the iteration does
+    nearly all of it.  Same decisions as the sequential oracle (SceneDensify.cpp:3395-3449), in both pixel orders of the C-ABI's raster
+    rule (order 0)."""
+    maps, order = chain_maps()
+    upload(ctx, maps)
+    want = O.fuse_depthmaps(maps, order, 20000, n_min_views_fuse=3)
+    got = ctx.fuse(order, 20000, n_min_views_fuse=3)
+    h, w = maps[0]["depth"].shape
+    assert want["n_points"] == h * (w // 2)                 # every other pixel of A, nothing from B and C
+    assert got["n_points"] == want["n_points"] and got["n_depths"] == want["n_depths"]
+    assert np.array_equal(got["xyz"], want["xyz"]) and np.array_equal(got["n_views"], want["n_views"])
+    for i, d in enumerate(want["depths"]):
+        assert np.array_equal(ctx.get_depthmap(i)[0], d)
