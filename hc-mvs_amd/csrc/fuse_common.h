@@ -34,21 +34,20 @@ void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsig
 struct FuseTables {
 	int32_t* targets;    // [w*h][nNeighbors]: pixel index A's pixel projects onto in neighbour q (SceneDensify.cpp:3387-3393) + what it can do there
 	                     // (bits 29-30: merge / in front); -1 when it can do nothing
-	uint32_t* cntT;      // [nNeighbors][stride]: number of pending pixels of A that project onto each neighbour pixel ("bidders" of that target)
-	uint32_t* offT;      // exclusive scan of cntT: start of that neighbour pixel's list in `bidders`
-	uint32_t* fillT;     // fill cursors while the lists are written
-	uint32_t* bidders;   // the lists: raster indices of A's pending pixels, per target
-	size_t stride;       // pixels reserved per neighbour map in cntT / offT / fillT
+	uint32_t* head;      // [nNeighbors][stride]: per neighbour pixel, the first entry of the list of A's pending pixels that project onto it
+	                     // (its "bidders"), 0xFFFFFFFF = none.  List entry e = q * (w*h) + pixel
+	uint32_t* next;      // [nNeighbors][w*h]: the entry after entry e in its target's list, 0xFFFFFFFF = end
+	size_t stride;       // pixels reserved per neighbour map in head
 };
 
-FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_t* fillT, uint32_t* bidders, size_t stride);
+FuseTables fuse_tables(int32_t* targets, uint32_t* head, uint32_t* next, size_t stride);
 // ctl: kCtlBytes, zero before the pass: [kCtlPending] pending pixels, [kCtlErr] the settle iteration gave up (never expected),
 // [kCtlSteps] steps it took, [kCtlWork + s] length of the work list step s wrote (diagnostics)
 constexpr int kSettleSteps = 3; // full-grid steps of the settle iteration after step 0; a single workgroup finishes what they leave
 constexpr int kCtlPending = 4, kCtlSteps = 6, kCtlWork = 16, kCtlErr = 32; // word indices
 constexpr size_t kCtlBytes = 256;
-void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
-                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, float thDepth, float normalError, hipStream_t s);
+void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, uint32_t* pending, uint32_t* ctl, uint8_t* flag,
+                       unsigned long long* counters, float thDepth, float normalError, hipStream_t s);
 // status words of a fusion enqueued without host synchronisation: [0] a pass gave up (never expected), [3] = 1 / 2: the cloud / the view
 // lists overflowed their capacity
 void launch_fuse_status(const uint32_t* ctl, uint32_t* status, hipStream_t s);

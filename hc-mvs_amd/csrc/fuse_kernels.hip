@@ -269,27 +269,16 @@ __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, u
 					}
 				}
 				tb.targets[(size_t)idx * A.nNeighbors + q] = t;
-				if (t >= 0) atomicAdd(&tb.cntT[q * tb.stride + ib], 1u);
+				if (t >= 0) { // pushed onto the target's list of bidders; list entry = q * pixels(A) + pixel
+					const uint32_t e = (uint32_t)q * (uint32_t)n + (uint32_t)idx;
+					tb.next[e] = atomicExch(&tb.head[q * tb.stride + ib], e);
+				}
 			}
 		}
 		list_append(pend, idx, pending, roundCnt + 1);
 	}
 	if (nd) atomicAdd(&counters[0], (unsigned long long)nd); // valid depths visited (SceneDensify.cpp:3359)
 }
-// write the per-target lists (any order inside a list)
-__global__ void fuse_fill_kernel(int nNb, FuseTables tb, const uint32_t* pending, const uint32_t* roundCnt) {
-	const int n = (int)roundCnt[1];
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const uint32_t idx = pending[i];
-		for (int q = 0; q < nNb; ++q) {
-			const int32_t tg = tb.targets[(size_t)idx * nNb + q];
-			if (tg < 0) continue;
-			const size_t t = q * tb.stride + (size_t)(tg & kTargetIndexMask);
-			tb.bidders[tb.offT[t] + atomicAdd(&tb.fillT[t], 1u)] = idx;
-		}
-	}
-}
-
 // order: 0 = raster order (the reference's), 1 = a fixed pseudo-random order (a bijective hash of the raster index)
 __device__ __forceinline__ uint32_t fuse_prio(uint32_t idx, int order) { return order ? idx * 0x9E3779B1u : idx; }
 
@@ -339,19 +328,19 @@ struct FuseSettle {
 	uint32_t* work[2];  // work lists: step s reads work[(s - 1) & 1] and writes work[s & 1]
 	uint32_t* ctl;      // kCtlWork + s: length of the list step s wrote
 	int nNb, nMinViewsFuse, order;
+	uint32_t nA;        // pixels of A: list entry e of neighbour q stands for pixel e - q * nA
 };
-// is p a point, given what acc says about the pixels before it?  (the targets' bidder lists are short: a handful of pixels)
+constexpr uint32_t kListEnd = 0xFFFFFFFFu;
+// is p a point, given what acc says about the pixels before it?  (a target's bidders are a linked list built by fuse_begin_kernel, a handful of pixels long)
 __device__ __forceinline__ bool settle_eval(const FuseSettle& S, uint32_t p, uint32_t* mergeOut, uint32_t* inFrontOut) {
 	const uint32_t pp = fuse_prio(p, S.order);
 	uint32_t merge = 0u, inFront = 0u;
 	for (int q = 0; q < S.nNb; ++q) {
 		const int32_t tg = S.tb.targets[(size_t)p * S.nNb + q];
 		if (tg < 0) continue;
-		const size_t t = q * S.tb.stride + (size_t)(tg & kTargetIndexMask);
-		const uint32_t o = S.tb.offT[t], len = S.tb.cntT[t];
 		bool avail = true;
-		for (uint32_t k = 0; k < len && avail; ++k) {
-			const uint32_t b = S.tb.bidders[o + k];
+		for (uint32_t e = S.tb.head[q * S.tb.stride + (size_t)(tg & kTargetIndexMask)]; e != kListEnd && avail; e = S.tb.next[e]) {
+			const uint32_t b = e - (uint32_t)q * S.nA; // the pixel of list entry e
 			if (b != p && fuse_prio(b, S.order) < pp && ld_u8(&S.acc[b]) != 0) avail = false;
 		}
 		if (!avail) continue;
@@ -370,10 +359,8 @@ __device__ __forceinline__ void settle_pixel(const FuseSettle& S, uint32_t p, ui
 	for (int q = 0; q < S.nNb; ++q) {
 		const int32_t tg = S.tb.targets[(size_t)p * S.nNb + q];
 		if (tg < 0) continue;
-		const size_t t = q * S.tb.stride + (size_t)(tg & kTargetIndexMask);
-		const uint32_t o = S.tb.offT[t], len = S.tb.cntT[t];
-		for (uint32_t k = 0; k < len; ++k) {
-			const uint32_t b = S.tb.bidders[o + k];
+		for (uint32_t e = S.tb.head[q * S.tb.stride + (size_t)(tg & kTargetIndexMask)]; e != kListEnd; e = S.tb.next[e]) {
+			const uint32_t b = e - (uint32_t)q * S.nA;
 			if (fuse_prio(b, S.order) > pp && atomicExch(&S.stamp[b], step + 1u) != step + 1u) append(b);
 		}
 	}
@@ -677,18 +664,16 @@ void launch_filter_vote(const DevMap& ref, const DevMap* nbs, int N, const unsig
                         int nMinViewsAdjust, float thr, float* newDepth, float* newConf, unsigned long long* counters, hipStream_t s) {
 	hipLaunchKernelGGL(filter_vote_kernel, kGrid, kBlock, 0, s, ref, nbs, N, keys, adjust, nMinViews, nMinViewsAdjust, thr, newDepth, newConf, counters);
 }
-FuseTables fuse_tables(int32_t* targets, uint32_t* cntT, uint32_t* offT, uint32_t* fillT, uint32_t* bidders, size_t stride) {
+FuseTables fuse_tables(int32_t* targets, uint32_t* head, uint32_t* next, size_t stride) {
 	FuseTables tb;
-	tb.targets = targets; tb.cntT = cntT; tb.offT = offT; tb.fillT = fillT; tb.bidders = bidders; tb.stride = stride;
+	tb.targets = targets; tb.head = head; tb.next = next; tb.stride = stride;
 	return tb;
 }
 // begin of an image pass: the pending list (its length in ctl[kCtlPending]), the pixels' targets and the per-target bidder lists
-// (cntT / fillT must be zero)
-void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, void* scanTemp, size_t scanTempBytes, uint32_t* pending,
-                       uint32_t* ctl, uint8_t* flag, unsigned long long* counters, float thDepth, float normalError, hipStream_t s) {
+// (tb.head must be all ones)
+void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, uint32_t* pending, uint32_t* ctl, uint8_t* flag,
+                       unsigned long long* counters, float thDepth, float normalError, hipStream_t s) {
 	hipLaunchKernelGGL(fuse_begin_kernel, kGrid, kBlock, 0, s, A, maps, tb, pending, ctl + kCtlPending - 1, flag, counters, thDepth, normalError); // roundCnt[1] == ctl[kCtlPending]
-	(void)hipcub::DeviceScan::ExclusiveSum(scanTemp, scanTempBytes, tb.cntT, tb.offT, (int)(tb.stride * (size_t)A.nNeighbors), s);
-	hipLaunchKernelGGL(fuse_fill_kernel, kGrid, kBlock, 0, s, A.nNeighbors, tb, pending, ctl + kCtlPending - 1);
 }
 // the image pass: which pending pixels become points (the settle iteration), their claims, then the points themselves.
 // settle: scratch of fuse_settle_bytes(pixels of A)
@@ -701,6 +686,7 @@ void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb,
 	FuseSettle S;
 	S.tb = tb; S.work[0] = (uint32_t*)settle; S.work[1] = S.work[0] + words; S.stamp = S.work[1] + words; S.acc = (uint8_t*)(S.stamp + words);
 	S.ctl = ctl; S.nNb = A.nNeighbors; S.nMinViewsFuse = nMinViewsFuse; S.order = order;
+	S.nA = (uint32_t)n;
 	(void)hipMemsetAsync(S.stamp, 0, n * 4, s);
 	(void)hipMemsetAsync(S.acc, 1, n, s);
 	for (int step = 0; step <= kSettleSteps; ++step) hipLaunchKernelGGL(fuse_settle_step_kernel, kGrid, kBlock, 0, s, S, pending, (uint32_t)step);

@@ -964,7 +964,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	const size_t tblElems = stride * (size_t)maxNb;
 	if (stride >= ((size_t)1 << 29)) return fail(c, HCMVS_ERR_CAPACITY, "fuse: maps of %zu pixels exceed the target tables (2^29 pixels)", stride);
 	if (tblElems > 0x7FFFFFFFull) return fail(c, HCMVS_ERR_CAPACITY, "fuse: %d neighbours of %zu pixels exceed the per-pass tables", maxNb, stride);
-	const size_t scanBytes = (std::max(fuse_scan_temp_bytes((int)maxArea), fuse_scan_temp_bytes((int)tblElems)) + 255) & ~(size_t)255;
+	const size_t scanBytes = (fuse_scan_temp_bytes((int)maxArea) + 255) & ~(size_t)255;
 	size_t off = 0;
 	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
 	// the device cloud (context scratch) ...
@@ -979,8 +979,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	// ... and the per-pass tables (sized for the largest image)
 	off = 0;
 	const size_t oPending = carve(maxArea * 4), oSettle = carve(fuse_settle_bytes(maxArea)), oTgt = carve(maxArea * 4 * (size_t)maxNb),
-	             oCntT = carve(tblElems * 4), oFillT = carve(tblElems * 4), oOffT = carve(tblElems * 4),
-	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(kCtlBytes), oCounters = carve(64), oStatus = carve(64), oTotals = carve(64),
+	             oHead = carve(tblElems * 4), oNext = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(kCtlBytes), oCounters = carve(64), oStatus = carve(64), oTotals = carve(64),
 	             oMerged = carve(maxArea * 4), oFlag = carve(maxArea), oFlag32 = carve(maxArea * 4), oPos = carve(maxArea * 4), oScan = carve(scanBytes),
 	             oXyz = carve(maxArea * 12), oNrm = carve(maxArea * 12), oBgr = carve(maxArea * 3), oNv = carve(maxArea * 4),
 	             oPV = carve(viewCapacity ? maxArea * 4 * (size_t)(maxNb + 1) : 0), oPW = carve(viewCapacity ? maxArea * 4 * (size_t)(maxNb + 1) : 0),
@@ -1006,13 +1005,13 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	uint32_t* status = (uint32_t*)(b + oStatus);
 	unsigned long long* totals = (unsigned long long*)(b + oTotals);
 	int32_t* targets = (int32_t*)(b + oTgt);
-	uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders);
+	uint32_t *head = (uint32_t*)(b + oHead), *next = (uint32_t*)(b + oNext);
 	uint8_t* flag = (uint8_t*)(b + oFlag);
 	uint32_t* flag32 = (uint32_t*)(b + oFlag32); uint32_t* pos = (uint32_t*)(b + oPos); uint32_t* merged = (uint32_t*)(b + oMerged);
 	float* pxyz = (float*)(b + oXyz); float* pnrm = (float*)(b + oNrm); uint8_t* pbgr = (uint8_t*)(b + oBgr); uint32_t* pnv = (uint32_t*)(b + oNv);
 	uint32_t* pviews = viewCapacity ? (uint32_t*)(b + oPV) : nullptr; float* pweights = viewCapacity ? (float*)(b + oPW) : nullptr;
 	uint32_t* voff = viewCapacity ? (uint32_t*)(b + oVoff) : nullptr;
-	const FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, stride);
+	const FuseTables tb = fuse_tables(targets, head, next, stride);
 	const auto tPasses = std::chrono::steady_clock::now();
 	HIPCHK(c, hipMemsetAsync(status, 0, 64, s));
 	HIPCHK(c, hipMemsetAsync(totals, 0, 64, s));
@@ -1022,9 +1021,8 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 		const auto tPass = std::chrono::steady_clock::now();
 		HIPCHK(c, hipMemsetAsync(counters, 0, 64, s));
 		HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
-		HIPCHK(c, hipMemsetAsync(cntT, 0, (size_t)A.nNeighbors * stride * 4, s));
-		HIPCHK(c, hipMemsetAsync(fillT, 0, (size_t)A.nNeighbors * stride * 4, s));
-		launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, thDepth, normalError, s);
+		HIPCHK(c, hipMemsetAsync(head, 0xFF, (size_t)A.nNeighbors * stride * 4, s)); // empty bidder lists
+		launch_fuse_begin(A, c->dMaps, tb, pendingList, ctl, flag, counters, thDepth, normalError, s);
 		launch_fuse_pass(A, c->dMaps, tb, pendingList, b + oSettle, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
 		                 merged, n_min_views_fuse, c->fuseOrder, counters, wantCloud, s);
 		launch_fuse_status(ctl, status, s);
@@ -1120,13 +1118,11 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 	for (int k = 0; k < n_ids; ++k) { View& v = c->views.find(ids[k])->second; maxIdArea = std::max(maxIdArea, (size_t)v.w * v.h); rc = ensure_gradient(c, v); if (rc) return rc; }
 	const size_t tblElems = stride * (size_t)maxNb;
 	if (stride >= ((size_t)1 << 29) || tblElems > 0x7FFFFFFFull) return fail(c, HCMVS_ERR_CAPACITY, "postfilter: %d neighbours of %zu pixels exceed the per-pass tables", maxNb, stride);
-	const size_t scanBytes = (std::max(fuse_scan_temp_bytes((int)maxArea), fuse_scan_temp_bytes((int)tblElems)) + 255) & ~(size_t)255;
 	size_t off = 0;
 	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
 	const size_t oPending = carve(maxArea * 4), oSettle = carve(fuse_settle_bytes(maxArea)), oTgt = carve(maxArea * 4 * (size_t)maxNb),
-	             oCntT = carve(tblElems * 4), oFillT = carve(tblElems * 4), oOffT = carve(tblElems * 4),
-	             oBidders = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(kCtlBytes), oCounters = carve(64), oStatus = carve(64), oMerged = carve(maxArea * 4),
-	             oFlag = carve(maxArea), oNv = carve(maxArea * 4), oScan = carve(scanBytes), oDF = carve(maxIdArea * 4), oNF = carve(maxIdArea * 12);
+	             oHead = carve(tblElems * 4), oNext = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(kCtlBytes), oCounters = carve(64), oStatus = carve(64),
+	             oMerged = carve(maxArea * 4), oFlag = carve(maxArea), oNv = carve(maxArea * 4), oDF = carve(maxIdArea * 4), oNF = carve(maxIdArea * 12);
 	if (c->capPass < off) {
 		if (c->passScratch) (void)hipFree(c->passScratch);
 		c->passScratch = nullptr; c->capPass = 0;
@@ -1138,12 +1134,12 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 	unsigned long long* counters = (unsigned long long*)(b + oCounters);
 	uint32_t* status = (uint32_t*)(b + oStatus);
 	int32_t* targets = (int32_t*)(b + oTgt);
-	uint32_t *cntT = (uint32_t*)(b + oCntT), *fillT = (uint32_t*)(b + oFillT), *offT = (uint32_t*)(b + oOffT), *bidders = (uint32_t*)(b + oBidders);
+	uint32_t *head = (uint32_t*)(b + oHead), *next = (uint32_t*)(b + oNext);
 	uint8_t* flag = (uint8_t*)(b + oFlag); uint32_t* merged = (uint32_t*)(b + oMerged); uint32_t* pnv = (uint32_t*)(b + oNv);
 	float* dF = (float*)(b + oDF); float* nF = (float*)(b + oNF);
 	const float normalError = cosf(normal_diff_deg * (3.14159274101257324f / 180.f)); // plain thresholds (SceneDensify.cpp:2083, 2177)
 	const float thDepth = depth_diff_threshold;
-	const FuseTables tb = fuse_tables(targets, cntT, offT, fillT, bidders, stride);
+	const FuseTables tb = fuse_tables(targets, head, next, stride);
 	hipStream_t s = c->stream;
 	HIPCHK(c, hipMemsetAsync(status, 0, 64, s));
 	HIPCHK(c, hipMemsetAsync(counters, 0, 64, s)); // counters[5]: pixels filled, summed over the sequence
@@ -1152,9 +1148,8 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 		for (int oi = 0; oi < n_order; ++oi) {
 			const DevMap& A = host[order[oi]];
 			HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
-			HIPCHK(c, hipMemsetAsync(cntT, 0, (size_t)A.nNeighbors * stride * 4, s)); // per-target counts of this image's neighbours
-			HIPCHK(c, hipMemsetAsync(fillT, 0, (size_t)A.nNeighbors * stride * 4, s));
-			launch_fuse_begin(A, c->dMaps, tb, b + oScan, scanBytes, pendingList, ctl, flag, counters, thDepth, normalError, s);
+			HIPCHK(c, hipMemsetAsync(head, 0xFF, (size_t)A.nNeighbors * stride * 4, s)); // empty bidder lists
+			launch_fuse_begin(A, c->dMaps, tb, pendingList, ctl, flag, counters, thDepth, normalError, s);
 			launch_fuse_pass(A, c->dMaps, tb, pendingList, b + oSettle, ctl, nullptr, nullptr, nullptr, pnv, flag, nullptr, nullptr, maxNb + 1, merged, n_min_views_fuse,
 			                 c->fuseOrder, counters, false, s);
 			launch_fuse_status(ctl, status, s);

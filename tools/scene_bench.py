@@ -60,12 +60,9 @@ print("scene: %d images %dx%d, %d sparse points, generated in %.1f s -> %s" % (N
 exe = os.path.join(ROOT, "hc-mvs_amd", "DensifyPointCloud")
 t1 = time.time()
 r = subprocess.run([exe, "-i", os.path.join(tmp, "scene.mvs"), "-o", os.path.join(tmp, "dense.mvs"), "--resolution-level", "0",
-                    "--number-views", "8", "--n-EstimationIters", str(SWEEPS), "--n-EstimationIters-external", "1", "--batch", "32", "-v", "3", "--fuse-order", os.environ.get("FUSE_ORDER", "1")],
-                   capture_output=True, text=True, env=dict(os.environ, HCMVS_FUSE_DEBUG='1'))
+                    "--number-views", "8", "--n-EstimationIters", str(SWEEPS), "--n-EstimationIters-external", "1", "--batch", os.environ.get("BATCH", "32"), "--resume", "0", "-v", "3", "--fuse-order", os.environ.get("FUSE_ORDER", "1")],
+                   capture_output=True, text=True)
 dt = time.time() - t1
-rounds = [int(l.split(':')[2].split('rounds')[0]) for l in r.stderr.split('\n') if l.startswith('fuse: image')]
-print('fuse rounds per image: min %d median %d max %d total %d' % (min(rounds), sorted(rounds)[len(rounds)//2], max(rounds), sum(rounds)) if rounds else 'no fuse debug')
-r.stderr = '\n'.join(l for l in r.stderr.split('\n') if not l.startswith('fuse: image'))
 lines = r.stdout.split('\n')
 batch_ms = sorted(set(l.split('batch ')[1] for l in lines if 'batch ' in l))
 print('\n'.join(l for l in lines if 'batch ' not in l and 'paired with' not in l)[-1500:]); print('batches:', batch_ms); print(r.stderr[-800:])
