@@ -175,16 +175,18 @@ __global__ void filter_vote_kernel(DevMap ref, const DevMap* nbs, int N, const u
 // fuse
 
 // target of pixel `point` in neighbour map m: returns false when it projects behind / outside (SceneDensify.cpp:3387-3393)
-__device__ __forceinline__ bool project_target(const DevMap& m, const float* point, float& ptz, int& ib, int& xB, int& yB) {
-	const double* p = m.P;
+__device__ __forceinline__ bool project_target(const double* p, int w, int h, const float* point, float& ptz, int& ib, int& xB, int& yB) {
 	const float ptx = (float)(p[0] * (double)point[0] + p[1] * (double)point[1] + p[2] * (double)point[2] + p[3]);
 	const float pty = (float)(p[4] * (double)point[0] + p[5] * (double)point[1] + p[6] * (double)point[2] + p[7]);
 	ptz = (float)(p[8] * (double)point[0] + p[9] * (double)point[1] + p[10] * (double)point[2] + p[11]);
 	if (ptz <= 0.f) return false;
 	xB = (int)floorf(ptx / ptz + .5f); yB = (int)floorf(pty / ptz + .5f);
-	if (xB < 0 || yB < 0 || xB >= m.w || yB >= m.h) return false;
-	ib = yB * m.w + xB;
+	if (xB < 0 || yB < 0 || xB >= w || yB >= h) return false;
+	ib = yB * w + xB;
 	return true;
+}
+__device__ __forceinline__ bool project_target(const DevMap& m, const float* point, float& ptz, int& ib, int& xB, int& yB) {
+	return project_target(m.P, m.w, m.h, point, ptz, ib, xB, yB);
 }
 __device__ __forceinline__ void pixel_point(const DevMap& A, int idx, float depth, float* point) {
 	double Xw[3];
@@ -223,10 +225,11 @@ constexpr int kTargetShift = 29;
 constexpr int32_t kTargetIndexMask = (1 << kTargetShift) - 1;
 constexpr int kTargetMerge = 1, kTargetInFront = 2;
 
-__device__ __forceinline__ void rotate_normal(const DevMap& M, const float* nm, float* out) { // camera -> world, SceneDensify.cpp:3384
+__device__ __forceinline__ void rotate_normal(const double* R, const float* nm, float* out) { // camera -> world, SceneDensify.cpp:3384
 #pragma unroll
-	for (int k = 0; k < 3; ++k) out[k] = (float)(M.R[0 * 3 + k] * (double)nm[0] + M.R[1 * 3 + k] * (double)nm[1] + M.R[2 * 3 + k] * (double)nm[2]);
+	for (int k = 0; k < 3; ++k) out[k] = (float)(R[0 * 3 + k] * (double)nm[0] + R[1 * 3 + k] * (double)nm[1] + R[2 * 3 + k] * (double)nm[2]);
 }
+__device__ __forceinline__ void rotate_normal(const DevMap& M, const float* nm, float* out) { rotate_normal(M.R, nm, out); }
 
 // pending pixels of A (valid depth, not yet claimed by an earlier image) -> first candidate list, their targets and the
 // per-target counts.  Everything about a (pixel, target) pair that does not depend on the order of the pass is settled
@@ -236,6 +239,18 @@ __device__ __forceinline__ void rotate_normal(const DevMap& M, const float* nm, 
 __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, uint32_t* pending, uint32_t* roundCnt, uint8_t* flag,
                                   unsigned long long* counters, float thDepth, float normalError) {
 	const int n = A.w * A.h;
+	// the neighbours' cameras and map pointers, once per workgroup (every thread needs all of them for every pixel)
+	__shared__ double sP[kFuseMaxViews - 1][12], sR[kFuseMaxViews - 1][9];
+	__shared__ const float* sDepth[kFuseMaxViews - 1];
+	__shared__ const float* sNormal[kFuseMaxViews - 1];
+	__shared__ int sW[kFuseMaxViews - 1], sH[kFuseMaxViews - 1];
+	for (int i = threadIdx.x; i < A.nNeighbors * 12; i += blockDim.x) sP[i / 12][i % 12] = maps[A.neighbors[i / 12]].P[i % 12];
+	for (int i = threadIdx.x; i < A.nNeighbors * 9; i += blockDim.x) sR[i / 9][i % 9] = maps[A.neighbors[i / 9]].R[i % 9];
+	for (int i = threadIdx.x; i < A.nNeighbors; i += blockDim.x) {
+		const DevMap& B = maps[A.neighbors[i]];
+		sDepth[i] = B.depth; sNormal[i] = B.normal; sW[i] = B.w; sH[i] = B.h;
+	}
+	__syncthreads();
 	unsigned nd = 0;
 	const int nPad = (n + 63) & ~63; // whole waves take part in list_append
 	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nPad; idx += gridDim.x * blockDim.x) {
@@ -252,16 +267,15 @@ __global__ void fuse_begin_kernel(DevMap A, const DevMap* maps, FuseTables tb, u
 			pixel_point(A, idx, A.depth[idx], point);
 			if (A.normal) rotate_normal(A, A.normal + 3 * (size_t)idx, normal);
 			for (int q = 0; q < A.nNeighbors; ++q) {
-				const DevMap& B = maps[A.neighbors[q]];
 				float ptz; int ib = -1, xB, yB;
 				int32_t t = -1;
-				if (B.depth && project_target(B, point, ptz, ib, xB, yB)) {
-					const float depthB = B.depth[ib];
+				if (sDepth[q] && project_target(sP[q], sW[q], sH[q], point, ptz, ib, xB, yB)) {
+					const float depthB = sDepth[q][ib];
 					if (depthB > 0.f) { // valid and free
 						int cls = 0;
 						if (is_depth_similar(ptz, depthB, thDepth)) {
 							float normalB[3] = {0.f, 0.f, -1.f};
-							if (B.normal) rotate_normal(B, B.normal + 3 * (size_t)ib, normalB);
+							if (sNormal[q]) rotate_normal(sR[q], sNormal[q] + 3 * (size_t)ib, normalB);
 							if (normal[0] * normalB[0] + normal[1] * normalB[1] + normal[2] * normalB[2] > normalError) cls = kTargetMerge;
 						}
 						if (!cls && ptz < depthB) cls = kTargetInFront;
