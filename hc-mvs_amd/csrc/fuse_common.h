@@ -56,8 +56,9 @@ size_t fuse_settle_bytes(size_t pixels); // scratch of launch_fuse_pass for an i
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, void* settle, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
                       uint32_t* merged, int nMinViewsFuse, int order, unsigned long long* counters, bool wantPoints, hipStream_t s);
-void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const DevMap* maps, int nMaps, const uint8_t* gra, float* dF, float* nF,
-                       int gap, float thr, unsigned long long* filled, hipStream_t s);
+// dF, dF2: w*h floats each, nF: 3*w*h floats of scratch
+void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const DevMap* maps, int nMaps, const uint8_t* gra, float* dF, float* dF2,
+                       float* nF, int gap, float thr, unsigned long long* filled, hipStream_t s);
 void launch_point_colors(unsigned long long n, const float* xyz, const unsigned long long* voff, const uint32_t* views, const DevMap* maps, uint8_t* bgr, hipStream_t s);
 size_t fuse_scan_temp_bytes(int n);
 // bases: device words [0] points, [1] view entries written by the images before this one (null: base / viewBase)

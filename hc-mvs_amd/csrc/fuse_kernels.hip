@@ -575,8 +575,8 @@ __global__ void point_colors_kernel(unsigned long long n, const float* xyz, cons
 // RemoveSmallSegments as the fork rewrote it (SceneDensify.cpp:2048-2275) = a complete fusion pass, after which depthMap_fuse /
 // normalMap_fuse are the image's maps restricted to the pixels that ended up in a fused point (postfilter_mask_kernel, from
 // the claim map the fuse pass leaves); GapInterpolation (SceneDensify.cpp:2280-3001): gaps along rows, then along columns
-// (gap_lines_kernel, one thread per line -- a line is filled left to right with a running counter, so it is sequential, while
-// the lines of a pass are independent), then the merge (SceneDensify.cpp:2989-3000).  The third, per-pixel pass of the
+// (gap_lines_kernel: the reference walks a line left to right with a running counter; the gaps of a line turn out to be
+// independent of each other, so every gap is found and filled by a thread of its own), then the merge (SceneDensify.cpp:2989-3000).  The third, per-pixel pass of the
 // reference (SceneDensify.cpp:2717-2983) reads uninitialised variables and is not reproduced.
 
 // runs BEFORE the claim marks come off: a negative depth = the pixel ended up in a fused point
@@ -587,52 +587,57 @@ __global__ void postfilter_mask_kernel(int n, const float* depth, const float* n
 		for (int k = 0; k < 3; ++k) nF[3 * i + k] = on ? normal[3 * i + k] : 0.f;
 	}
 }
-__global__ void gap_lines_kernel(float* dF, float* nF, float* conf, const uint8_t* gra, int nLines, int len, size_t lineStride, size_t stride, int gap,
-                                 float thr, unsigned long long* filledOut) {
-	const int line = blockIdx.x * blockDim.x + threadIdx.x;
-	if (line >= nLines) return;
-	const size_t base = (size_t)line * lineStride;
-	unsigned count = 0;
+// One thread per PIXEL: the thread of a valid pixel that ends a run of empty ones measures the run and, when the rule says so,
+// fills it (left to right, with the running sums of the reference).  Gaps do not interact: the two ends of a gap are pixels that were
+// valid before the pass, and a pass only writes pixels that were empty, so every gap sees exactly what the sequential scan of its line
+// would have seen.  To keep it so while other threads are filling their gaps, the depths are READ from dIn, which nobody writes during
+// the pass, and WRITTEN to dOut (a copy of dIn when the pass begins); normals and confidences are only read at the ends of a gap,
+// which are never written.
+__global__ void gap_lines_kernel(const float* dIn, float* dOut, float* nF, float* conf, const uint8_t* gra, int nLines, int len, size_t lineStride,
+                                 size_t stride, int gap, float thr, unsigned long long* filledOut) {
+	const size_t total = (size_t)nLines * len;
 	unsigned long long filled = 0;
-	for (int u = 0; u < len; ++u) {
+	for (size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (size_t)gridDim.x * blockDim.x) {
+		// neighbouring threads touch neighbouring addresses in either direction of the pass
+		const int line = stride == 1 ? (int)(tid / len) : (int)(tid % nLines);
+		const int u = stride == 1 ? (int)(tid % len) : (int)(tid / nLines);
+		const size_t base = (size_t)line * lineStride;
 		const size_t iu = base + (size_t)u * stride;
-		const float depth = dF[iu];
-		if (depth <= 0.f) { ++count; continue; }
-		if (count == 0) continue;
-		if ((unsigned)u > count) {
-			const size_t i0 = base + (size_t)(u - (int)count - 1) * stride;
-			const float depthFirst = dF[i0];
-			bool fill;
-			if (count <= (unsigned)gap) fill = is_depth_similar(depthFirst, depth, thr);
-			else {
-				const float t0 = (float)gra[i0], t1 = (float)gra[iu];
-				const float ratio = (t1 - t0) / t0;
-				// the reference compares the float against the DOUBLE literal 0.1 (SceneDensify.cpp:2390 rows, :2720 columns): a ratio that
-				// rounds to 0.1f -- gradient pairs (10, 11), (20, 22) ... -- is above it and does not fill
-				fill = (double)ratio <= 0.1 || is_depth_similar(depthFirst, depth, thr);
-			}
-			if (fill) {
-				const float cnt1 = (float)(count + 1);
-				const float diff = (depth - depthFirst) / cnt1;
-				float d = depthFirst;
-				const float c = conf[i0] < conf[iu] ? conf[i0] : conf[iu];
-				float p0 = pm_atan2f(nF[3 * i0 + 1], nF[3 * i0]), p1 = pm_acosf(nF[3 * i0 + 2]);               // Normal2Dir, Util.inl:614-618
-				const float q0 = pm_atan2f(nF[3 * iu + 1], nF[3 * iu]), q1 = pm_acosf(nF[3 * iu + 2]);
-				const float dd0 = (q0 - p0) / cnt1, dd1 = (q1 - p1) / cnt1;
-				for (int uc = u - (int)count; uc < u; ++uc) {
-					const size_t ic = base + (size_t)uc * stride;
-					d += diff;
-					dF[ic] = d;
-					p0 += dd0; p1 += dd1;
-					float s0, c0, s1, c1;
-					pm_sincosf(p0, &s0, &c0); pm_sincosf(p1, &s1, &c1);                                       // Dir2Normal, Util.inl:620-625
-					nF[3 * ic] = c0 * s1; nF[3 * ic + 1] = s0 * s1; nF[3 * ic + 2] = c1;
-					conf[ic] = c;
-					++filled;
-				}
-			}
+		const float depth = dIn[iu];
+		if (!(depth > 0.f) || u == 0 || dIn[iu - stride] > 0.f) continue; // not the end of a run of empty pixels
+		int count = 1;
+		while (count < u && !(dIn[iu - (size_t)(count + 1) * stride] > 0.f)) ++count;
+		if (count >= u) continue; // the run begins at the start of the line: nothing to interpolate from
+		const size_t i0 = iu - (size_t)(count + 1) * stride;
+		const float depthFirst = dIn[i0];
+		bool fill;
+		if (count <= gap) fill = is_depth_similar(depthFirst, depth, thr);
+		else {
+			const float t0 = (float)gra[i0], t1 = (float)gra[iu];
+			const float ratio = (t1 - t0) / t0;
+			// the reference compares the float against the DOUBLE literal 0.1 (SceneDensify.cpp:2390 rows, :2720 columns): a ratio that
+			// rounds to 0.1f -- gradient pairs (10, 11), (20, 22) ... -- is above it and does not fill
+			fill = (double)ratio <= 0.1 || is_depth_similar(depthFirst, depth, thr);
 		}
-		count = 0;
+		if (!fill) continue;
+		const float cnt1 = (float)(count + 1);
+		const float diff = (depth - depthFirst) / cnt1;
+		float d = depthFirst;
+		const float c = conf[i0] < conf[iu] ? conf[i0] : conf[iu];
+		float p0 = pm_atan2f(nF[3 * i0 + 1], nF[3 * i0]), p1 = pm_acosf(nF[3 * i0 + 2]);               // Normal2Dir, Util.inl:614-618
+		const float q0 = pm_atan2f(nF[3 * iu + 1], nF[3 * iu]), q1 = pm_acosf(nF[3 * iu + 2]);
+		const float dd0 = (q0 - p0) / cnt1, dd1 = (q1 - p1) / cnt1;
+		for (int k = 1; k <= count; ++k) {
+			const size_t ic = i0 + (size_t)k * stride;
+			d += diff;
+			dOut[ic] = d;
+			p0 += dd0; p1 += dd1;
+			float s0, c0, s1, c1;
+			pm_sincosf(p0, &s0, &c0); pm_sincosf(p1, &s1, &c1);                                       // Dir2Normal, Util.inl:620-625
+			nF[3 * ic] = c0 * s1; nF[3 * ic + 1] = s0 * s1; nF[3 * ic + 2] = c1;
+			conf[ic] = c;
+			++filled;
+		}
 	}
 	if (filled) atomicAdd(filledOut, filled);
 }
@@ -644,13 +649,15 @@ __global__ void postfilter_merge_kernel(int n, float* depth, float* normal, cons
 	}
 }
 // the image's own maps still carry the claim marks of the fusion that has just run; `maps` = all maps, unmarked after the mask is taken
-void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const DevMap* maps, int nMaps, const uint8_t* gra, float* dF, float* nF,
-                       int gap, float thr, unsigned long long* filled, hipStream_t s) {
+void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const DevMap* maps, int nMaps, const uint8_t* gra, float* dF, float* dF2,
+                       float* nF, int gap, float thr, unsigned long long* filled, hipStream_t s) {
 	const int n = w * h;
 	hipLaunchKernelGGL(postfilter_mask_kernel, kGrid, kBlock, 0, s, n, depth, normal, dF, nF);
 	launch_unclaim(maps, nMaps, s);
-	hipLaunchKernelGGL(gap_lines_kernel, dim3((h + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, h, w, (size_t)w, (size_t)1, gap, thr, filled);   // rows
-	hipLaunchKernelGGL(gap_lines_kernel, dim3((w + 63) / 64), dim3(64), 0, s, dF, nF, conf, gra, w, h, (size_t)1, (size_t)w, gap, thr, filled);   // columns
+	(void)hipMemcpyAsync(dF2, dF, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
+	hipLaunchKernelGGL(gap_lines_kernel, kGrid, kBlock, 0, s, dF, dF2, nF, conf, gra, h, w, (size_t)w, (size_t)1, gap, thr, filled);   // rows
+	(void)hipMemcpyAsync(dF, dF2, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
+	hipLaunchKernelGGL(gap_lines_kernel, kGrid, kBlock, 0, s, dF2, dF, nF, conf, gra, w, h, (size_t)1, (size_t)w, gap, thr, filled);   // columns
 	hipLaunchKernelGGL(postfilter_merge_kernel, kGrid, kBlock, 0, s, n, depth, normal, dF, nF);
 }
 void launch_unclaim(const DevMap* maps, int nMaps, hipStream_t s) {

@@ -1122,7 +1122,7 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
 	const size_t oPending = carve(maxArea * 4), oSettle = carve(fuse_settle_bytes(maxArea)), oTgt = carve(maxArea * 4 * (size_t)maxNb),
 	             oHead = carve(tblElems * 4), oNext = carve(maxArea * 4 * (size_t)maxNb), oCtl = carve(kCtlBytes), oCounters = carve(64), oStatus = carve(64),
-	             oMerged = carve(maxArea * 4), oFlag = carve(maxArea), oNv = carve(maxArea * 4), oDF = carve(maxIdArea * 4), oNF = carve(maxIdArea * 12);
+	             oMerged = carve(maxArea * 4), oFlag = carve(maxArea), oNv = carve(maxArea * 4), oDF = carve(maxIdArea * 4), oDF2 = carve(maxIdArea * 4), oNF = carve(maxIdArea * 12);
 	if (c->capPass < off) {
 		if (c->passScratch) (void)hipFree(c->passScratch);
 		c->passScratch = nullptr; c->capPass = 0;
@@ -1136,7 +1136,7 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 	int32_t* targets = (int32_t*)(b + oTgt);
 	uint32_t *head = (uint32_t*)(b + oHead), *next = (uint32_t*)(b + oNext);
 	uint8_t* flag = (uint8_t*)(b + oFlag); uint32_t* merged = (uint32_t*)(b + oMerged); uint32_t* pnv = (uint32_t*)(b + oNv);
-	float* dF = (float*)(b + oDF); float* nF = (float*)(b + oNF);
+	float* dF = (float*)(b + oDF); float* dF2 = (float*)(b + oDF2); float* nF = (float*)(b + oNF);
 	const float normalError = cosf(normal_diff_deg * (3.14159274101257324f / 180.f)); // plain thresholds (SceneDensify.cpp:2083, 2177)
 	const float thDepth = depth_diff_threshold;
 	const FuseTables tb = fuse_tables(targets, head, next, stride);
@@ -1154,7 +1154,7 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 			                 c->fuseOrder, counters, false, s);
 			launch_fuse_status(ctl, status, s);
 		}
-		launch_postfilter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, c->dMaps, (int)host.size(), v.gra, dF, nF, gap_size, depth_diff_threshold * 2.5f, counters + 5, s);
+		launch_postfilter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, c->dMaps, (int)host.size(), v.gra, dF, dF2, nF, gap_size, depth_diff_threshold * 2.5f, counters + 5, s);
 	}
 	HIPCHK(c, hipGetLastError());
 	uint32_t st[4] = {0, 0, 0, 0};
