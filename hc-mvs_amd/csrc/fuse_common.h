@@ -43,19 +43,18 @@ struct FuseTables {
 FuseTables fuse_tables(int32_t* targets, uint32_t* head, uint32_t* next, size_t stride);
 // ctl: kCtlBytes, zero before the pass: [kCtlPending] pending pixels, [kCtlErr] the settle iteration gave up (never expected),
 // [kCtlSteps] steps it took, [kCtlWork + s] length of the work list step s wrote (diagnostics)
-constexpr int kSettleSteps = 3; // full-grid steps of the settle iteration after step 0; a single workgroup finishes what they leave
+constexpr int kSettleSteps = 1; // full-grid steps of the settle iteration after step 0; a single workgroup finishes what they leave
 constexpr int kCtlPending = 4, kCtlSteps = 6, kCtlWork = 16, kCtlErr = 32; // word indices
 constexpr size_t kCtlBytes = 256;
 void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb, uint32_t* pending, uint32_t* ctl, uint8_t* flag,
                        unsigned long long* counters, float thDepth, float normalError, hipStream_t s);
 // status words of a fusion enqueued without host synchronisation: [0] a pass gave up (never expected), [3] = 1 / 2: the cloud / the view
 // lists overflowed their capacity
-void launch_fuse_status(const uint32_t* ctl, uint32_t* status, hipStream_t s);
 void launch_unclaim(const DevMap* maps, int nMaps, hipStream_t s); // takes the claim marks (negative depths) off every map
 size_t fuse_settle_bytes(size_t pixels); // scratch of launch_fuse_pass for an image of that many pixels
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, void* settle, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
-                      uint32_t* merged, int nMinViewsFuse, int order, unsigned long long* counters, bool wantPoints, hipStream_t s);
+                      uint32_t* merged, int nMinViewsFuse, int order, unsigned long long* counters, uint32_t* status, bool wantPoints, hipStream_t s);
 // dF, dF2: w*h floats each, nF: 3*w*h floats of scratch
 void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, const DevMap* maps, int nMaps, const uint8_t* gra, float* dF, float* dF2,
                        float* nF, int gap, float thr, unsigned long long* filled, hipStream_t s);

@@ -300,11 +300,6 @@ struct FuseOut { // per pixel of the current image, compacted in raster order af
 	float* xyz; float* normal; uint8_t* bgr; uint32_t* nviews; uint8_t* flag;
 	uint32_t* views; float* weights; int vstride; // optional: the point's view list (image ids ascending) and weights, vstride per pixel
 };
-// status words of a fusion enqueued without host synchronisation: [0] the settle iteration of a pass gave up (never expected)
-__global__ void fuse_status_kernel(const uint32_t* ctl, uint32_t* status) {
-	if (blockIdx.x != 0 || threadIdx.x != 0) return;
-	if (ctl[kCtlErr] != 0u) status[0] = 1u;
-}
 // after an image's compaction: the image's counts (counters[0] depths, [3] points, [4] view entries) join the running totals the
 // next image's compaction starts from; status[3] says that the cloud (1) or the view lists (2) do not fit
 __global__ void fuse_advance_kernel(const unsigned long long* counters, unsigned long long* totals, unsigned long long capacity,
@@ -391,12 +386,12 @@ __global__ void fuse_settle_step_kernel(FuseSettle S, const uint32_t* pending, u
 }
 // whatever the kSettleSteps launches left: one workgroup goes on until the list is empty (no host in the loop, no bound on the
 // number of steps other than the safety limit)
-__global__ __launch_bounds__(1024) void fuse_settle_rest_kernel(FuseSettle S) {
+__global__ __launch_bounds__(1024) void fuse_settle_rest_kernel(FuseSettle S, uint32_t* status) {
 	__shared__ uint32_t nNext;
 	uint32_t n = S.ctl[kCtlWork + kSettleSteps];
 	uint32_t step = (uint32_t)kSettleSteps + 1u;
 	for (; n != 0u; ++step) {
-		if (step > (1u << 20)) { if (threadIdx.x == 0) S.ctl[kCtlErr] = 1u; break; } // never expected: bounded all the same
+		if (step > (1u << 20)) { if (threadIdx.x == 0) { S.ctl[kCtlErr] = 1u; status[0] = 1u; } break; } // never expected: bounded all the same
 		if (threadIdx.x == 0) nNext = 0u;
 		__syncthreads();
 		const uint32_t* list = S.work[(step - 1u) & 1u];
@@ -663,9 +658,6 @@ void launch_postfilter(int w, int h, float* depth, float* normal, float* conf, c
 void launch_unclaim(const DevMap* maps, int nMaps, hipStream_t s) {
 	hipLaunchKernelGGL(unclaim_kernel, dim3(256, nMaps < 1024 ? (nMaps > 0 ? nMaps : 1) : 1024), dim3(256), 0, s, maps, nMaps);
 }
-void launch_fuse_status(const uint32_t* ctl, uint32_t* status, hipStream_t s) {
-	hipLaunchKernelGGL(fuse_status_kernel, dim3(1), dim3(64), 0, s, ctl, status);
-}
 
 void launch_point_colors(unsigned long long n, const float* xyz, const unsigned long long* voff, const uint32_t* views, const DevMap* maps, uint8_t* bgr, hipStream_t s) {
 	hipLaunchKernelGGL(point_colors_kernel, dim3(2048), dim3(256), 0, s, n, xyz, voff, views, maps, bgr);
@@ -701,7 +693,7 @@ void launch_fuse_begin(const DevMap& A, const DevMap* maps, const FuseTables& tb
 size_t fuse_settle_bytes(size_t pixels) { return ((pixels * 4 + 255) & ~(size_t)255) * 3 + pixels; }
 void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb, const uint32_t* pending, void* settle, uint32_t* ctl,
                       float* oxyz, float* onormal, uint8_t* obgr, uint32_t* onv, uint8_t* oflag, uint32_t* oviews, float* oweights, int vstride,
-                      uint32_t* merged, int nMinViewsFuse, int order, unsigned long long* counters, bool wantPoints, hipStream_t s) {
+                      uint32_t* merged, int nMinViewsFuse, int order, unsigned long long* counters, uint32_t* status, bool wantPoints, hipStream_t s) {
 	FuseOut out{oxyz, onormal, obgr, onv, oflag, oviews, oweights, vstride};
 	const size_t n = (size_t)A.w * A.h, words = ((n * 4 + 255) & ~(size_t)255) / 4;
 	FuseSettle S;
@@ -711,7 +703,7 @@ void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb,
 	(void)hipMemsetAsync(S.stamp, 0, n * 4, s);
 	(void)hipMemsetAsync(S.acc, 1, n, s);
 	for (int step = 0; step <= kSettleSteps; ++step) hipLaunchKernelGGL(fuse_settle_step_kernel, kGrid, kBlock, 0, s, S, pending, (uint32_t)step);
-	hipLaunchKernelGGL(fuse_settle_rest_kernel, dim3(1), dim3(1024), 0, s, S);
+	hipLaunchKernelGGL(fuse_settle_rest_kernel, dim3(1), dim3(1024), 0, s, S, status);
 	hipLaunchKernelGGL(fuse_settle_apply_kernel, kGrid, kBlock, 0, s, A, maps, S, pending, merged, out, counters);
 	if (!wantPoints) return;
 	if (A.nNeighbors < 16) hipLaunchKernelGGL(fuse_points_kernel<16>, kGrid, kBlock, 0, s, A, maps, tb, merged, out, pending, ctl + kCtlPending - 1);

@@ -1024,8 +1024,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 		HIPCHK(c, hipMemsetAsync(head, 0xFF, (size_t)A.nNeighbors * stride * 4, s)); // empty bidder lists
 		launch_fuse_begin(A, c->dMaps, tb, pendingList, ctl, flag, counters, thDepth, normalError, s);
 		launch_fuse_pass(A, c->dMaps, tb, pendingList, b + oSettle, ctl, pxyz, cN ? pnrm : nullptr, cB ? pbgr : nullptr, pnv, flag, pviews, pweights, vstride,
-		                 merged, n_min_views_fuse, c->fuseOrder, counters, wantCloud, s);
-		launch_fuse_status(ctl, status, s);
+		                 merged, n_min_views_fuse, c->fuseOrder, counters, status, wantCloud, s);
 		if (wantCloud)
 			launch_fuse_compact(n, flag, flag32, pos, b + oScan, scanBytes, pxyz, pnrm, pbgr, pnv, 0, capacity, cX, cN, cB, cV, pviews, pweights, vstride,
 			                    voff, 0, viewCapacity, cVI, cVW, totals, s);
@@ -1151,8 +1150,7 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 			HIPCHK(c, hipMemsetAsync(head, 0xFF, (size_t)A.nNeighbors * stride * 4, s)); // empty bidder lists
 			launch_fuse_begin(A, c->dMaps, tb, pendingList, ctl, flag, counters, thDepth, normalError, s);
 			launch_fuse_pass(A, c->dMaps, tb, pendingList, b + oSettle, ctl, nullptr, nullptr, nullptr, pnv, flag, nullptr, nullptr, maxNb + 1, merged, n_min_views_fuse,
-			                 c->fuseOrder, counters, false, s);
-			launch_fuse_status(ctl, status, s);
+			                 c->fuseOrder, counters, status, false, s);
 		}
 		launch_postfilter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, c->dMaps, (int)host.size(), v.gra, dF, dF2, nF, gap_size, depth_diff_threshold * 2.5f, counters + 5, s);
 	}
