@@ -1,5 +1,5 @@
 """diagnostic (not a test): batched sweep time of the bench workload (B x 1080p, 8 views, 7x7) under different tuning knobs
-and diagnostic builds, one process:  python tools/sweep_knobs.py B SWEEPS "lib:lag[:affinity[:nw[:band]]]" ...
+and diagnostic builds, one process:  python tools/sweep_knobs.py B SWEEPS "lib:lag[:affinity[:nw]]" ...
   lib = '' (the product library) | occ4 | occ2 | ... (libhcmvs_hip_<lib>.so)"""
 import ctypes as C, importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +24,6 @@ for cfg in configs:
     os.environ["HCMVS_XCD_AFFINITY"] = parts[2] if len(parts) > 2 and parts[2] else "1"
     if len(parts) > 3 and parts[3]: os.environ["HCMVS_WAVES_PER_ROW"] = parts[3]
     else: os.environ.pop("HCMVS_WAVES_PER_ROW", None)
-    os.environ["HCMVS_BAND"] = parts[4] if len(parts) > 4 and parts[4] else "0"
     binding._lib = None
     binding.LIB_PATH = base.replace("libhcmvs_hip.so", "libhcmvs_hip_%s.so" % libname) if libname else base
     ctx = binding.Context(0)
