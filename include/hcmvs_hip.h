@@ -200,11 +200,11 @@ int hcmvs_filter(hcmvs_ctx* ctx, uint32_t ref_id, const uint32_t* neighbor_ids, 
                  float* out_conf, uint64_t* n_processed, uint64_t* n_discarded);
 
 /* Order in which the pixels of ONE image are visited by hcmvs_fuse (the image order is always the caller's).
- * 0 (default): raster order, the reference's (SceneDensify.cpp:3355-3358); the cloud equals the sequential one bit for
- *    bit, but neighbouring pixels that share target pixels form dependence chains thousands of rounds long.
+ * 0 (default): raster order, the reference's (SceneDensify.cpp:3355-3358); the cloud equals the sequential one bit for bit.
  * 1: a fixed pseudo-random order (a bijective hash of the raster index): the same greedy rule visits the pixels in
- *    another order, the chains are O(log n) rounds, and the cloud differs from the reference's within the tolerance
- *    the north star states (point count within 1 %); the output is still written in raster order and deterministic. */
+ *    another order, and the cloud differs from the reference's within the tolerance the north star states (point count
+ *    within 1 %); the output is still written in raster order and deterministic.  (The option dates from the rounds in
+ *    which the order decided how long the fusion took; it no longer does.) */
 int hcmvs_set_fuse_order(hcmvs_ctx* ctx, int32_t mode);
 
 /* void DepthMapsData::FuseDepthMaps(PointCloud&, bool, bool) (SceneDensify.cpp:3265-3495).  order: image ids,
