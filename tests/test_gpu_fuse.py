@@ -311,3 +311,22 @@ def test_fuse_alternating_chain_through_the_settle_loop(ctx):
     assert np.array_equal(got["xyz"], want["xyz"]) and np.array_equal(got["n_views"], want["n_views"])
     for i, d in enumerate(want["depths"]):
         assert np.array_equal(ctx.get_depthmap(i)[0], d)
+
+
+@pytest.mark.parametrize("kw,fk", [
+    (dict(w=640, h=480, f=600.0, n_views=9, noise=0.008, outliers=0.15, holes=0.05, seed=12), dict(n_min_views_fuse=3)),
+    (dict(w=512, h=384, f=480.0, n_views=12, noise=0.003, outliers=0.05, holes=0.3, seed=13, far=2, far_factor=2.2), dict(depthweight=2.0, normalweight=1.5))])
+def test_fuse_bit_exact_large_dirty_maps(ctx, kw, fk):
+    """bigger and dirtier than the scenes above (15 % outliers, 30 % holes, a coarse neighbour, 11 neighbours per image; nMinViewsFuse 3;
+    the depth / normal weights of FuseDepthMaps): many pixels do NOT become points here, so the settle iteration starts far from its
+    fixed point.  Cloud, point order and invalidated depths equal the sequential oracle's."""
+    maps, order = make_maps(**kw)
+    upload(ctx, maps)
+    cap = kw["w"] * kw["h"] * kw["n_views"]
+    want = O.fuse_depthmaps(maps, order, cap, **fk)
+    got = ctx.fuse(order, cap, **fk)
+    assert got["n_points"] == want["n_points"] > 100000 and got["n_depths"] == want["n_depths"]
+    assert np.array_equal(got["xyz"], want["xyz"]) and np.array_equal(got["n_views"], want["n_views"])
+    assert np.array_equal(got["normal"], want["normal"]) and np.array_equal(got["bgr"], want["bgr"])
+    for i, d in enumerate(want["depths"]):
+        assert np.array_equal(ctx.get_depthmap(i)[0], d)
