@@ -599,9 +599,10 @@ __global__ void gap_lines_kernel(const float* dIn, float* dOut, float* nF, float
 		const size_t base = (size_t)line * lineStride;
 		const size_t iu = base + (size_t)u * stride;
 		const float depth = dIn[iu];
-		if (!(depth > 0.f) || u == 0 || dIn[iu - stride] > 0.f) continue; // not the end of a run of empty pixels
+		// "empty" is `depth <= 0` as in the reference's scan (SceneDensify.cpp:2305 rows, :2636 columns)
+		if (depth <= 0.f || u == 0 || !(dIn[iu - stride] <= 0.f)) continue; // not the end of a run of empty pixels
 		int count = 1;
-		while (count < u && !(dIn[iu - (size_t)(count + 1) * stride] > 0.f)) ++count;
+		while (count < u && dIn[iu - (size_t)(count + 1) * stride] <= 0.f) ++count;
 		if (count >= u) continue; // the run begins at the start of the line: nothing to interpolate from
 		const size_t i0 = iu - (size_t)(count + 1) * stride;
 		const float depthFirst = dIn[i0];
