@@ -163,6 +163,17 @@ int hcor_filter_depthmap(const hcor_depthmap* maps, uint32_t ref_id, const uint3
 
 /* ------------------------------------------------------------------------------------------------ */
 
+/* order in which the pixels of an image are visited: 0 = raster order (the reference's, SD.cpp:3355-3358), 1 = the C-ABI's
+ * hcmvs_set_fuse_order(ctx, 1): ascending idx * 0x9E3779B1 (mod 2^32), a bijection of the raster index.  Test infrastructure for that
+ * option; the points then come out in visiting order, not in raster order as the device writes them. */
+static int g_fuse_pixel_order = 0;
+void hcor_set_fuse_pixel_order(int mode) { g_fuse_pixel_order = mode; }
+static const uint32_t* g_sort_key;
+static int cmp_by_key(const void* a, const void* b) {
+	const uint32_t ka = g_sort_key[*(const uint32_t*)a], kb = g_sort_key[*(const uint32_t*)b];
+	return ka < kb ? -1 : (ka > kb ? 1 : 0);
+}
+
 int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, int n_order, int nMinViewsFuse,
                         float fDepthDiffThreshold, float fNormalDiffDeg, float depthweight, float normalweight,
                         hcor_cloud* cloud) {
@@ -190,9 +201,20 @@ int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, 
 		const uint32_t A = order[oi];
 		hcor_depthmap* dA = &maps[A];
 		const int W = dA->width, H = dA->height;
-		for (int i = 0; i < H && !rc; ++i)
-			for (int j = 0; j < W; ++j) {
-				const size_t idx = (size_t)i * W + j;
+		const size_t areaA = (size_t)W * H;
+		uint32_t* perm = NULL;
+		if (g_fuse_pixel_order == 1) { /* not thread-safe (file-static key): the tests call it from one thread */
+			perm = (uint32_t*)malloc(areaA * sizeof(uint32_t));
+			uint32_t* key = (uint32_t*)malloc(areaA * sizeof(uint32_t));
+			for (size_t k = 0; k < areaA; ++k) { perm[k] = (uint32_t)k; key[k] = (uint32_t)k * 0x9E3779B1u; }
+			g_sort_key = key;
+			qsort(perm, areaA, sizeof(uint32_t), cmp_by_key);
+			free(key);
+		}
+		for (size_t kk = 0; kk < areaA && !rc; ++kk) {
+			{
+				const size_t idx = perm ? perm[kk] : kk;
+				const int i = (int)(idx / (size_t)W), j = (int)(idx % (size_t)W);
 				const float depth = dA->depth[idx];
 				if (depth == 0) continue;
 				++cloud->n_depths;
@@ -285,6 +307,8 @@ int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, 
 					for (int v = 0; v < ninv; ++v) *invalid[v] = 0; /* SD.cpp:3447-3449 */
 				}
 			}
+		}
+		free(perm);
 	}
 	if (cloud->claim_mask && (int)cloud->claim_image < n_maps && claim[cloud->claim_image]) {
 		const size_t area = (size_t)maps[cloud->claim_image].width * maps[cloud->claim_image].height;

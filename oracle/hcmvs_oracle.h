@@ -205,6 +205,9 @@ void hcor_estimate_point_colors(const hcor_depthmap* maps, int n_maps, uint64_t 
 
 /* SD.cpp:3265-3495 FuseDepthMaps.  order: image ids sorted by #neighbours descending (SD.cpp:3302;
  * ties broken by ascending id here -- std::sort leaves them unspecified).  returns 0 ok, 1 = capacity */
+/* pixel visiting order of hcor_fuse_depthmaps / hcor_postfilter: 0 raster (the reference's), 1 the hashed order of the C-ABI's
+ * hcmvs_set_fuse_order(ctx, 1) */
+void hcor_set_fuse_pixel_order(int mode);
 int hcor_fuse_depthmaps(hcor_depthmap* maps, int n_maps, const uint32_t* order, int n_order,
                         int n_min_views_fuse, float depth_diff_threshold, float normal_diff_deg,
                         float depthweight, float normalweight, hcor_cloud* cloud);

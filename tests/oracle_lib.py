@@ -104,6 +104,8 @@ def lib():
         L.hcor_fuse_depthmaps.argtypes = [C.POINTER(DepthMap), C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int,
                                           C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Cloud)]
         L.hcor_fuse_depthmaps.restype = C.c_int
+        L.hcor_set_fuse_pixel_order.argtypes = [C.c_int]
+        L.hcor_set_fuse_pixel_order.restype = None
         L.hcor_estimate_point_colors.argtypes = [C.POINTER(DepthMap), C.c_int, C.c_uint64, fp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p]
         L.hcor_estimate_point_colors.restype = None
         L.hcor_postfilter.argtypes = [C.POINTER(DepthMap), C.c_int, C.c_uint32, u8p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_float, C.c_float,
@@ -238,7 +240,9 @@ def filter_depthmap(maps, ref_id, neighbor_ids, adjust=True, n_min_views=2, n_mi
     return ok, d, c, npr.value, nd.value
 
 
-def fuse_depthmaps(maps, order, capacity, n_min_views_fuse=2, thr=0.01, normal_deg=25.0, depthweight=1.0, normalweight=1.0):
+def fuse_depthmaps(maps, order, capacity, n_min_views_fuse=2, thr=0.01, normal_deg=25.0, depthweight=1.0, normalweight=1.0, pixel_order=0):
+    """pixel_order 1: the pixels of an image in the hashed order of hcmvs_set_fuse_order(ctx, 1); the points then come out in visiting
+    order (the device writes them in raster order)"""
     arr, depths = make_depthmaps(maps)
     xyz = np.zeros((capacity, 3), np.float32); nrm = np.zeros((capacity, 3), np.float32)
     bgr = np.zeros((capacity, 3), np.uint8); nv = np.zeros(capacity, np.uint32)
@@ -248,8 +252,12 @@ def fuse_depthmaps(maps, order, capacity, n_min_views_fuse=2, thr=0.01, normal_d
     vids = np.zeros(max(vcap, 1), np.uint32); vwts = np.zeros(max(vcap, 1), np.float32)
     cl.views_capacity = vcap; cl.view_ids = vids.ctypes.data_as(C.POINTER(C.c_uint32)); cl.view_weights = fptr(vwts)
     ids = (C.c_uint32 * len(order))(*order)
-    rc = lib().hcor_fuse_depthmaps(arr, len(maps), ids, len(order), n_min_views_fuse, thr, normal_deg, depthweight,
-                                   normalweight, C.byref(cl))
+    lib().hcor_set_fuse_pixel_order(int(pixel_order))
+    try:
+        rc = lib().hcor_fuse_depthmaps(arr, len(maps), ids, len(order), n_min_views_fuse, thr, normal_deg, depthweight,
+                                       normalweight, C.byref(cl))
+    finally:
+        lib().hcor_set_fuse_pixel_order(0)
     assert rc == 0
     k = cl.n_points
     ne = cl.n_view_entries

@@ -137,6 +137,29 @@ def test_fuse_hashed_order_within_tolerance(ctx, kw):
         ctx.set_fuse_order(2)
 
 
+@pytest.mark.parametrize("kw", [dict(noise=0.003, outliers=0.05, holes=0.1), dict(w=144, h=112, f=130.0, n_views=7, noise=0.002, outliers=0.03)])
+def test_fuse_hashed_order_equals_the_oracle_in_that_order(ctx, kw):
+    """hcmvs_set_fuse_order(1) against the sequential oracle visiting the pixels of every image in the same hashed order: the same
+    points with the same attributes (the oracle emits them in visiting order, the device in raster order, so both are sorted before
+    the comparison) and the same invalidated depths, exactly."""
+    maps, order = make_maps(**kw)
+    want = O.fuse_depthmaps(maps, order, 200000, pixel_order=1)
+    try:
+        ctx.set_fuse_order(1)
+        upload(ctx, maps)
+        got = ctx.fuse(order, 200000)
+    finally:
+        ctx.set_fuse_order(0)
+    assert got["n_points"] == want["n_points"] > 100 and got["n_depths"] == want["n_depths"]
+    def rows(c):
+        r = np.concatenate([c["xyz"].view(np.uint32).astype(np.uint64), c["normal"].view(np.uint32).astype(np.uint64),
+                            c["bgr"].astype(np.uint64), c["n_views"][:, None].astype(np.uint64)], axis=1)
+        return r[np.lexsort(r.T[::-1])]
+    assert np.array_equal(rows(got), rows(want))
+    for i, d in enumerate(want["depths"]):
+        assert np.array_equal(ctx.get_depthmap(i)[0], d)
+
+
 def test_fuse_cloud_views_weights_colors_normals(ctx):
     """the complete PointCloud (SURVEY.md 8f row F2): view lists + weights of every fused point (PointCloud::pointViews /
     pointWeights, SceneDensify.cpp:3376-3411) bit-exact against the oracle; MVS::EstimatePointColors (DepthMap.cpp:2125-2161)
