@@ -338,6 +338,8 @@ struct FuseSettle {
 	uint32_t* ctl;      // kCtlWork + s: length of the list step s wrote
 	int nNb, nMinViewsFuse, order;
 	uint32_t nA;        // pixels of A: list entry e of neighbour q stands for pixel e - q * nA
+	uint32_t* mergeMask; // [w*h] bit q: the pixel would merge its target in neighbour q / lies in front of it and would remove it -- as of the
+	uint32_t* frontMask; // pixel's last evaluation
 };
 constexpr uint32_t kListEnd = 0xFFFFFFFFu;
 // is p a point, given what acc says about the pixels before it?  (a target's bidders are a linked list built by fuse_begin_kernel, a handful of pixels long)
@@ -361,7 +363,11 @@ __device__ __forceinline__ bool settle_eval(const FuseSettle& S, uint32_t p, uin
 // one pixel of a step: re-evaluate; when the answer changed, the later bidders of its targets go on the next list (once per step)
 template <class APPEND>
 __device__ __forceinline__ void settle_pixel(const FuseSettle& S, uint32_t p, uint32_t step, APPEND append) {
-	const bool now = settle_eval(S, p, nullptr, nullptr);
+	uint32_t merge, inFront;
+	const bool now = settle_eval(S, p, &merge, &inFront);
+	// what the pixel would merge and remove: kept from its LAST evaluation, whose inputs are final (a later change of any of them would
+	// have put the pixel on a work list again), for fuse_settle_apply_kernel
+	S.mergeMask[p] = merge; S.frontMask[p] = inFront;
 	if ((ld_u8(&S.acc[p]) != 0) == now) return;
 	st_u8(&S.acc[p], now ? 1 : 0);
 	const uint32_t pp = fuse_prio(p, S.order);
@@ -413,8 +419,7 @@ __global__ void fuse_settle_apply_kernel(DevMap A, const DevMap* maps, FuseSettl
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint32_t p = pending[i];
 		if (!S.acc[p]) continue;
-		uint32_t merge = 0u, inFront = 0u;
-		settle_eval(S, p, &merge, &inFront);
+		const uint32_t merge = S.mergeMask[p], inFront = S.frontMask[p];
 		A.depth[p] = -A.depth[p]; // the claim mark (launch_unclaim restores the sign)
 		for (int q = 0; q < S.nNb; ++q) {
 			if (!((merge | inFront) >> q & 1u)) continue;
@@ -701,6 +706,7 @@ void launch_fuse_pass(const DevMap& A, const DevMap* maps, const FuseTables& tb,
 	S.tb = tb; S.work[0] = (uint32_t*)settle; S.work[1] = S.work[0] + words; S.stamp = S.work[1] + words; S.acc = (uint8_t*)(S.stamp + words);
 	S.ctl = ctl; S.nNb = A.nNeighbors; S.nMinViewsFuse = nMinViewsFuse; S.order = order;
 	S.nA = (uint32_t)n;
+	S.mergeMask = merged; S.frontMask = onv; // onv: the points' view counts, written by the apply kernel after it has read the mask
 	(void)hipMemsetAsync(S.stamp, 0, n * 4, s);
 	(void)hipMemsetAsync(S.acc, 1, n, s);
 	for (int step = 0; step <= kSettleSteps; ++step) hipLaunchKernelGGL(fuse_settle_step_kernel, kGrid, kBlock, 0, s, S, pending, (uint32_t)step);
