@@ -895,7 +895,9 @@ int main(int argc, char** argv) {
 	};
 	std::thread loaderThread(loader);
 	struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } loaderJoin{loaderThread};
+	const double tDecode = now_s();
 	load_images();
+	if (o.verbosity > 2) printf("Start-up: %.2f s until the images are decoded (scene file, headers, view selection, device context), %.2f s decoding + uploading them\n", tDecode - tStart, now_s() - tDecode);
 	if (!loadError.empty()) { fprintf(stderr, "error: %s\n", loadError.c_str()); return EXIT_FAILURE; }
 	if (o.verbosity > 1) printf("Scene loaded: %zu images (%u calibrated), %zu sparse points\n", images.size(), nValid, verts.size());
 	const double tLoaded = now_s();
