@@ -56,7 +56,7 @@ SYMBOLS = ["hcmvs_default_params", "hcmvs_create", "hcmvs_destroy", "hcmvs_last_
            "hcmvs_synchronize", "hcmvs_upload_view", "hcmvs_set_view_device", "hcmvs_release_view", "hcmvs_rescale_view", "hcmvs_get_view_info",
            "hcmvs_get_view_gray",
            "hcmvs_get_gradient_map", "hcmvs_estimate", "hcmvs_estimate_device", "hcmvs_estimate_batch_device", "hcmvs_get_stats",
-           "hcmvs_splat_init", "hcmvs_triangulate_init", "hcmvs_triangulate_points", "hcmvs_set_depthmap", "hcmvs_set_depthmap_device", "hcmvs_get_depthmap",
+           "hcmvs_splat_init", "hcmvs_splat_points", "hcmvs_triangulate_init", "hcmvs_triangulate_points", "hcmvs_set_depthmap", "hcmvs_set_depthmap_device", "hcmvs_get_depthmap",
            "hcmvs_set_neighbors", "hcmvs_filter", "hcmvs_set_fuse_order", "hcmvs_fuse", "hcmvs_fuse_cloud", "hcmvs_estimate_point_colors",
            "hcmvs_estimate_point_normals", "hcmvs_postfilter", "hcmvs_postfilter_sequence", "hcmvs_resize_area_up"]
 
@@ -123,6 +123,7 @@ def lib():
         L.hcmvs_estimate_batch_device.argtypes = [vp, C.POINTER(BatchItem), C.c_int32, C.POINTER(Params)]
         L.hcmvs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.hcmvs_splat_init.argtypes = [vp, C.c_uint32, fp, C.c_int32, fp, fp, fp, fp]
+        L.hcmvs_splat_points.argtypes = [C.c_int32, C.c_int32, dp, dp, dp, fp, C.c_int32, fp, fp, fp, fp]
         L.hcmvs_triangulate_init.argtypes = [vp, C.c_uint32, fp, C.c_int32, C.c_float, C.c_int32, fp, fp, fp, fp]
         dp = C.POINTER(C.c_double)
         L.hcmvs_triangulate_points.argtypes = [C.c_int32, C.c_int32, dp, dp, dp, fp, C.c_int32, C.c_float, C.c_int32, fp, fp, fp, fp]

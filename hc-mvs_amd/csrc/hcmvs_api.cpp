@@ -680,28 +680,23 @@ int hcmvs_estimate(hcmvs_ctx* c, uint32_t ref_id, const uint32_t* src_ids, int32
 	return hcmvs_get_stats(c, &st); // surfaces a sweep timeout as an error
 }
 
-int hcmvs_splat_init(hcmvs_ctx* c, uint32_t id, const float* pts, int32_t n, float* depth, float* normal, float* d_min,
-                     float* d_max) {
-	if (!c) return HCMVS_ERR_INVALID;
-	if (!pts || !depth || !normal || !d_min || !d_max || n < 1) return fail(c, HCMVS_ERR_INVALID, "splat_init: bad arguments");
-	auto it = c->views.find(id);
-	if (it == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "splat_init: unknown view %u", id);
-	const View& v = it->second;
-	const int W = v.w, H = v.h;
+int hcmvs_splat_points(int32_t W, int32_t H, const double K[9], const double R[9], const double C[3], const float* pts, int32_t n, float* depth,
+                       float* normal, float* d_min, float* d_max) {
+	if (!K || !R || !C || !pts || !depth || !normal || !d_min || !d_max || n < 1 || W < 1 || H < 1) return HCMVS_ERR_INVALID;
 	memset(depth, 0, sizeof(float) * (size_t)W * H);
 	float dmin = 3.402823466e+38f, dmax = 0.f;
 	for (int i = 0; i < n; ++i) { // SceneDensify.cpp:789-806
-		const double X[3] = {pts[3 * i] - v.C[0], pts[3 * i + 1] - v.C[1], pts[3 * i + 2] - v.C[2]};
+		const double X[3] = {pts[3 * i] - C[0], pts[3 * i + 1] - C[1], pts[3 * i + 2] - C[2]};
 		double cam[3];
-		for (int r = 0; r < 3; ++r) cam[r] = v.R[r * 3] * X[0] + v.R[r * 3 + 1] * X[1] + v.R[r * 3 + 2] * X[2];
-		const int x = (int)std::floor(v.K[2] + v.K[0] * (cam[0] / cam[2]) + .5);
-		const int y = (int)std::floor(v.K[5] + v.K[4] * (cam[1] / cam[2]) + .5);
+		for (int r = 0; r < 3; ++r) cam[r] = R[r * 3] * X[0] + R[r * 3 + 1] * X[1] + R[r * 3 + 2] * X[2];
+		const int x = (int)std::floor(K[2] + K[0] * (cam[0] / cam[2]) + .5);
+		const int y = (int)std::floor(K[5] + K[4] * (cam[1] / cam[2]) + .5);
 		const float d = (float)cam[2];
 		const int sx = x - 2 > 0 ? x - 2 : 0, sy = y - 2 > 0 ? y - 2 : 0;
 		const int ex = x + 2 < W - 1 ? x + 2 : W - 1, ey = y + 2 < H - 1 ? y + 2 : H - 1;
 		for (int yy = sy; yy <= ey; ++yy)
 			for (int xx = sx; xx <= ex; ++xx) {
-				depth[yy * W + xx] = d;
+				depth[(size_t)yy * W + xx] = d;
 				float* nn = normal + 3 * ((size_t)yy * W + xx);
 				nn[0] = nn[1] = nn[2] = 0.f;
 			}
@@ -711,6 +706,15 @@ int hcmvs_splat_init(hcmvs_ctx* c, uint32_t id, const float* pts, int32_t n, flo
 	*d_min = dmin * 0.9f;
 	*d_max = dmax * 1.1f;
 	return HCMVS_OK;
+}
+int hcmvs_splat_init(hcmvs_ctx* c, uint32_t id, const float* pts, int32_t n, float* depth, float* normal, float* d_min,
+                     float* d_max) {
+	if (!c) return HCMVS_ERR_INVALID;
+	if (!pts || !depth || !normal || !d_min || !d_max || n < 1) return fail(c, HCMVS_ERR_INVALID, "splat_init: bad arguments");
+	auto it = c->views.find(id);
+	if (it == c->views.end()) return fail(c, HCMVS_ERR_INVALID, "splat_init: unknown view %u", id);
+	const View& v = it->second;
+	return hcmvs_splat_points(v.w, v.h, v.K, v.R, v.C, pts, n, depth, normal, d_min, d_max);
 }
 
 int hcmvs_triangulate_points(int32_t W, int32_t H, const double K[9], const double R[9], const double C[3], const float* pts,
@@ -1140,6 +1144,7 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 	const float thDepth = depth_diff_threshold;
 	const FuseTables tb = fuse_tables(targets, head, next, stride);
 	hipStream_t s = c->stream;
+	launch_unclaim(c->dMaps, (int)host.size(), s); // no claim mark may be left over from a fusion or post-filter that failed half way
 	HIPCHK(c, hipMemsetAsync(status, 0, 64, s));
 	HIPCHK(c, hipMemsetAsync(counters, 0, 64, s)); // counters[5]: pixels filled, summed over the sequence
 	for (int k = 0; k < n_ids; ++k) {
@@ -1149,8 +1154,10 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 			HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
 			HIPCHK(c, hipMemsetAsync(head, 0xFF, (size_t)A.nNeighbors * stride * 4, s)); // empty bidder lists
 			launch_fuse_begin(A, c->dMaps, tb, pendingList, ctl, flag, counters, thDepth, normalError, s);
+			// the fork's RemoveSmallSegments visits the pixels in raster order (SceneDensify.cpp:2130-2131), whatever hcmvs_set_fuse_order says
+			// about FuseDepthMaps
 			launch_fuse_pass(A, c->dMaps, tb, pendingList, b + oSettle, ctl, nullptr, nullptr, nullptr, pnv, flag, nullptr, nullptr, maxNb + 1, merged, n_min_views_fuse,
-			                 c->fuseOrder, counters, status, false, s);
+			                 0, counters, status, false, s);
 		}
 		launch_postfilter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, c->dMaps, (int)host.size(), v.gra, dF, dF2, nF, gap_size, depth_diff_threshold * 2.5f, counters + 5, s);
 	}
@@ -1160,7 +1167,11 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 	HIPCHK(c, hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, s));
 	HIPCHK(c, hipMemcpyAsync(cnt, counters, 48, hipMemcpyDeviceToHost, s));
 	HIPCHK(c, hipStreamSynchronize(s));
-	if (st[0] != 0) return fail(c, HCMVS_ERR_TIMEOUT, "postfilter: the settle iteration of a fusion pass gave up; the registered depth maps are left partially fused");
+	if (st[0] != 0) {
+		launch_unclaim(c->dMaps, (int)host.size(), s); // an estimate or a saved map must never see a claim mark (negative depth)
+		(void)hipStreamSynchronize(s);
+		return fail(c, HCMVS_ERR_TIMEOUT, "postfilter: the settle iteration of a fusion pass gave up; the registered depth maps are left partially fused");
+	}
 	if (n_filled) *n_filled = cnt[5];
 	return HCMVS_OK;
 }

@@ -75,8 +75,15 @@ def gather_scene_maps(order, my_maps, h, w, group=None, device=None):
     return {img: unpack_maps(allm[slab_index(k, world, n_local)], h, w) for k, img in enumerate(order)}
 
 
+def _device_sync(dev):
+    """The context enqueues on a stream of its own (hipStreamNonBlocking, hcmvs_api.cpp hcmvs_create): whatever torch or RCCL wrote into
+    buffers the context is about to read -- gathered maps, copied-back slabs -- must have landed first, and the other way round."""
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+
+
 def densify_scene(ctx, views, srcs, neighbors, order, init, params, group=None, device=None, batch=32, capacity=None,
-                  fuse_kw=None, n_external_iters=1, postfilter=False, pf_kw=None):
+                  fuse_kw=None, n_external_iters=1, postfilter=False, pf_kw=None, interleave=False):
     """The multi-rank scene path (BASELINE.json configs[3]) over the C-ABI binding, with the reference's outer
     iterations (SceneDensify.cpp:3684) and the fork's post-filters after outer iterations 1 and 2 (SceneDensify.cpp:3939-3958):
 
@@ -93,6 +100,13 @@ def densify_scene(ctx, views, srcs, neighbors, order, init, params, group=None, 
     chain on identical gathered maps with a deterministic kernel, hence every rank holds identical filtered maps and no scatter is
     needed -- the result is independent of the number of ranks.  One all-gather per filtered outer iteration and one before the
     fusion (SURVEY.md 8e budgets exactly that).
+
+    That batch schedule is a DEPARTURE from the reference: there image k is filtered right after its own
+    estimate (EVTEstimateDepthMap queues EVTOptimizeDepthMap FIRST, SceneDensify.cpp:3914-3925), so its fusion sees the images > k as
+    the previous outer iteration left them and zeroes depths in them before they are estimated again.  interleave=True is that order,
+    exactly (the single-thread event order; image ids ascending): in outer iterations 1 and 2 the images are estimated ONE AT A TIME,
+    each followed by its post-filter on every rank; the owner of an image broadcasts its fresh maps first.  Nothing runs in parallel
+    across ranks there -- it is the exact mode, not the fast one.
 
     ctx:       binding.Context of this rank's device (one process per GPU)
     views:     {image id: dict(gray, K, R, C[, bgr])} of EVERY image (all the same size).  A rank uploads the gray image only of
@@ -126,19 +140,24 @@ def densify_scene(ctx, views, srcs, neighbors, order, init, params, group=None, 
             ctx.upload_view(i, None, v["K"], v["R"], v["C"], bgr=v["bgr"])
     slabs = torch.zeros(n_local, FLOATS_PER_PIXEL * hw, dtype=torch.float32, device=dev)
     rng = torch.zeros(n_local, 2, dtype=torch.float32, device=dev)      # (d_min, d_max) travel with the maps
-    items_by_class = {}
     for j, img in enumerate(mine):
         d0, n0, dmin, dmax = init[img]
         slabs[j, :hw] = torch.from_numpy(np.ascontiguousarray(d0, np.float32)).reshape(-1).to(dev)
         slabs[j, hw:4 * hw] = torch.from_numpy(np.ascontiguousarray(n0, np.float32)).reshape(-1).to(dev)
         rng[j, 0], rng[j, 1] = float(dmin), float(dmax)
-        base = slabs[j].data_ptr()
-        v = len(srcs[img])
-        cls = 8 if v <= 8 else 16   # the items of a batch share a lane-layout class (up to 8 views, or 9..16)
-        items_by_class.setdefault(cls, []).append(dict(ref_id=img, src_ids=list(srcs[img]), d_min=float(dmin), d_max=float(dmax),
-                                                       d_depth=base, d_normal=base + 4 * hw, d_conf=base + 16 * hw, seed_offset=img))
     allr = allgather_maps(rng, group)
     gathered = torch.empty(world * n_local, FLOATS_PER_PIXEL * hw, dtype=torch.float32, device=dev) if world > 1 else None
+
+    def item_of(img, base):
+        r = allr[slab_index(ids.index(img), world, n_local)]
+        return dict(ref_id=img, src_ids=list(srcs[img]), d_min=float(r[0]), d_max=float(r[1]), d_depth=base, d_normal=base + 4 * hw,
+                    d_conf=base + 16 * hw, seed_offset=img)
+
+    def my_items(store, row_of):
+        by_class = {}
+        for img in mine:        # the items of a batch share a lane-layout class (up to 8 views, or 9..16)
+            by_class.setdefault(8 if len(srcs[img]) <= 8 else 16, []).append(item_of(img, store[row_of(img)].data_ptr()))
+        return by_class
 
     def register(allm):
         for k, img in enumerate(ids):
@@ -149,22 +168,54 @@ def densify_scene(ctx, views, srcs, neighbors, order, init, params, group=None, 
 
     p = copy.copy(params)
     p.n_external_iters = int(n_external_iters)
-    torch.cuda.synchronize(dev)
+    _device_sync(dev)
     for it in range(int(n_external_iters)):
         p.it_external = it
-        for cls, items in sorted(items_by_class.items()):     # NO collective on the estimation path
+        filt = postfilter and it in (1, 2)
+        if filt and interleave:
+            # the reference's order: estimate(k) -> post-filter(k) -> estimate(k + 1), image ids ascending.  The gathered buffer is the
+            # state of the whole scene on every rank; an image is estimated in place by its owner and broadcast before its filter runs
+            allm = allgather_maps(slabs, group, out=gathered)
+            _device_sync(dev)
+            register(allm)
+            for img in sorted(ids):
+                k = ids.index(img)
+                row = slab_index(k, world, n_local)
+                owner = k % world
+                if owner == rank:
+                    ctx.estimate_batch_device([item_of(img, allm[row].data_ptr())], p)
+                    ctx.synchronize()
+                if world > 1:
+                    if allm.is_cuda and dist.get_backend(group) == "gloo":      # one-GPU rehearsal: gloo moves host tensors
+                        host = allm[row].cpu()
+                        dist.broadcast(host, src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
+                        allm[row].copy_(host)
+                    else:
+                        dist.broadcast(allm[row], src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
+                    _device_sync(dev)
+                ctx.postfilter(img, ids, **(pf_kw or {}))
+            ctx.synchronize()
+            if world > 1:
+                for j, img in enumerate(mine):
+                    slabs[j].copy_(allm[slab_index(ids.index(img), world, n_local)])
+                _device_sync(dev)
+            continue
+        for cls, items in sorted(my_items(slabs, lambda img: mine.index(img)).items()):     # NO collective on the estimation path
             for b0 in range(0, len(items), batch):
                 ctx.estimate_batch_device(items[b0:b0 + batch], p)
         ctx.synchronize()
-        if postfilter and it in (1, 2):
+        if filt:
             allm = allgather_maps(slabs, group, out=gathered)  # every rank: every image's current maps
+            _device_sync(dev)
             register(allm)
-            ctx.postfilter_sequence(sorted(ids), ids, **(pf_kw or {}))   # image after image, as the reference's event loop runs them
+            ctx.postfilter_sequence(sorted(ids), ids, **(pf_kw or {}))   # image after image (batch schedule, D6)
             ctx.synchronize()
             if world > 1:                                      # my images' filtered maps: out of the gathered buffer, back into my slabs
                 for j, img in enumerate(mine):
                     slabs[j].copy_(allm[slab_index(ids.index(img), world, n_local)])
+                _device_sync(dev)                              # the next estimate reads the slabs on the context's stream
     allm = allgather_maps(slabs, group, out=gathered)          # the exchange before fusion: 20 B/px, rank-major equal slabs
+    _device_sync(dev)
     register(allm)
     maps = {img: unpack_maps(allm[slab_index(k, world, n_local)], h, w) for k, img in enumerate(ids)}
     cap = capacity if capacity is not None else hw * len(ids) // 2

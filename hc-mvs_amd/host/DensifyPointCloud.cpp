@@ -64,6 +64,8 @@ struct Options { // DensifyPointCloud.cpp:139-198 (defaults from there)
 	int nOptimize = 2;            // --n-nOptimize (DensifyPointCloud.cpp:164, 268): bits REMOVE_SPECKLES 1 | FILL_GAPS 2 (DepthMap.h:113-118) gate the fork's
 	                              // RemoveSmallSegments + GapInterpolation after outer iterations 1 and 2 (SceneDensify.cpp:3916, 3939-3958)
 	int postFilter = -1;          // --n-postfilter 0|1: override of that gate (-1: follow --n-nOptimize)
+	int postFilterInterleave = 0; // --n-postfilter-interleave 1: estimate(k) -> post-filter(k) -> estimate(k + 1), the reference's own order
+	                              // (SceneDensify.cpp:3889-3965), one image per launch; 0: estimate all, then filter all
 	int resume = 1;               // skip-if-exists (SceneDensify.cpp:3865-3880): an image whose final depth map is already in the working folder is not estimated again
 	int restoreHypothesis = 0;    // 1: the `restore` binary's extra last-sweep hypothesis from the previous level's maps
 	                              // (restore/libs/MVS/DepthMap.cpp:1527-1549); needs the previous level's maps in the working folder
@@ -582,7 +584,7 @@ int main(int argc, char** argv) {
 		"--n-usegeoconsistency", "--n-initTriangulate", "--n-viewspread", "--n-opticalflow", "--n-adapthalfwin",
 		"--n-propagatehalfwin", "--n-propagatestep",
 		// this driver's own
-		"--min-views-trust-point", "--fuse-order", "--device", "--batch", "--seed", "--restore-hypothesis", "--n-postfilter", "--resume"};
+		"--min-views-trust-point", "--fuse-order", "--device", "--batch", "--seed", "--restore-hypothesis", "--n-postfilter", "--n-postfilter-interleave", "--resume"};
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i], val;
 		if (a == "-h" || a == "--help") { kv["--help"] = "1"; continue; }
@@ -610,7 +612,7 @@ int main(int argc, char** argv) {
 	geti("--n-propagatehalfwin", o.propagateHalfWin); geti("--n-propagatestep", o.propagateStep);
 	getf("--n-photometric_flow", o.photometricFlow); getf("--depthweight", o.depthweight); getf("--normalweight", o.normalweight);
 	geti("--n-initTriangulate", o.initTriangulate); geti("--min-views-trust-point", o.minViewsTrustPoint);
-	geti("--fuse-order", o.fuseOrder); geti("--restore-hypothesis", o.restoreHypothesis); geti("--n-postfilter", o.postFilter); geti("--n-nOptimize", o.nOptimize); geti("--resume", o.resume);
+	geti("--fuse-order", o.fuseOrder); geti("--restore-hypothesis", o.restoreHypothesis); geti("--n-postfilter", o.postFilter); geti("--n-postfilter-interleave", o.postFilterInterleave); geti("--n-nOptimize", o.nOptimize); geti("--resume", o.resume);
 	geti("--device", o.device); geti("--batch", o.batch);
 	if (kv.count("--seed")) o.seed = (uint32_t)strtoul(kv["--seed"].c_str(), nullptr, 10);
 	geti("--estimate-colors", o.estimateColors); geti("--estimate-normals", o.estimateNormals);
@@ -683,8 +685,7 @@ int main(int argc, char** argv) {
 	// AFTER the loader thread below has started: the triangulated initial maps need cameras and sparse points only, so the first
 	// batch's initialisation overlaps the decoding.
 	std::string loadError;
-	std::mutex upMu; std::condition_variable upCv;
-	bool uploadsDone = false;
+	std::mutex upMu;
 	auto load_images = [&]() {
 		const long N = (long)images.size();
 #pragma omp parallel for schedule(dynamic, 1)
@@ -715,8 +716,6 @@ int main(int argc, char** argv) {
 			if (hcmvs_upload_view(ctx, im.id, im.w, im.h, gray, bgrUp, im.cam.K, im.cam.R, im.cam.C) != HCMVS_OK && loadError.empty())
 				loadError = std::string("upload of image '") + paths[t] + "' failed: " + hcmvs_last_error(ctx);
 		}
-		{ std::lock_guard<std::mutex> g(upMu); uploadsDone = true; }
-		upCv.notify_all();
 	};
 	createThread.join();
 	if (createRc != HCMVS_OK) { fprintf(stderr, "error: no usable MI355X device (there is no CPU path)\n"); return EXIT_FAILURE; }
@@ -822,8 +821,9 @@ int main(int argc, char** argv) {
 				for (uint32_t idx : im.points) { pts.push_back(verts[idx].X[0]); pts.push_back(verts[idx].X[1]); pts.push_back(verts[idx].X[2]); }
 				M.d.assign(n, 0.f); M.n.assign(3 * n, 0.f);
 				if (o.minViewsTrustPoint < 2) {
-					{ std::unique_lock<std::mutex> g(upMu); upCv.wait(g, [&] { return uploadsDone; }); } // the splat helper looks the view up in the context
-					if (hcmvs_splat_init(ctx, im.id, pts.data(), (int32_t)im.points.size(), M.d.data(), M.n.data(), &im.dMin, &im.dMax) != HCMVS_OK) M.failed = 1;
+					// the context-free form: the loader's workers never touch the context (it is not thread-safe, and the main thread is
+					// registering views meanwhile)
+					if (hcmvs_splat_points(im.w, im.h, im.cam.K, im.cam.R, im.cam.C, pts.data(), (int32_t)im.points.size(), M.d.data(), M.n.data(), &im.dMin, &im.dMax) != HCMVS_OK) M.failed = 1;
 				} else if (o.initTriangulate || o.restoreHypothesis) { // the `restore` binary always triangulates (restore/libs/MVS/SceneDensify.cpp:508-511)
 					if (hcmvs_triangulate_points(im.w, im.h, im.cam.K, im.cam.R, im.cam.C, pts.data(), (int32_t)im.points.size(), 0.f, 1, M.d.data(), M.n.data(),
 					                             &im.dMin, &im.dMax) != HCMVS_OK) M.failed = 1;
@@ -836,12 +836,15 @@ int main(int argc, char** argv) {
 					// another size are brought to this one with that cubic kernel
 					if (pm.w == im.w && pm.h == im.h) { M.d.swap(pm.d); M.n.swap(pm.n); }
 					else { resize_cubic(pm.d, pm.w, pm.h, 1, M.d, im.w, im.h); resize_cubic(pm.n, pm.w, pm.h, 3, M.n, im.w, im.h); }
-					// depth range of the map (SceneDensify.cpp:544-553; over the valid depths only: the cubic kernel overshoots next to
-					// holes and a non-positive bound would poison the random-depth range)
+					// depth range of the map, SceneDensify.cpp:544-553: over EVERY value of the handed-over map, the empty pixels (0) included
+					// -- an estimated map always has them (its border), so the lower bound is 0, exactly what the `restore` branch below ends
+					// up with (one rule for both; DESIGN.md section 5, D7: the reference's running min / max start from uninitialised members).
+					// Values the cubic kernel pushed below 0 next to holes (maps of another size only) count as empty.
 					float lo = 3.402823466e+38f, hi = 0.f;
 					for (size_t q_ = 0; q_ < n; ++q_) {
-						if (!(M.d[q_] > 0.f)) { M.d[q_] = 0.f; continue; }
+						if (!(M.d[q_] > 0.f)) M.d[q_] = 0.f;
 						lo = std::min(lo, M.d[q_]); hi = std::max(hi, M.d[q_]);
+						if (M.d[q_] == 0.f) continue;
 						float* q = &M.n[3 * q_];
 						const float len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
 						if (len > 0.f) { q[0] /= len; q[1] /= len; q[2] /= len; }
@@ -1002,9 +1005,75 @@ int main(int argc, char** argv) {
 	double tPostfilter = 0;
 	const bool filterOnLast = o.postFilter && (o.estimationItersExternal - 1 == 1 || o.estimationItersExternal - 1 == 2);
 	// outer iterations over all images (SceneDensify.cpp:3684)
+	auto estimate_images = [&](const std::vector<uint32_t>& ids, int it) -> bool { // one launch set for the reference images `ids`
+		std::vector<hcmvs_batch_item> items;
+		for (uint32_t id : ids) {
+			ImageData& im = images[id];
+			hcmvs_batch_item itx;
+			itx.ref_id = im.id; itx.src_ids = im.srcs.data(); itx.n_src = (int32_t)im.srcs.size(); itx.seed_offset = im.id;
+			itx.d_min = im.dMin; itx.d_max = im.dMax; itx.d_depth = im.dDepth; itx.d_normal = im.dNormal; itx.d_conf = im.dConf;
+			itx.d_hint_depth = im.dHintDepth; itx.d_hint_normal = im.dHintNormal;
+			items.push_back(itx);
+		}
+		hcmvs_stats st;
+		if (hcmvs_estimate_batch_device(ctx, items.data(), (int32_t)items.size(), &prm) != HCMVS_OK || hcmvs_get_stats(ctx, &st) != HCMVS_OK) {
+			fprintf(stderr, "error: depth-map estimation failed (%s)\n", hcmvs_last_error(ctx));
+			return false;
+		}
+		if (o.verbosity > 2)
+			for (const auto& itx : items)
+				printf("Depth-map for image %3u estimated using %2d images: %dx%d (outer iteration %d, batch %.0f ms)\n", itx.ref_id,
+				       itx.n_src, images[itx.ref_id].w, images[itx.ref_id].h, it, st.ms_total);
+		return true;
+	};
+	// the maps and neighbour lists the post-filters' fusion works on: every image of the scene, best connected first
+	std::vector<uint32_t> filterOrder(todo);
+	std::stable_sort(filterOrder.begin(), filterOrder.end(), [&](uint32_t a, uint32_t b) { return images[a].neighbors.size() > images[b].neighbors.size(); });
+	auto register_maps = [&]() -> bool {
+		for (uint32_t id : todo) {
+			ImageData& im = images[id];
+			std::vector<uint32_t> nb;
+			for (const auto& x : im.neighbors) if (std::find(todo.begin(), todo.end(), x.id) != todo.end()) nb.push_back(x.id);
+			if (nb.size() > 31) nb.resize(31);
+			if (hcmvs_set_depthmap_device(ctx, id, im.dDepth, im.dNormal, im.dConf, im.dMin, im.dMax) != HCMVS_OK ||
+			    hcmvs_set_neighbors(ctx, id, nb.data(), (int32_t)nb.size()) != HCMVS_OK) {
+				fprintf(stderr, "error: registering the maps of image %u failed (%s)\n", id, hcmvs_last_error(ctx));
+				return false;
+			}
+		}
+		return true;
+	};
+	const int nMinViewsFuse = std::min<int>(o.numberViewsFuse, (int)images.size());
 	for (int it = 0; it < o.estimationItersExternal; ++it) {
 		prm.it_external = it;
 		const bool last = it == o.estimationItersExternal - 1;
+		// SceneDensify.cpp:3916, 3939-3958: with --n-nOptimize's REMOVE_SPECKLES | FILL_GAPS bits, after the estimates of outer
+		// iterations 1 and 2 every image goes through RemoveSmallSegments (in the fork: a whole fusion pass over the current maps of all
+		// images) and GapInterpolation
+		const bool filtered = o.postFilter && (it == 1 || it == 2) && !work.empty();
+		if (filtered && o.postFilterInterleave) {
+			// the reference's order, exactly (single-thread event loop, SceneDensify.cpp:3889-3965: EVTEstimateDepthMap(k) queues
+			// EVTOptimizeDepthMap(k) FIRST): image k is filtered right after its own estimate, so its fusion sees the images > k as the
+			// previous outer iteration left them and zeroes depths in them before they are estimated again.  One image per launch: the
+			// exact mode, not the fast one
+			const double tp = now_s();
+			if (!register_maps()) return EXIT_FAILURE;
+			uint64_t filledAll = 0;
+			double tf = 0;
+			for (uint32_t id : work) {
+				if (!estimate_images(std::vector<uint32_t>(1, id), it)) return EXIT_FAILURE;
+				const double t0 = now_s();
+				uint64_t filled = 0;
+				CHK(hcmvs_postfilter(ctx, id, filterOrder.data(), (int32_t)filterOrder.size(), nMinViewsFuse, 0.01f, 25.f, 7, &filled));
+				filledAll += filled;
+				tf += now_s() - t0;
+			}
+			tPostfilter += tf;
+			if (o.verbosity > 1) printf("Depth-maps estimated and filtered image after image in outer iteration %d (the reference's order): %llu pixels filled "
+			                            "(%.2f s, %.2f s of it post-filters)\n", it, (unsigned long long)filledAll, now_s() - tp, tf);
+			if (last) saver_submit(work);
+			continue;
+		}
 		for (size_t b = 0; b < batches.size(); ++b) {
 			if (it == 0) { // the batch's initial maps must have arrived
 				std::unique_lock<std::mutex> g(prepMu);
@@ -1015,43 +1084,16 @@ int main(int argc, char** argv) {
 				if (pr.failed == 3) { fprintf(stderr, "error: the previous level's depth map of image %u holds no valid depth\n", pr.failedId); return EXIT_FAILURE; }
 				if (pr.failed) { fprintf(stderr, "error: initialisation of image %u failed (%s)\n", pr.failedId, pr.failed == 4 ? "device memory" : hcmvs_last_error(ctx)); return EXIT_FAILURE; }
 			}
-			std::vector<hcmvs_batch_item> items;
-			for (uint32_t id : batches[b]) {
-				ImageData& im = images[id];
-				hcmvs_batch_item itx;
-				itx.ref_id = im.id; itx.src_ids = im.srcs.data(); itx.n_src = (int32_t)im.srcs.size(); itx.seed_offset = im.id;
-				itx.d_min = im.dMin; itx.d_max = im.dMax; itx.d_depth = im.dDepth; itx.d_normal = im.dNormal; itx.d_conf = im.dConf;
-				itx.d_hint_depth = im.dHintDepth; itx.d_hint_normal = im.dHintNormal;
-				items.push_back(itx);
-			}
-			CHK(hcmvs_estimate_batch_device(ctx, items.data(), (int32_t)items.size(), &prm));
-			hcmvs_stats st;
-			CHK(hcmvs_get_stats(ctx, &st));
-			if (o.verbosity > 2)
-				for (const auto& itx : items)
-					printf("Depth-map for image %3u estimated using %2d images: %dx%d (outer iteration %d, batch %.0f ms)\n", itx.ref_id,
-					       itx.n_src, images[itx.ref_id].w, images[itx.ref_id].h, it, st.ms_total);
+			if (!estimate_images(batches[b], it)) return EXIT_FAILURE;
 			if (last && !filterOnLast) saver_submit(batches[b]); // final maps of this batch: off to the host while the next batch runs
 		}
-		// SceneDensify.cpp:3916, 3939-3958: with --n-nOptimize's REMOVE_SPECKLES | FILL_GAPS bits, after outer iterations 1 and 2
-		// every image goes through RemoveSmallSegments (in the fork: a whole fusion pass over the current maps of all images) and
-		// GapInterpolation, one image after the other
-		if (o.postFilter && (it == 1 || it == 2) && !work.empty()) {
+		// the batch schedule of the post-filters: every image of the outer iteration has been estimated, now
+		// they are filtered one image after the other (hcmvs_postfilter_sequence keeps the whole chain on the device)
+		if (filtered) {
 			const double tp = now_s();
-			std::vector<uint32_t> ord(todo);
-			std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return images[a].neighbors.size() > images[b].neighbors.size(); });
-			for (uint32_t id : todo) {
-				ImageData& im = images[id];
-				CHK(hcmvs_set_depthmap_device(ctx, id, im.dDepth, im.dNormal, im.dConf, im.dMin, im.dMax));
-				std::vector<uint32_t> nb;
-				for (const auto& x : im.neighbors) if (std::find(todo.begin(), todo.end(), x.id) != todo.end()) nb.push_back(x.id);
-				if (nb.size() > 31) nb.resize(31);
-				CHK(hcmvs_set_neighbors(ctx, id, nb.data(), (int32_t)nb.size()));
-			}
-			CHK(hcmvs_set_fuse_order(ctx, o.fuseOrder));
+			if (!register_maps()) return EXIT_FAILURE;
 			uint64_t filledAll = 0;
-			CHK(hcmvs_postfilter_sequence(ctx, work.data(), (int32_t)work.size(), ord.data(), (int32_t)ord.size(), std::min<int>(o.numberViewsFuse, (int)images.size()),
-			                              0.01f, 25.f, 7, &filledAll));
+			CHK(hcmvs_postfilter_sequence(ctx, work.data(), (int32_t)work.size(), filterOrder.data(), (int32_t)filterOrder.size(), nMinViewsFuse, 0.01f, 25.f, 7, &filledAll));
 			tPostfilter += now_s() - tp;
 			if (o.verbosity > 1) printf("Depth-maps filtered after outer iteration %d: fuse-consistency mask + gap interpolation, %llu pixels filled (%.2f s)\n", it,
 			                            (unsigned long long)filledAll, now_s() - tp);

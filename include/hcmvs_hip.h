@@ -155,6 +155,9 @@ int hcmvs_get_stats(hcmvs_ctx* ctx, hcmvs_stats* out);
  * into host maps depth (w*h) / normal (w*h*3); returns the depth range (min*0.9, max*1.1). Host-side helper. */
 int hcmvs_splat_init(hcmvs_ctx* ctx, uint32_t id, const float* points_xyz, int32_t n_points, float* depth,
                      float* normal, float* d_min, float* d_max);
+/* the same without a context (size and camera given): pure host code, callable from any thread */
+int hcmvs_splat_points(int32_t width, int32_t height, const double K[9], const double R[9], const double C[3],
+                       const float* points_xyz, int32_t n_points, float* depth, float* normal, float* d_min, float* d_max);
 
 /* DepthMap.cpp:1796-1936 TriangulatePoints2DepthMap (the default initialisation, nMinViewsTrustPoint >= 2) as
  * DepthMapsData::InitDepthMap uses it (SceneDensify.cpp:522-526): Delaunay-triangulate the projections of the sparse

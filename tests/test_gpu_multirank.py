@@ -24,7 +24,7 @@ def _scene():
     return base, views, srcs, neighbors, order
 
 
-def _run(rank, world, port, ret, outer=1, postfilter=False):
+def _run(rank, world, port, ret, outer=1, postfilter=False, interleave=False):
     import torch
     import torch.distributed as dist
     binding = importlib.import_module("hc-mvs_amd.binding")
@@ -44,7 +44,7 @@ def _run(rank, world, port, ret, outer=1, postfilter=False):
             pts = synth.sparse_points([base[i]], 120, seed=40 + i)
             init[i] = ctx.splat_init(i, pts)
         p = binding.default_params(adapthalfwin=6, n_estimation_iters=3 if outer == 1 else 2, seed=900, propagate_halfwin=5, propagate_step=4)
-        cloud = D.densify_scene(ctx, views, srcs, neighbors, order, init, p, device=torch.device("cuda", 0), n_external_iters=outer, postfilter=postfilter)
+        cloud = D.densify_scene(ctx, views, srcs, neighbors, order, init, p, device=torch.device("cuda", 0), n_external_iters=outer, postfilter=postfilter, interleave=interleave)
         ret[rank] = (cloud["n_points"], cloud["n_depths"], cloud["xyz"].tobytes(), cloud["n_views"].tobytes(),
                      {i: cloud["maps"][i][0].cpu().numpy().tobytes() for i in order})
         ctx.close()
@@ -92,3 +92,24 @@ def test_two_ranks_outer_iterations_with_postfilters():
     plain = mgr.dict()
     mp.spawn(_run, args=(1, 0, plain, 3, False), nprocs=1, join=True)
     assert plain[0][2] != single[0][2]
+
+
+def test_two_ranks_interleaved_postfilters():
+    """the reference's own order of the post-filters (estimate(k) -> post-filter(k) -> estimate(k + 1), SceneDensify.cpp:3889-3965;
+    DESIGN.md section 5, D6) across two ranks: the owner of an image estimates it and broadcasts its maps, every rank filters.  Cloud and
+    maps of both ranks == the single-rank run in that order, and differ from the batch schedule's."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    single = mgr.dict()
+    mp.spawn(_run, args=(1, 0, single, 3, True, True), nprocs=1, join=True)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ret = mgr.dict()
+    mp.spawn(_run, args=(2, port, ret, 3, True, True), nprocs=2, join=True)
+    assert len(ret) == 2 and single[0][0] > 2000
+    for r in (0, 1):
+        assert ret[r][0] == single[0][0] and ret[r][2] == single[0][2] and ret[r][3] == single[0][3]
+    for i in single[0][4]:
+        assert ret[0][4][i] == ret[1][4][i] == single[0][4][i]
+    batch = mgr.dict()
+    mp.spawn(_run, args=(1, 0, batch, 3, True, False), nprocs=1, join=True)
+    assert batch[0][2] != single[0][2]
