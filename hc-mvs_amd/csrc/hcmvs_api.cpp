@@ -605,7 +605,9 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 			// pair-packing variant, which is correct for the other items of its layout class too
 			int vSel = items[0].n_src;
 			for (int i = 0; i < n_items; ++i) if (items[i].n_src % 8 != 0 && items[i].n_src % 8 != 7) vSel = items[i].n_src;
-			launch_sweep(c->dItems, n_items, maxRows, totalRows, vSel, p->adapthalfwin > kHalfWindow, sy, iter, c->sweepLag, nw, c->xcdAffinity, s);
+			bool hint = false; // the `restore` variant's extra hypothesis is offered in this sweep by some item: the kernel instance that knows it
+			for (int i = 0; i < n_items; ++i) hint = hint || (c->hItems[i].hintDepth && c->hItems[i].hintIter == iter);
+			launch_sweep(c->dItems, n_items, maxRows, totalRows, vSel, p->adapthalfwin > kHalfWindow, hint, sy, iter, c->sweepLag, nw, c->xcdAffinity, s);
 		}
 	}
 	HIPCHK(c, hipEventRecord(c->ev[2], s));

@@ -74,7 +74,7 @@ void launch_median3(const float* in, float* out, int W, int H, hipStream_t s);
 void launch_quads(const float* gray, float4* out, int W, int H, hipStream_t s); // 2 x 2 footprint layout of a source view
 void launch_score_pass(const EstConst& c, const float* depthIn, const float* normalIn, unsigned long long* evals,
                        hipStream_t s);
-void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int lag,
+void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, bool hint, const SweepSync& sync, int iter, int lag,
                   int wavesPerRow, int affinity, hipStream_t s);
 void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s);
 

@@ -275,8 +275,22 @@ struct WavePark { // LDS of one wave of a row worker
 	float ps[3][8][8];        // py | w | tw as [column][row], read by every view group
 	float cl[9][kMaxSlots];   // smoothness neighbours, slot k at [.][k]: X0 X1 X2 | n0 n1 n2 | k0 k1 k2 (see Close)
 	float4 hl[8][64 / S][3];  // homographies of the (hypothesis, view) pairs of the current chunk of eight hypotheses
+#ifdef HCMVS_PARTHALF
+	float part[3][8][64 / S][S / 2]; // their ZNCC sums (sum | sumSq | num), neighbouring lane pairs of the view group already added (the butterfly's first step)
+#else
 	float part[3][8][64 / S][S]; // their ZNCC sums (sum | sumSq | num) as the S lanes of the view group left them: added up per chunk, not per evaluation
+#endif
 };
+// park the lane's partial sums of pair (g, v) for the chunk epilogue
+template <int S>
+__device__ __forceinline__ void park_partials(WavePark<S>* pk, int g, int v, int seg, bool valid, float sum, float sumSq, float num) {
+#ifdef HCMVS_PARTHALF
+	sum = sum + lane_xor<1>(sum); sumSq = sumSq + lane_xor<1>(sumSq); num = num + lane_xor<1>(num);
+	if (valid && !(seg & 1)) { pk->part[0][g][v][seg >> 1] = sum; pk->part[1][g][v][seg >> 1] = sumSq; pk->part[2][g][v][seg >> 1] = num; }
+#else
+	if (valid) { pk->part[0][g][v][seg] = sum; pk->part[1][g][v][seg] = sumSq; pk->part[2][g][v][seg] = num; }
+#endif
+}
 template <int S>
 struct LdsStore {
 	static constexpr int MAXM = 64 / S;
@@ -526,9 +540,44 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 	float a = 0.f, b2 = 0.f, cnum = 0.f;
 	SUBMARK(tap_sample)
 	if (!bad) {
+		const HC_GLOBAL char* imgBase = as_global(c.imgBase);
+		float Pw[64 / S], Ptw[64 / S];
+#ifdef HCMVS_TAPHALF
+		// diagnostic variant (profiles/r04_sweep_levers.md): the rows in two halves -- half the gathered footprints live at a time
+		constexpr int HALF = (MAXM + 1) / 2;
+		st.get_w(Pw, Ptw);
+#pragma unroll
+		for (int h0 = 0; h0 < MAXM; h0 += HALF) {
+			float2 top[HALF], bot[HALF];
+			float fx[HALF], fy[HALF];
+#pragma unroll
+			for (int u = 0; u < HALF; ++u) {
+				const int m = h0 + u < MAXM ? h0 + u : MAXM - 1;
+				const int lx = (int)qx[m], ly = (int)qy[m];
+				fx[u] = __builtin_amdgcn_fractf(qx[m]);
+				fy[u] = __builtin_amdgcn_fractf(qy[m]);
+				const unsigned off = L.imgOff + ((unsigned)(__mul24(ly, L.iw) + lx) << 4);
+				const f32x4 fp = *(const HC_GLOBAL f32x4*)(imgBase + off);
+				top[u] = make_float2(fp.x, fp.y);
+				bot[u] = make_float2(fp.z, fp.w);
+			}
+#pragma unroll
+			for (int u = 0; u < HALF; ++u) {
+				if (h0 + u >= MAXM) continue;
+				const int m = h0 + u;
+				const float t = fmaf(fx[u], top[u].y, top[u].x);
+				const float b = fmaf(fx[u], bot[u].y, bot[u].x);
+				const float val = fmaf(fy[u], b - t, t);
+				const float vw = val * Pw[m];
+				a = a + vw;
+				b2 = fmaf(val, vw, b2);
+				cnum = fmaf(val, Ptw[m], cnum);
+			}
+			asm volatile("" ::: "memory"); // the second half's gathers are not hoisted above the first half's arithmetic
+		}
+#else
 		float2 top[MAXM], bot[MAXM];
 		float fx[MAXM], fy[MAXM];
-		const HC_GLOBAL char* imgBase = as_global(c.imgBase);
 #pragma unroll
 		for (int m = 0; m < MAXM; ++m) {
 			const int lx = (int)qx[m], ly = (int)qy[m];
@@ -546,7 +595,6 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 			bot[m] = make_float2(fp.z, fp.w);
 #endif
 		}
-		float Pw[64 / S], Ptw[64 / S];
 		st.get_w(Pw, Ptw);
 #pragma unroll
 		for (int m = 0; m < MAXM; ++m) {
@@ -559,6 +607,7 @@ __device__ __forceinline__ void score_taps(const EstConst& c, const LaneCtx<S>& 
 			b2 = fmaf(val, vw, b2);
 			cnum = fmaf(val, Ptw[m], cnum);
 		}
+#endif
 	}
 	// a tap outside the image (or a degenerate warp) must turn the view's score into thRobust: the lane poisons its
 	// partial sum, the NaN survives the butterfly and fails the `nrmSq > 0` test of view_score
@@ -743,7 +792,7 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 					bool viewBad;
 					if constexpr (NR == 0) score_taps_big<S, LdsStore<S>, false>(c, Lp, st, H, sum, sumSq, num, viewBad);
 					else score_taps<S, NR, LdsStore<S>, false>(c, Lp, P, st, H, sum, sumSq, num, viewBad);
-					if (valid) { pk->part[0][g][v][L.seg] = sum; pk->part[1][g][v][L.seg] = sumSq; pk->part[2][g][v][L.seg] = num; }
+					park_partials<S>(pk, g, v, L.seg, valid, sum, sumSq, num);
 				}
 				issued += (unsigned)n;
 				return;
@@ -761,7 +810,7 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 			if constexpr (NR == 0) score_taps_big<S, LdsStore<S>, false>(c, L, st, H, sum, sumSq, num, viewBad);
 			else score_taps<S, NR, LdsStore<S>, false>(c, L, P, st, H, sum, sumSq, num, viewBad);
 			++issued;
-			pk->part[0][g][L.vloc][L.seg] = sum; pk->part[1][g][L.vloc][L.seg] = sumSq; pk->part[2][g][L.vloc][L.seg] = num;
+			park_partials<S>(pk, g, L.vloc, L.seg, true, sum, sumSq, num);
 		}
 	};
 	if (BIG && P.a > kHalfWindow) {
@@ -782,9 +831,14 @@ __device__ __forceinline__ void score_chunk(const EstConst& c, const LaneCtx<S>&
 #pragma unroll
 		for (int k = 0; k < 3; ++k) {
 			static_assert(S == 8, "tree below is written for 8 lanes per view group");
+#ifdef HCMVS_PARTHALF
+			const float4 a = *(const float4*)&pk->part[k][g][pv][0]; // (l0 + l1, l2 + l3, l4 + l5, l6 + l7)
+			rs[k] = (a.x + a.y) + (a.z + a.w);
+#else
 			const float4* q = (const float4*)&pk->part[k][g][pv][0];
 			const float4 a = q[0], b = q[1];
 			rs[k] = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+#endif
 		}
 		const float Fg = __shfl(F, g * 8, 64);
 		const float s = view_score(c, rs[0], rs[1], rs[2], false, P.invSumW, P.normSq0, Fg);
@@ -817,11 +871,12 @@ __device__ __forceinline__ void random_normal(const PixelGeom& G, float u1, floa
 	dir2normal(p0, p1, n0, n1, n2);
 	if (dot3(n0, n1, n2, G.v0, G.v1, 1.f) > 0.f) { n0 = -n0; n1 = -n1; n2 = -n2; }
 }
-// DepthMap.h:629-634 CorrectNormal + Rotation.inl:707-733 (Rodrigues)
-__device__ __forceinline__ void correct_normal(const PixelGeom& G, float& n0, float& n1, float& n2) {
-	const float v0 = G.v0, v1 = G.v1, v2 = 1.f;
-	const float cosAngLen = dot3(n0, n1, n2, v0, v1, v2);
-	if (!(cosAngLen >= 0.f)) return;
+// DepthMap.h:629-634 CorrectNormal + Rotation.inl:707-733 (Rodrigues).  The rotation runs only for a normal that faces away from the
+// camera -- a wave sees one in well under 1 % of the pixels and branches around the block otherwise (s_cbranch_execz).  Tried in
+// round 4 as a real function (noinline): the call needs a stack (80-144 bytes of scratch per lane) and the caller-saved registers
+// around it spill 4-15 VGPRs in the two-wave / TWO / PACK instances (profiles/r04_sweep_levers.md), so it stays inline
+__device__ __forceinline__ void correct_normal_rotate(float v0, float v1, float cosAngLen, float& n0, float& n1, float& n2) {
+	const float v2 = 1.f;
 	const float a0 = n1 * v2 - n2 * v1, a1 = n2 * v0 - n0 * v2, a2 = n0 * v1 - n1 * v0;
 	const float vlen = sqrtf(dot3(v0, v1, v2, v0, v1, v2));
 	float phi = (pm_acosf(cosAngLen / vlen) - fd2r(90.f)) * 1.01f;
@@ -847,6 +902,10 @@ __device__ __forceinline__ void correct_normal(const PixelGeom& G, float& n0, fl
 	const float r0 = R[0] * n0 + R[1] * n1 + R[2] * n2, r1 = R[3] * n0 + R[4] * n1 + R[5] * n2,
 	            r2 = R[6] * n0 + R[7] * n1 + R[8] * n2;
 	n0 = r0; n1 = r1; n2 = r2;
+}
+__device__ __forceinline__ void correct_normal(const PixelGeom& G, float& n0, float& n1, float& n2) {
+	const float cosAngLen = dot3(n0, n1, n2, G.v0, G.v1, 1.f);
+	if (cosAngLen >= 0.f) correct_normal_rotate(G.v0, G.v1, cosAngLen, n0, n1, n2);
 }
 // DepthMap.cpp:1671-1726 InterpolatePixel (ray-plane form)
 __device__ __forceinline__ float interpolate_pixel(const EstConst& c, const PixelGeom& G, int nx, int ny, float depth,
@@ -1044,7 +1103,9 @@ __device__ __forceinline__ float share_scores(RowShared<NW>& sh, int& par, int l
 // 1484).  Refinement trials depend on earlier accepts: after an accepted trial the later ones are regenerated.
 // TWO: the estimate has 9..16 source views: a second set of eight view groups (L1: views 8..15 in the same lane layout) is
 // scored after the first, and the two best views are taken over both
-template <int S, int NW, bool BIG, bool TWO, bool PACK>
+// HINT: the launch is the sweep in which the `restore` variant offers the up-sampled coarser level as one more hypothesis
+// (EstConst::hintDepth / hintIter); every other launch -- all of BASELINE configs[1] -- runs the instance without that code
+template <int S, int NW, bool BIG, bool TWO, bool PACK, bool HINT>
 __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S>& L, const LaneCtx<S>& L1, RowShared<NW>& sh, int& par, int wv,
                                               int x, int y, int q, int iter, const PixIn<S>& in, const Patch<S>& P,
                                               const LdsStore<S>& st, RowPipe<S>& pp, unsigned& evals, unsigned& issued STAMP_ARGS) {
@@ -1261,7 +1322,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		if (phase == PH_DONE) break;
 	}
 	SUBMARK(blk_pixel_tail)
-	if (c.hintDepth && iter == c.hintIter) {
+	if constexpr (HINT) if (c.hintDepth && iter == c.hintIter) {
 		// restore variant, last sweep of the last outer iteration (restore/libs/MVS/DepthMap.cpp:1527-1549): the estimate of the
 		// up-sampled coarser level is one more hypothesis; it wins even when up to 0.1 worse.  Every wave evaluates it itself.
 		const float hdep = as_global(c.hintDepth)[idx];
@@ -1312,7 +1373,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 #ifndef HCMVS_OCC
 #define HCMVS_OCC 3 // waves per SIMD the register allocation of the 5..8-view sweep worker is held to (diagnostic builds vary it)
 #endif
-template <int S, int NW, bool BIG, bool TWO = false, bool PACK = false>
+template <int S, int NW, bool BIG, bool TWO = false, bool PACK = false, bool HINT = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? HCMVS_OCC : 1, !BIG ? HCMVS_OCC : 2))) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
                                                         int iter, int lag, int affinity) {
 	__shared__ RowShared<NW> sh;
@@ -1426,7 +1487,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			}
 			STAMP(0)
 			const unsigned e0 = evals;
-			process_pixel<S, NW, BIG, TWO, PACK>(c, L, L1, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
+			process_pixel<S, NW, BIG, TWO, PACK, HINT>(c, L, L1, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
 			taps += (unsigned long long)(evals - e0) * (unsigned)((P.a + 1) * (P.a + 1));
 		}
 		if (pp.fail) break;
@@ -1688,7 +1749,7 @@ void launch_score_pass(const EstConst& c, const float* depthIn, const float* nor
 	else launch_score_big<false>(c, evals, s);
 }
 
-template <int NW, bool BIG>
+template <int NW, bool BIG, bool HINT>
 static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int lag,
                             int affinity, hipStream_t s) {
 	// one workgroup per row; rows beyond the resident set are picked up through the ticket
@@ -1699,27 +1760,39 @@ static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int
 	// (hypothesis, view) pairs of their own (score_chunk PACK; with one idle group it costs more than it saves)
 	const bool pack = V % 8 != 0 && V % 8 != 7;
 	if (V <= 8) {
-		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
-		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, true>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
+		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, false, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
+		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, true, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
 	} else {
-		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
-		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, true>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
+		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, false, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
+		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, true, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
 	}
 
 }
-void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int lag,
-                  int wavesPerRow, int affinity, hipStream_t s) {
+template <bool HINT>
+static void launch_sweep_hint(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int lag,
+                              int wavesPerRow, int affinity, hipStream_t s) {
 	if (bigPatch) { // patches beyond 64 taps: one or two waves per row
-		if (wavesPerRow >= 2) launch_sweep_nw<2, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s);
-		else launch_sweep_nw<1, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s);
+		if (wavesPerRow >= 2) launch_sweep_nw<2, true, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s);
+		else launch_sweep_nw<1, true, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s);
+		return;
+	}
+	if constexpr (HINT) { // the one sweep of a run that carries the hint: one or two waves per row
+		if (wavesPerRow >= 2) launch_sweep_nw<2, false, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s);
+		else launch_sweep_nw<1, false, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s);
 		return;
 	}
 	switch (wavesPerRow) {
-	case 1: launch_sweep_nw<1, false>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
-	case 3: launch_sweep_nw<3, false>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
-	case 4: launch_sweep_nw<4, false>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
-	default: launch_sweep_nw<2, false>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
+	case 1: launch_sweep_nw<1, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
+	case 3: launch_sweep_nw<3, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
+	case 4: launch_sweep_nw<4, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
+	default: launch_sweep_nw<2, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
 	}
+}
+// hint: some item of the batch offers the `restore` variant's extra hypothesis in THIS sweep (EstConst::hintDepth, hintIter == iter)
+void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, bool hint, const SweepSync& sync, int iter, int lag,
+                  int wavesPerRow, int affinity, hipStream_t s) {
+	if (hint) launch_sweep_hint<true>(dItems, nItems, maxRows, totalRows, V, bigPatch, sync, iter, lag, wavesPerRow, affinity, s);
+	else launch_sweep_hint<false>(dItems, nItems, maxRows, totalRows, V, bigPatch, sync, iter, lag, wavesPerRow, affinity, s);
 }
 
 void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s) {

@@ -154,13 +154,20 @@ def test_densify_driver_coarse_to_fine_handoff(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "read  :" in r.stdout
+    assert mvsio.read_dmap(os.path.join(tmp, "depth0000.dmap"))["d_min"] == 0.0   # the reference's range rule: zeros included
     handoff = _accuracy(tmp, views)
     # the same single fine sweep started from the triangulated sparse points
     r = subprocess.run([EXE, "-i", scene, "--resolution-level", "0", "--n-initTriangulate", "1", "--n-EstimationIters", "1"] + common,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     tri = _accuracy(tmp, views)
-    assert handoff is not None and handoff > 0.7 and handoff >= tri - 0.02
+    # The depth range of a handed-over map follows the reference (SceneDensify.cpp:544-553): minimum and maximum over EVERY value of the
+    # map, its empty pixels (0) included, so the lower bound is 0.  Depth 0 then counts as "inside the range"
+    # in the init pass (SceneDensify.cpp:660-664) and the empty pixels are left to the sweeps' propagation / full-random branch instead
+    # of being re-seeded at once -- after ONE fine sweep the hand-off is therefore a few points behind the triangulated start
+    # (measured 0.83 vs 0.87; with the valid-depths-only range of rounds 2-3 it was level).  Bounded from below, not required to win.
+    assert handoff is not None and handoff > 0.7 and handoff >= tri - 0.06
+    assert mvsio.read_dmap(os.path.join(tmp, "depth0000.dmap"))["d_max"] > 0    # (the file holds the triangulated run's range by now)
     # the hand-off pair the next stage of run.sh moves (DepthMap.h:76-80, SceneDensify.cpp:3984-3988) is written beside depth%04u.dmap
     hd = mvsio.read_dmap(os.path.join(tmp, "depthmap", "depth0000.dmap"))
     assert hd["depth"].shape == (256, 384) and "normal" not in hd and np.array_equal(hd["depth"], mvsio.read_dmap(os.path.join(tmp, "depth0000.dmap"))["depth"])
