@@ -157,10 +157,98 @@ def fuse_throughput(ctx, views, pts, dev):
             got = ctx.fuse([9000 + i for i in range(n)], HW * n // 2)
             dt = time.perf_counter() - t0
             if best is None or dt < best[0]:
-                best = (dt, got["n_points"], got["n_depths"])
-        dt, npts, ndep = best
+                best = (dt, got["n_points"], got["n_depths"], int(got["n_views"].astype(np.int64).sum()) - int(got["n_points"]))
+        dt, npts, ndep, nmerged = best
         out[name] = {"points_per_s": round(npts / dt), "depths_per_s": round(ndep / dt), "ms": round(dt * 1e3, 2), "points": int(npts)}
+        if mode == 0:
+            # algorithmic bytes per reference pixel = 20 B own + per neighbour 4 B depth + 4 B claim index, + on
+            # agreement 12 B normal + 4 B conf + 3 B colour.  The fusion is a chain of >= 12 small launches per image plus the copy of
+            # the cloud to the caller's (pageable) host buffers: latency-bound, nowhere near the HBM roofline -- the fraction says so.
+            alg = ndep * (20.0 + (n - 1) * 8.0) + nmerged * 19.0
+            cloud_bytes = npts * 31                                # xyz 12 + normal 12 + colour 3 + view count 4
+            probe = torch.empty(max(cloud_bytes, 1), dtype=torch.uint8, device=dev)
+            host = np.empty(max(cloud_bytes, 1), np.uint8)         # pageable, like the caller's arrays
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); host[...] = probe.cpu().numpy(); d2h = time.perf_counter() - t0
+            out["roofline"] = {"kernel": "FuseDepthMaps (fuse_begin / settle / apply / points / compaction kernels, %d images)" % n, "bound": "latency",
+                               "achieved": round(alg / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4),
+                               "algorithmic_bytes": int(alg), "ms": round(dt * 1e3, 2),
+                               "d2h_cloud_bytes": int(cloud_bytes), "d2h_ms_probe": round(d2h * 1e3, 2), "d2h_share": round(min(1.0, d2h / dt), 3),
+                               "note": "SURVEY.md 8d bytes (20 + N_nb x 8 per valid depth, + 19 per merged estimate) over the wall time of hcmvs_fuse incl. the copy of "
+                                       "the cloud to pageable host memory (d2h_ms_probe: a copy of the same size timed alone); >= 12 dependent launches per image"}
     ctx.set_fuse_order(0)
+    return out
+
+
+AUTHORS = dict(batch=16, n_src=10, ahw=7, sweeps=3, outer=4, prop_halfwin=5, prop_step=4, photometric_flow=0.26)
+
+
+def authors_config(ctx, dev, pmc=True):
+    """The reference authors' own settings (data/frame_main/resize3/run.py:35-78: --number-views 10, --n-adapthalfwin 7, 4 outer x 3 inner
+    sweeps, cross pattern 5 / 4, photometric_flow 0.26) as a batch of 16 reference images of 1920x1080: outer iteration 1 (the first with
+    the cross pattern) is timed, after an untimed outer iteration 0 produced its input maps.  This is the TWO + PACK instance of the sweep
+    kernel (two sets of eight view groups, idle groups take pairs of their own), which the headline configuration never runs."""
+    import numpy as np
+    import torch
+    binding = importlib.import_module("hc-mvs_amd.binding")
+    synth = importlib.import_module("hc-mvs_amd.synth")
+    A = AUTHORS
+    B, V, HW = A["batch"], A["n_src"], H * W
+    work = torch.empty(B, 5 * HW, dtype=torch.float32, device=dev)
+    items, keep, scenes = [], [], {}
+    for b_ in range(B):
+        if b_ % 2 not in scenes:                       # two distinct scenes; every unit has its own copy of images and maps in HBM
+            vs = synth.make_views(W, H, FOCAL, V, seed=40 + b_ % 2)
+            scenes[b_ % 2] = (vs, synth.sparse_points(vs, 2000, seed=45 + b_ % 2))
+        views, pts = scenes[b_ % 2]
+        slab = torch.from_numpy(np.stack([v["gray"] for v in views])).to(dev)
+        keep.append(slab)
+        for i, v in enumerate(views):
+            ctx.set_view_device(20000 + 100 * b_ + i, W, H, slab[i].data_ptr(), v["K"], v["R"], v["C"])
+        ctx.shapes[20000 + 100 * b_] = (H, W)
+        d0, n0, dmin, dmax = ctx.splat_init(20000 + 100 * b_, pts)
+        work[b_, :HW] = torch.from_numpy(d0).reshape(-1).to(dev); work[b_, HW:4 * HW] = torch.from_numpy(n0).reshape(-1).to(dev); work[b_, 4 * HW:] = 0
+        base = work[b_].data_ptr()
+        items.append(dict(ref_id=20000 + 100 * b_, src_ids=[20000 + 100 * b_ + i for i in range(1, V + 1)], d_min=dmin, d_max=dmax, d_depth=base,
+                          d_normal=base + 4 * HW, d_conf=base + 16 * HW, seed_offset=b_))
+    kw = dict(adapthalfwin=A["ahw"], n_estimation_iters=A["sweeps"], n_external_iters=A["outer"], propagate_halfwin=A["prop_halfwin"],
+              propagate_step=A["prop_step"], photometric_flow=A["photometric_flow"], seed=4321)
+    torch.cuda.synchronize()
+    ctx.estimate_batch_device(items, binding.default_params(it_external=0, **kw))
+    ctx.synchronize()
+    after0 = work.clone()
+    best = None
+    for _ in range(2):
+        work.copy_(after0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.estimate_batch_device(items, binding.default_params(it_external=1, **kw))
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        st = ctx.stats()
+        if best is None or st.ms_sweep_avg < best[0]:
+            best = (st.ms_sweep_avg, dt, st.ms_total, st.evals, st.evals_issued)
+    ms_sweep, dt, ms_total, evals, issued = best
+    P = (W - 14) * (H - 14)
+    out = {"workload": "batch of %d reference images x %d source views, 1920x1080, 8x8 taps (adapthalfwin 7), outer iteration 1 of 4 (cross pattern %d / %d), "
+                       "%d sweeps, photometric_flow %.2f" % (B, V, A["prop_halfwin"], A["prop_step"], A["sweeps"], A["photometric_flow"]),
+           "kernel": "sweep_kernel<8,1,false,TWO,PACK>", "sweep_launch_ms": round(ms_sweep, 3), "Mpix_s_per_sweep": round(B * W * H / ms_sweep / 1e3, 2),
+           "estimate_ms": round(ms_total, 2), "Mpix_s_outer_iteration": round(B * W * H / dt / 1e6, 3),
+           "evals_per_pixel_sweep": round((evals / (B * P) - 1) / A["sweeps"], 3), "evals_issued_per_pixel_sweep": round((issued / (B * P) - 1) / A["sweeps"], 3)}
+    if pmc:
+        live = live_pmc(B, kernel="sweep_kernel<8, 1, false, true, true", extra=["--authors-only"], sets=(("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"),),
+                        need=("SQ_INSTS_VALU",))
+        if live:
+            t = ms_sweep * 1e-3
+            out["valu"] = {"insts_per_launch": int(live["SQ_INSTS_VALU"]), "insts_per_pixel_sweep": round(live["SQ_INSTS_VALU"] / (B * P), 1),
+                           "frac": round(live["SQ_INSTS_VALU"] / t / VALU_PEAK_INSTS, 4),
+                           "busy_frac_rocprof_4_cycles": round(live.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (N_SIMD * CLOCK_HZ * t), 4),
+                           "counter_source": "rocprofv3 --pmc child run of `bench.py --authors-only`, now"}
+        else:
+            out["valu"] = None
+    for b_ in range(B):
+        for i in range(V + 1):
+            ctx.release_view(20000 + 100 * b_ + i)
     return out
 
 
@@ -192,7 +280,8 @@ def pmc_value(batch, what):
         return None
 
 
-def live_pmc(batch, timeout_s=150):
+def live_pmc(batch, timeout_s=150, kernel=None, extra=(), sets=(("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU")),
+             need=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")):
     """HBM traffic and VALU instruction counters of the sweep kernel, measured NOW: one `rocprofv3 --pmc` child run of this same
     command (one step, same batch) per counter set, collected the way MI355X_MICROARCH.md prescribes (separate --pmc passes, no
     trace domain beside them).  The children are ordinary subprocesses; this process only waits.  Returns {counter: mean per
@@ -205,14 +294,14 @@ def live_pmc(batch, timeout_s=150):
         return None
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["TMPDIR"] = "/tmp"
-    kernel = "sweep_kernel<8, %d" % (1 if batch >= 3 else 2)   # waves per row the library picks
+    kernel = kernel or "sweep_kernel<8, %d" % (1 if batch >= 3 else 2)   # waves per row the library picks
     tmp = tempfile.mkdtemp(prefix="hcmvs_pmc_", dir="/tmp")
     res = {}
     try:
-        for i, cs in enumerate((("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"))):
+        for i, cs in enumerate(sets):
             d = os.path.join(tmp, "p%d" % i)
             cmd = [exe, "--pmc", *cs, "--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py"), "--steps", "1",
-                   "--warmup", "0", "--batch", str(batch), "--no-cpu-baseline", "--no-fuse", "--no-pmc"]
+                   "--warmup", "0", "--batch", str(batch), "--no-cpu-baseline", "--no-fuse", "--no-pmc", "--no-authors", *extra]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             if r.returncode != 0:
                 return None
@@ -228,7 +317,7 @@ def live_pmc(batch, timeout_s=150):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return res if all(k in res for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")) else None
+    return res if all(k in res for k in need) else None
 
 
 def main():
@@ -239,6 +328,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="independent reference images per step and GPU (1..64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse", action="store_true", help="skip the FuseDepthMaps points/s figure")
+    ap.add_argument("--no-authors", action="store_true", help="skip the authors_config figure (10 views, 8x8 taps, cross pattern: the TWO + PACK kernel)")
+    ap.add_argument("--authors-only", action="store_true", help="run only the authors_config workload (what its rocprofv3 child run executes)")
     ap.add_argument("--no-pmc", action="store_true", help="take roofline.traffic / the VALU counters from profiles/ instead of measuring them "
                                                           "in rocprofv3 --pmc child runs")
     args = ap.parse_args()
@@ -277,6 +368,10 @@ def main():
     ctx = binding.Context(local_rank)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
+    if args.authors_only:
+        print(json.dumps({"authors_config": authors_config(ctx, dev, pmc=False)}), flush=True)
+        ctx.close()
+        return
     HW = H * W
     params = binding.default_params(adapthalfwin=AHW, n_estimation_iters=SWEEPS, it_external=0, n_external_iters=1,
                                     seed=1234)
@@ -362,7 +457,7 @@ def main():
                                    "(adapthalfwin 6), 8 sweeps, it_external 0, full EstimateDepthMap (median + init score + "
                                    "sweeps + end pass)" % B,
                        "units_per_step": "%d reference images per GPU (%d px each)" % (B, W * H), "batch": B,
-                       "exchange": "RCCL all-gather of 20 B/px maps per step" if world > 1 else "none",
+                       "exchange": ("%s all-gather of 20 B/px maps per step" % ("RCCL" if backend == "nccl" else backend + " (rehearsal, not a measurement)")) if world > 1 else "none",
                        "evals_per_pixel_sweep": round((st.evals / (B * P) - 1) / SWEEPS, 3)},
             "per_gpu": round(B * W * H * args.steps / dt / 1e6, 4),
             "single_unit": {"ms": round(single_ms, 2), "Mpix/s": round(W * H / single_ms / 1e3, 3)},
@@ -424,6 +519,8 @@ def main():
                                        "avg_launch_ms": round(st1.ms_sweep_avg, 3), "estimate_ms": round(st1.ms_total, 2)}
         if world == 1 and not args.no_fuse:
             out["fuse"] = fuse_throughput(ctx, scenes[0][0], scenes[0][1], dev)
+        if world == 1 and not args.no_authors:
+            out["authors_config"] = authors_config(ctx, dev, pmc=not args.no_pmc)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_cores())   # every host core this process may use
         print(json.dumps(out), flush=True)

@@ -70,6 +70,8 @@ struct Options { // DensifyPointCloud.cpp:139-198 (defaults from there)
 	int restoreHypothesis = 0;    // 1: the `restore` binary's extra last-sweep hypothesis from the previous level's maps
 	                              // (restore/libs/MVS/DepthMap.cpp:1527-1549); needs the previous level's maps in the working folder
 	int device = 0, batch = 32;   // reference images per launch: 32 is the measured optimum (profiles/r02_knobs.txt); lowered when HBM is short
+	std::vector<int> devices;     // --devices 0,1,...: one context + host thread per entry; reference images sharded over them by their position in
+	                              // the fusion order (k mod N); post-filters and fusion on the first (an ordinal may repeat: two contexts on one GPU)
 	uint32_t seed = 1234;
 };
 
@@ -89,7 +91,9 @@ struct ImageData {
 	std::vector<float> srcScale;                // per source view: 1 or the scale it is resampled by (ViewData::ScaleImage)
 	std::vector<uint32_t> srcImages;            // the scene images behind srcs
 	float dMin = 0, dMax = 0;
-	float *dDepth = nullptr, *dNormal = nullptr, *dConf = nullptr; // device maps
+	int dev = 0;                                                    // index of the device context that estimates this image (--devices)
+	float *dDepth = nullptr, *dNormal = nullptr, *dConf = nullptr; // device maps, on the owner's device
+	float *gDepth = nullptr, *gNormal = nullptr, *gConf = nullptr; // the copy on the first device, where the post-filters and the fusion run (== d* when dev == 0)
 	float *dHintDepth = nullptr, *dHintNormal = nullptr;            // previous level's maps, resized (restore variant)
 };
 struct Vertex { float X[3]; std::vector<std::pair<uint32_t, float>> views; };
@@ -584,7 +588,7 @@ int main(int argc, char** argv) {
 		"--n-usegeoconsistency", "--n-initTriangulate", "--n-viewspread", "--n-opticalflow", "--n-adapthalfwin",
 		"--n-propagatehalfwin", "--n-propagatestep",
 		// this driver's own
-		"--min-views-trust-point", "--fuse-order", "--device", "--batch", "--seed", "--restore-hypothesis", "--n-postfilter", "--n-postfilter-interleave", "--resume"};
+		"--min-views-trust-point", "--fuse-order", "--device", "--devices", "--batch", "--seed", "--restore-hypothesis", "--n-postfilter", "--n-postfilter-interleave", "--resume"};
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i], val;
 		if (a == "-h" || a == "--help") { kv["--help"] = "1"; continue; }
@@ -614,6 +618,16 @@ int main(int argc, char** argv) {
 	geti("--n-initTriangulate", o.initTriangulate); geti("--min-views-trust-point", o.minViewsTrustPoint);
 	geti("--fuse-order", o.fuseOrder); geti("--restore-hypothesis", o.restoreHypothesis); geti("--n-postfilter", o.postFilter); geti("--n-postfilter-interleave", o.postFilterInterleave); geti("--n-nOptimize", o.nOptimize); geti("--resume", o.resume);
 	geti("--device", o.device); geti("--batch", o.batch);
+	if (kv.count("--devices")) { // comma-separated HIP ordinals
+		std::stringstream ss(kv["--devices"]);
+		std::string tok;
+		while (std::getline(ss, tok, ',')) {
+			if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) { fprintf(stderr, "error: --devices expects a comma-separated list of device ordinals\n"); return EXIT_FAILURE; }
+			o.devices.push_back(atoi(tok.c_str()));
+		}
+		if (o.devices.empty() || o.devices.size() > 64) { fprintf(stderr, "error: --devices expects 1 to 64 device ordinals\n"); return EXIT_FAILURE; }
+	} else o.devices.push_back(o.device);
+	o.device = o.devices[0];
 	if (kv.count("--seed")) o.seed = (uint32_t)strtoul(kv["--seed"].c_str(), nullptr, 10);
 	geti("--estimate-colors", o.estimateColors); geti("--estimate-normals", o.estimateNormals);
 	geti("--max-resolution", o.maxResolution); geti("--min-resolution", o.minResolution);
@@ -638,10 +652,13 @@ int main(int argc, char** argv) {
 	if (o.batch > HCMVS_MAX_BATCH) o.batch = HCMVS_MAX_BATCH;
 	if (o.estimationItersExternal < 1) o.estimationItersExternal = 1;
 
-	// the device context comes up (HIP runtime start, ~0.4 s) while the scene is read and the views are selected on the host
-	hcmvs_ctx* ctx = nullptr;
-	int createRc = HCMVS_OK;
-	std::thread createThread([&] { createRc = hcmvs_create(o.device, &ctx); });
+	// the device contexts come up (HIP runtime start, ~0.4 s) while the scene is read and the views are selected on the host.
+	// One context and, later, one host thread per entry of --devices; devs[0] is where the post-filters and the fusion run.
+	struct DeviceCtx { int ordinal = 0; hcmvs_ctx* ctx = nullptr; int createRc = HCMVS_OK; std::mutex upMu; std::vector<uint32_t> work; };
+	std::vector<DeviceCtx> devs(o.devices.size());
+	for (size_t d = 0; d < devs.size(); ++d) devs[d].ordinal = o.devices[d];
+	const int nDev = (int)devs.size();
+	std::thread createThread([&] { for (auto& d : devs) d.createRc = hcmvs_create(d.ordinal, &d.ctx); });
 	struct CreateJoin { std::thread& t; ~CreateJoin() { if (t.joinable()) t.join(); } } createJoin{createThread};
 	std::vector<MvsPlatform> platforms; std::vector<MvsImage> mimages; std::vector<Vertex> verts;
 	if (!load_mvs(o.input, platforms, mimages, verts)) { fprintf(stderr, "error: can not load '%s'\n", o.input.c_str()); return EXIT_FAILURE; }
@@ -685,7 +702,11 @@ int main(int argc, char** argv) {
 	// AFTER the loader thread below has started: the triangulated initial maps need cameras and sparse points only, so the first
 	// batch's initialisation overlaps the decoding.
 	std::string loadError;
-	std::mutex upMu;
+	std::mutex errMu;
+	// which device needs the gray image of which scene image (its own reference images and their source views); filled in once the
+	// images are assigned to the devices, before load_images() runs.  The first device also gets camera + colour image of every
+	// other image (a fuse-only view: hcmvs_upload_view with gray = NULL), because it filters and fuses the whole scene.
+	std::vector<std::vector<char>> needGray(devs.size(), std::vector<char>(images.size(), 1));
 	auto load_images = [&]() {
 		const long N = (long)images.size();
 #pragma omp parallel for schedule(dynamic, 1)
@@ -694,7 +715,7 @@ int main(int argc, char** argv) {
 			if (!im.valid) continue;
 			int fw = 0, fh = 0;
 			std::vector<uint8_t> bgr;
-			if (!load_pnm(paths[t], fw, fh, bgr)) { std::lock_guard<std::mutex> g(upMu); loadError = "failed loading image '" + paths[t] + "'"; continue; }
+			if (!load_pnm(paths[t], fw, fh, bgr)) { std::lock_guard<std::mutex> g(errMu); loadError = "failed loading image '" + paths[t] + "'"; continue; }
 			if (fw != im.w || fh != im.h) resize_area_bgr(fw, fh, bgr, im.w, im.h);
 			// gray and colour image go into page-locked memory of this thread: what is left for the (serial) upload is the transfer
 			static thread_local struct Pinned { char* p = nullptr; size_t cap = 0; } pin; // lives as long as its thread; the process ends with them
@@ -702,7 +723,7 @@ int main(int argc, char** argv) {
 			if (pin.cap < need) {
 				if (pin.p) (void)hipHostFree(pin.p);
 				pin.p = nullptr; pin.cap = 0;
-				if (hipSetDevice(o.device) == hipSuccess && hipHostMalloc((void**)&pin.p, need, hipHostMallocDefault) == hipSuccess) pin.cap = need;
+				if (hipSetDevice(o.device) == hipSuccess && hipHostMalloc((void**)&pin.p, need, hipHostMallocPortable) == hipSuccess) pin.cap = need;
 				else { (void)hipGetLastError(); pin.p = nullptr; }
 			}
 			std::vector<float> grayVec;
@@ -712,14 +733,23 @@ int main(int argc, char** argv) {
 			else memcpy(bgrUp, bgr.data(), px * 3);
 			for (size_t k = 0; k < px; ++k) // Types.inl:2354-2400 toGray, normalised
 				gray[k] = (0.114f * bgr[3 * k] + 0.587f * bgr[3 * k + 1] + 0.299f * bgr[3 * k + 2]) / 255.f;
-			std::lock_guard<std::mutex> g(upMu); // one HIP stream: uploads one after the other, while the other cores decode
-			if (hcmvs_upload_view(ctx, im.id, im.w, im.h, gray, bgrUp, im.cam.K, im.cam.R, im.cam.C) != HCMVS_OK && loadError.empty())
-				loadError = std::string("upload of image '") + paths[t] + "' failed: " + hcmvs_last_error(ctx);
+			for (size_t d = 0; d < devs.size(); ++d) {
+				const bool g = needGray[d][(size_t)t] != 0;
+				if (!g && d != 0) continue; // this device never touches the image
+				std::lock_guard<std::mutex> lk(devs[d].upMu); // one HIP stream per context: uploads one after the other, while the other cores decode
+				if (hcmvs_upload_view(devs[d].ctx, im.id, im.w, im.h, g ? gray : nullptr, bgrUp, im.cam.K, im.cam.R, im.cam.C) != HCMVS_OK) {
+					std::lock_guard<std::mutex> e(errMu);
+					if (loadError.empty()) loadError = std::string("upload of image '") + paths[t] + "' failed: " + hcmvs_last_error(devs[d].ctx);
+				}
+			}
 		}
 	};
 	createThread.join();
-	if (createRc != HCMVS_OK) { fprintf(stderr, "error: no usable MI355X device (there is no CPU path)\n"); return EXIT_FAILURE; }
+	for (auto& d : devs)
+		if (d.createRc != HCMVS_OK) { fprintf(stderr, "error: device %d is not a usable MI355X (there is no CPU path)\n", d.ordinal); return EXIT_FAILURE; }
+	hcmvs_ctx* ctx = devs[0].ctx; // the context of the post-filters and the fusion
 	if (hipSetDevice(o.device) != hipSuccess) { fprintf(stderr, "error: hipSetDevice failed\n"); return EXIT_FAILURE; }
+	if (nDev > 1 && o.postFilterInterleave) { fprintf(stderr, "error: --n-postfilter-interleave 1 estimates one image at a time and runs on one device (drop --devices)\n"); return EXIT_FAILURE; }
 	std::vector<uint32_t> todo;
 	for (auto& im : images) {
 		if (!im.valid) continue;
@@ -743,15 +773,57 @@ int main(int argc, char** argv) {
 	prm.adapthalfwin = o.adaptHalfWin; prm.n_estimation_iters = o.estimationIters; prm.n_external_iters = o.estimationItersExternal;
 	prm.propagate_halfwin = o.propagateHalfWin; prm.propagate_step = o.propagateStep; prm.photometric_flow = o.photometricFlow; prm.seed = o.seed;
 
-	// the batch size the device memory allows: per image of a batch the working state (24 B/px) on top of what stays resident per
-	// image (maps 20 B/px, hint maps 16 B/px, gray + colour + gradient 8 B/px, source footprints 16 B/px)
+	// the order of the fusion and of the post-filters' fusion: best connected images first (SceneDensify.cpp:3285-3302).  It also
+	// deals the reference images to the devices: position k of it goes to device k mod N, so that the devices
+	// are loaded alike.  A device holds the gray image of its own reference images and of their source views only.
+	std::vector<uint32_t> fuseOrder(todo);
+	std::stable_sort(fuseOrder.begin(), fuseOrder.end(), [&](uint32_t a, uint32_t b) { return images[a].neighbors.size() > images[b].neighbors.size(); });
+	for (size_t k = 0; k < fuseOrder.size(); ++k) images[fuseOrder[k]].dev = (int)(k % (size_t)nDev);
+	if (nDev > 1) {
+		for (auto& v : needGray) std::fill(v.begin(), v.end(), 0);
+		for (uint32_t id : todo) {
+			needGray[(size_t)images[id].dev][id] = 1;
+			for (uint32_t s : images[id].srcs) needGray[(size_t)images[id].dev][s] = 1; // (srcs still holds scene image ids here)
+		}
+	}
+
+	// What has to fit into a device (bytes per pixel of an image): resident per reference image of the device -- maps 20, hint maps 16
+	// (restore variant), gray + colour + gradient 8; per source view the 2 x 2 footprints 16; per image of a batch the working state 24.
+	// The first device also holds colour + gradient (4) and, with several devices, a copy of the maps (20) of EVERY image, the per-pass
+	// tables of the fusion (12 B per pixel and neighbour of the largest image + 40 B per pixel) and the device copy of the cloud
+	// (about half a point per pixel: 31 B, + 8 B per view entry).  The batch shrinks until the first device fits; a scene that does
+	// not fit at one image per launch is refused here, before anything is uploaded (DESIGN.md section 4 has configs[3] in numbers).
 	{
-		size_t freeB = 0, totalB = 0, maxPx = 0, allPx = 0;
-		HIPOK(hipMemGetInfo(&freeB, &totalB));
+		size_t maxPx = 0, allPx = 0;
 		for (uint32_t id : todo) { const size_t px = (size_t)images[id].w * images[id].h; maxPx = std::max(maxPx, px); allPx += px; }
-		const size_t resident = allPx * (size_t)(20 + 16 + 8 + (o.restoreHypothesis ? 16 : 0)) + ((size_t)2 << 30); // nothing is uploaded yet
-		while (o.batch > 1 && resident + (size_t)o.batch * maxPx * 24 > freeB) o.batch /= 2;
-		if (o.verbosity > 2) printf("Batch of %d reference images per launch (%.1f GiB of device memory free)\n", o.batch, freeB / 1073741824.0);
+		for (int d = 0; d < nDev; ++d) {
+			size_t freeB = 0, totalB = 0;
+			HIPOK(hipSetDevice(devs[(size_t)d].ordinal));
+			HIPOK(hipMemGetInfo(&freeB, &totalB));
+			size_t ownPx = 0, grayPx = 0;
+			for (uint32_t id : todo) if (images[id].dev == d) ownPx += (size_t)images[id].w * images[id].h;
+			for (size_t i = 0; i < images.size(); ++i) if (images[i].valid && needGray[(size_t)d][i]) grayPx += (size_t)images[i].w * images[i].h;
+			size_t resident = ownPx * (size_t)(20 + (o.restoreHypothesis ? 16 : 0)) + grayPx * (size_t)(8 + 16) + ((size_t)1 << 30);
+			if (d == 0) {
+				size_t maxNb = 1;
+				for (uint32_t id : todo) maxNb = std::max(maxNb, std::min<size_t>(images[id].neighbors.size(), 31));
+				resident += allPx * 4 + (nDev > 1 ? allPx * 20 : 0) + maxPx * (12 * maxNb + 40);
+				if (o.fusionMode != 1) resident += allPx / 2 * 31 + allPx * 8;
+			}
+			int batch = o.batch;
+			while (batch > 1 && resident + (size_t)batch * maxPx * 24 > freeB) batch /= 2;
+			if (resident + (size_t)batch * maxPx * 24 > freeB) {
+				fprintf(stderr, "error: the scene does not fit device %d: %.1f GiB needed for its share (%zu of %zu images; maps, images, source footprints%s), "
+				                "%.1f GiB free.  Use more devices (--devices), a coarser --resolution-level or fewer --number-views\n",
+				        devs[(size_t)d].ordinal, (resident + (size_t)batch * maxPx * 24) / 1073741824.0, (size_t)std::count_if(todo.begin(), todo.end(), [&](uint32_t id) { return images[id].dev == d; }),
+				        todo.size(), d == 0 ? ", the whole scene's maps, fusion tables and cloud" : "", freeB / 1073741824.0);
+				return EXIT_FAILURE;
+			}
+			o.batch = std::min(o.batch, batch);
+			if (o.verbosity > 2) printf("Device %d (context %d of %d): %.1f GiB resident + %.1f GiB per batch of %d, %.1f GiB free\n", devs[(size_t)d].ordinal, d, nDev,
+			                            resident / 1073741824.0, (size_t)batch * maxPx * 24 / 1073741824.0, batch, freeB / 1073741824.0);
+		}
+		HIPOK(hipSetDevice(o.device));
 	}
 
 	// skip-if-exists resume (SceneDensify.cpp:3865-3880: "try to load already compute depth-map for this image"): an image whose
@@ -761,7 +833,7 @@ int main(int argc, char** argv) {
 	for (uint32_t id : todo) {
 		DmapFile hdr;
 		if (o.resume && load_dmap(map_path(o.workdir, "/depth%04u.dmap", id), hdr, 7, true) && hdr.w == images[id].w && hdr.h == images[id].h) resumed[id] = 1;
-		else work.push_back(id);
+		else { work.push_back(id); devs[(size_t)images[id].dev].work.push_back(id); }
 	}
 	for (uint32_t id : todo) {
 		if (!resumed[id]) continue;
@@ -770,20 +842,32 @@ int main(int argc, char** argv) {
 		if (!load_dmap(map_path(o.workdir, "/depth%04u.dmap", id), m, 7)) { fprintf(stderr, "error: invalid depth-map '%s'\n", map_path(o.workdir, "/depth%04u.dmap", id).c_str()); return EXIT_FAILURE; }
 		const size_t n = (size_t)im.w * im.h;
 		im.dMin = m.dMin; im.dMax = m.dMax;
+		HIPOK(hipSetDevice(devs[(size_t)im.dev].ordinal));
 		HIPOK(hipMalloc(&im.dDepth, n * 4)); HIPOK(hipMalloc(&im.dNormal, n * 12)); HIPOK(hipMalloc(&im.dConf, n * 4));
 		HIPOK(hipMemcpy(im.dDepth, m.d.data(), n * 4, hipMemcpyHostToDevice)); HIPOK(hipMemcpy(im.dNormal, m.n.data(), n * 12, hipMemcpyHostToDevice));
 		HIPOK(hipMemcpy(im.dConf, m.c.data(), n * 4, hipMemcpyHostToDevice));
 		if (o.verbosity > 1) printf("Depth-map for image %3u loaded from '%s' (not estimated again)\n", id, map_path(o.workdir, "/depth%04u.dmap", id).c_str());
 	}
+	HIPOK(hipSetDevice(o.device));
 
-	// batches: images of one lane layout class (up to 8 source views, or 9..16) share a launch
-	std::vector<std::vector<uint32_t>> batches;
+	// batches: images of one device and one lane layout class (up to 8 source views, or 9..16) share a launch.  The loader serves the
+	// devices in turn (first batch of every device first).
+	struct Batch { int dev; std::vector<uint32_t> ids; };
+	std::vector<Batch> batches;
 	{
-		std::map<int, std::vector<uint32_t>> byClass;
-		for (uint32_t id : work) byClass[images[id].srcs.size() <= 8 ? 8 : 16].push_back(id);
-		for (auto& g : byClass)
-			for (size_t b0 = 0; b0 < g.second.size(); b0 += (size_t)o.batch)
-				batches.emplace_back(g.second.begin() + (long)b0, g.second.begin() + (long)std::min(g.second.size(), b0 + (size_t)o.batch));
+		std::vector<std::vector<Batch>> perDev((size_t)nDev);
+		for (int d = 0; d < nDev; ++d) {
+			std::map<int, std::vector<uint32_t>> byClass;
+			for (uint32_t id : devs[(size_t)d].work) byClass[images[id].srcs.size() <= 8 ? 8 : 16].push_back(id);
+			for (auto& g : byClass)
+				for (size_t b0 = 0; b0 < g.second.size(); b0 += (size_t)o.batch)
+					perDev[(size_t)d].push_back(Batch{d, std::vector<uint32_t>(g.second.begin() + (long)b0, g.second.begin() + (long)std::min(g.second.size(), b0 + (size_t)o.batch))});
+		}
+		for (size_t k = 0;; ++k) {
+			bool any = false;
+			for (int d = 0; d < nDev; ++d) if (k < perDev[(size_t)d].size()) { batches.push_back(perDev[(size_t)d][k]); any = true; }
+			if (!any) break;
+		}
 	}
 
 	// ---- the loader: initial maps of batch k + 1 while batch k is estimated (outer iteration 0) ----
@@ -806,11 +890,16 @@ int main(int argc, char** argv) {
 		return load_dmap(map_path(o.workdir, "/depth%04u.dmap", id), out, 3);
 	};
 	auto loader = [&]() {
-		if (hipSetDevice(o.device) != hipSuccess) { std::lock_guard<std::mutex> g(prepMu); prepError = "hipSetDevice failed in the loader"; prepCv.notify_all(); return; }
-		Uploader up; // page-locked staging: a pageable hipMemcpy of the initial maps (33 MB per 1080p image) crawls
-		if (!up.init()) { std::lock_guard<std::mutex> g(prepMu); prepError = "no copy stream for the loader"; prepCv.notify_all(); return; }
+		// page-locked staging, one copy stream per device: a pageable hipMemcpy of the initial maps (33 MB per 1080p image) crawls
+		std::vector<std::unique_ptr<Uploader>> ups((size_t)nDev);
+		for (int d = 0; d < nDev; ++d) {
+			ups[(size_t)d].reset(new Uploader);
+			if (hipSetDevice(devs[(size_t)d].ordinal) != hipSuccess || !ups[(size_t)d]->init()) { std::lock_guard<std::mutex> g(prepMu); prepError = "no copy stream for the loader"; prepCv.notify_all(); return; }
+		}
 		for (size_t b = 0; b < batches.size(); ++b) {
-			const std::vector<uint32_t>& ids = batches[b];
+			const std::vector<uint32_t>& ids = batches[b].ids;
+			Uploader& up = *ups[(size_t)batches[b].dev];
+			if (hipSetDevice(devs[(size_t)batches[b].dev].ordinal) != hipSuccess) { std::lock_guard<std::mutex> g(prepMu); prepError = "hipSetDevice failed in the loader"; prepCv.notify_all(); return; }
 			std::vector<InitMaps> maps(ids.size());
 #pragma omp parallel for schedule(dynamic, 1)
 			for (long k = 0; k < (long)ids.size(); ++k) {
@@ -905,9 +994,10 @@ int main(int argc, char** argv) {
 	if (o.verbosity > 1) printf("Scene loaded: %zu images (%u calibrated), %zu sparse points\n", images.size(), nValid, verts.size());
 	const double tLoaded = now_s();
 	// neighbours whose footprint scale differs by >= 15 % are resampled on the device and registered as views of their own
-	// (DepthData::ViewData::ScaleImage + Image::GetCamera, SceneDensify.cpp:372-374); one copy per (image, new size)
+	// (DepthData::ViewData::ScaleImage + Image::GetCamera, SceneDensify.cpp:372-374); one copy per (image, new size) and device
 	{
 		std::map<std::pair<uint32_t, std::pair<int, int>>, uint32_t> scaled;
+		std::vector<std::map<uint32_t, bool>> made((size_t)nDev);
 		uint32_t nextId = 0x8000;
 		for (uint32_t id : todo) {
 			ImageData& im = images[id];
@@ -920,13 +1010,18 @@ int main(int argc, char** argv) {
 				auto it = scaled.find(key);
 				if (it == scaled.end()) {
 					if (nextId >= 65536) { fprintf(stderr, "error: too many resampled neighbour views\n"); return EXIT_FAILURE; }
-					CHK(hcmvs_rescale_view(ctx, sv.id, nextId, im.srcScale[k]));
-					if (o.verbosity > 2) printf("Image %3u resampled by %.2f to %dx%d as view %u\n", sv.id, im.srcScale[k], size.first, size.second, nextId);
 					it = scaled.emplace(key, nextId++).first;
+				}
+				if (!made[(size_t)im.dev].count(it->second)) {
+					hcmvs_ctx* dctx = devs[(size_t)im.dev].ctx;
+					if (hcmvs_rescale_view(dctx, sv.id, it->second, im.srcScale[k]) != HCMVS_OK) { fprintf(stderr, "error: resampling image %u failed (%s)\n", sv.id, hcmvs_last_error(dctx)); return EXIT_FAILURE; }
+					if (o.verbosity > 2) printf("Image %3u resampled by %.2f to %dx%d as view %u\n", sv.id, im.srcScale[k], size.first, size.second, it->second);
+					made[(size_t)im.dev][it->second] = true;
 				}
 				im.srcs[k] = it->second;
 			}
 		}
+		HIPOK(hipSetDevice(o.device));
 	}
 
 	// ---- the saver: copies + files of the final maps, behind the estimation ----
@@ -941,10 +1036,11 @@ int main(int argc, char** argv) {
 		       save_dmap(map_path(o.workdir, "/normalmap/normal%04u.dmap", j.id), im, nullptr, j.n.data(), nullptr);
 	};
 	auto copier = [&]() {
-		hipStream_t cs = nullptr;
-		if (hipSetDevice(o.device) != hipSuccess || hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) {
-			std::lock_guard<std::mutex> g(sv.mu); sv.error = "no copy stream"; sv.cv.notify_all(); return;
-		}
+		std::vector<hipStream_t> css((size_t)nDev, nullptr); // a map is copied on a stream of the device that holds it
+		for (int d = 0; d < nDev; ++d)
+			if (hipSetDevice(devs[(size_t)d].ordinal) != hipSuccess || hipStreamCreateWithFlags(&css[(size_t)d], hipStreamNonBlocking) != hipSuccess) {
+				std::lock_guard<std::mutex> g(sv.mu); sv.error = "no copy stream"; sv.cv.notify_all(); return;
+			}
 		for (;;) {
 			uint32_t id;
 			{
@@ -961,7 +1057,9 @@ int main(int argc, char** argv) {
 			const size_t n = (size_t)im.w * im.h;
 			std::unique_ptr<SaveJob> j(new SaveJob);
 			j->id = id; j->d.resize(n); j->n.resize(3 * n); j->c.resize(n);
-			const bool ok = hipMemcpyAsync(j->d.data(), im.dDepth, n * 4, hipMemcpyDeviceToHost, cs) == hipSuccess &&
+			hipStream_t cs = css[(size_t)im.dev];
+			const bool ok = hipSetDevice(devs[(size_t)im.dev].ordinal) == hipSuccess &&
+			                hipMemcpyAsync(j->d.data(), im.dDepth, n * 4, hipMemcpyDeviceToHost, cs) == hipSuccess &&
 			                hipMemcpyAsync(j->n.data(), im.dNormal, n * 12, hipMemcpyDeviceToHost, cs) == hipSuccess &&
 			                hipMemcpyAsync(j->c.data(), im.dConf, n * 4, hipMemcpyDeviceToHost, cs) == hipSuccess && hipStreamSynchronize(cs) == hipSuccess;
 			std::lock_guard<std::mutex> g(sv.mu);
@@ -969,7 +1067,7 @@ int main(int argc, char** argv) {
 			else { sv.toWrite.push_back(std::move(j)); ++sv.copied; }
 			sv.cv.notify_all();
 		}
-		(void)hipStreamDestroy(cs);
+		for (int d = 0; d < nDev; ++d) if (css[(size_t)d]) { (void)hipSetDevice(devs[(size_t)d].ordinal); (void)hipStreamDestroy(css[(size_t)d]); }
 	};
 	auto writer = [&]() {
 		for (;;) {
@@ -1004,8 +1102,9 @@ int main(int argc, char** argv) {
 	const double tInit = now_s();
 	double tPostfilter = 0;
 	const bool filterOnLast = o.postFilter && (o.estimationItersExternal - 1 == 1 || o.estimationItersExternal - 1 == 2);
-	// outer iterations over all images (SceneDensify.cpp:3684)
-	auto estimate_images = [&](const std::vector<uint32_t>& ids, int it) -> bool { // one launch set for the reference images `ids`
+	// one launch set for the reference images `ids` (all of device context d)
+	auto estimate_images = [&](int d, const std::vector<uint32_t>& ids, const hcmvs_params& pr, std::string& err) -> bool {
+		hcmvs_ctx* dctx = devs[(size_t)d].ctx;
 		std::vector<hcmvs_batch_item> items;
 		for (uint32_t id : ids) {
 			ImageData& im = images[id];
@@ -1016,26 +1115,51 @@ int main(int argc, char** argv) {
 			items.push_back(itx);
 		}
 		hcmvs_stats st;
-		if (hcmvs_estimate_batch_device(ctx, items.data(), (int32_t)items.size(), &prm) != HCMVS_OK || hcmvs_get_stats(ctx, &st) != HCMVS_OK) {
-			fprintf(stderr, "error: depth-map estimation failed (%s)\n", hcmvs_last_error(ctx));
+		if (hcmvs_estimate_batch_device(dctx, items.data(), (int32_t)items.size(), &pr) != HCMVS_OK || hcmvs_get_stats(dctx, &st) != HCMVS_OK) {
+			err = std::string("depth-map estimation failed (") + hcmvs_last_error(dctx) + ")";
 			return false;
 		}
 		if (o.verbosity > 2)
 			for (const auto& itx : items)
-				printf("Depth-map for image %3u estimated using %2d images: %dx%d (outer iteration %d, batch %.0f ms)\n", itx.ref_id,
-				       itx.n_src, images[itx.ref_id].w, images[itx.ref_id].h, it, st.ms_total);
+				printf("Depth-map for image %3u estimated using %2d images: %dx%d (outer iteration %d, batch %.0f ms%s)\n", itx.ref_id,
+				       itx.n_src, images[itx.ref_id].w, images[itx.ref_id].h, pr.it_external, st.ms_total, nDev > 1 ? (", device context " + std::to_string(d)).c_str() : "");
 		return true;
 	};
-	// the maps and neighbour lists the post-filters' fusion works on: every image of the scene, best connected first
-	std::vector<uint32_t> filterOrder(todo);
-	std::stable_sort(filterOrder.begin(), filterOrder.end(), [&](uint32_t a, uint32_t b) { return images[a].neighbors.size() > images[b].neighbors.size(); });
+	// The first device filters and fuses the whole scene: it holds a copy (g*) of the maps the other devices estimate.  gather: owner ->
+	// first device, scatter: back (after the post-filters changed them).  Peer copies over xGMI (hipMemcpyPeerAsync); two contexts on one
+	// GPU (--devices 0,0) copy device to device.  Single process: nothing is replicated, nobody else filters.
+	hipStream_t xs = nullptr;
+	HIPOK(hipStreamCreateWithFlags(&xs, hipStreamNonBlocking));
+	struct StreamGuard { hipStream_t s; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } xsGuard{xs};
+	auto exchange_maps = [&](bool toFirst) -> bool {
+		const int ord0 = devs[0].ordinal;
+		if (hipSetDevice(ord0) != hipSuccess) return false; // the copies on the first device are allocated there
+		for (uint32_t id : todo) {
+			ImageData& im = images[id];
+			const size_t n = (size_t)im.w * im.h;
+			if (im.dev == 0) { im.gDepth = im.dDepth; im.gNormal = im.dNormal; im.gConf = im.dConf; continue; }
+			if (!im.gDepth && (hipMalloc(&im.gDepth, n * 4) != hipSuccess || hipMalloc(&im.gNormal, n * 12) != hipSuccess || hipMalloc(&im.gConf, n * 4) != hipSuccess)) return false;
+			const int ord = devs[(size_t)im.dev].ordinal;
+			float* const dst[3] = {toFirst ? im.gDepth : im.dDepth, toFirst ? im.gNormal : im.dNormal, toFirst ? im.gConf : im.dConf};
+			float* const src[3] = {toFirst ? im.dDepth : im.gDepth, toFirst ? im.dNormal : im.gNormal, toFirst ? im.dConf : im.gConf};
+			const size_t bytes[3] = {n * 4, n * 12, n * 4};
+			for (int k = 0; k < 3; ++k) {
+				const hipError_t e = ord == ord0 ? hipMemcpyAsync(dst[k], src[k], bytes[k], hipMemcpyDeviceToDevice, xs)
+				                                 : hipMemcpyPeerAsync(dst[k], toFirst ? ord0 : ord, src[k], toFirst ? ord : ord0, bytes[k], xs);
+				if (e != hipSuccess) return false;
+			}
+		}
+		return hipStreamSynchronize(xs) == hipSuccess;
+	};
+	// the maps and neighbour lists the post-filters' fusion works on: every image of the scene, on the first device
+	const std::vector<uint32_t>& filterOrder = fuseOrder;
 	auto register_maps = [&]() -> bool {
 		for (uint32_t id : todo) {
 			ImageData& im = images[id];
 			std::vector<uint32_t> nb;
 			for (const auto& x : im.neighbors) if (std::find(todo.begin(), todo.end(), x.id) != todo.end()) nb.push_back(x.id);
 			if (nb.size() > 31) nb.resize(31);
-			if (hcmvs_set_depthmap_device(ctx, id, im.dDepth, im.dNormal, im.dConf, im.dMin, im.dMax) != HCMVS_OK ||
+			if (hcmvs_set_depthmap_device(ctx, id, im.gDepth ? im.gDepth : im.dDepth, im.gNormal ? im.gNormal : im.dNormal, im.gConf ? im.gConf : im.dConf, im.dMin, im.dMax) != HCMVS_OK ||
 			    hcmvs_set_neighbors(ctx, id, nb.data(), (int32_t)nb.size()) != HCMVS_OK) {
 				fprintf(stderr, "error: registering the maps of image %u failed (%s)\n", id, hcmvs_last_error(ctx));
 				return false;
@@ -1044,24 +1168,81 @@ int main(int argc, char** argv) {
 		return true;
 	};
 	const int nMinViewsFuse = std::min<int>(o.numberViewsFuse, (int)images.size());
+	// outer iterations over all images (SceneDensify.cpp:3684).  Every device context has a host thread that estimates the context's
+	// batches; where an outer iteration ends with the post-filters the threads meet, the main thread gathers the maps on the first
+	// device, filters, hands the filtered maps back and lets the threads go on.
+	std::mutex runMu; std::condition_variable runCv;
+	std::string runError;
+	int arrived = 0, released = -1; // workers waiting at the end of a filtered outer iteration; the last iteration whose filters are done
+	auto wait_prepared = [&](size_t b) -> bool {
+		std::unique_lock<std::mutex> g(prepMu);
+		prepCv.wait(g, [&] { return prepared[b].ready || !prepError.empty(); });
+		if (!prepError.empty()) { fprintf(stderr, "error: %s\n", prepError.c_str()); return false; }
+		const Prepared& pr = prepared[b];
+		if (pr.failed == 2) { fprintf(stderr, "error: can not read the previous level's maps of image %u ('%s/depthmap/depth%04u.dmap' + normalmap, or '%s/depth%04u.dmap')\n", pr.failedId, o.workdir.c_str(), pr.failedId, o.workdir.c_str(), pr.failedId); return false; }
+		if (pr.failed == 3) { fprintf(stderr, "error: the previous level's depth map of image %u holds no valid depth\n", pr.failedId); return false; }
+		if (pr.failed) { fprintf(stderr, "error: initialisation of image %u failed (%s)\n", pr.failedId, pr.failed == 4 ? "device memory" : "no sparse point in front of the image"); return false; }
+		return true;
+	};
+	auto fail_run = [&](const std::string& msg) { { std::lock_guard<std::mutex> g(runMu); if (runError.empty()) runError = msg; } runCv.notify_all(); };
+	auto worker = [&](int d) {
+		if (hipSetDevice(devs[(size_t)d].ordinal) != hipSuccess) { fail_run("hipSetDevice failed in an estimation thread"); return; }
+		hcmvs_params pr = prm;
+		for (int it = 0; it < o.estimationItersExternal; ++it) {
+			pr.it_external = it;
+			const bool last = it == o.estimationItersExternal - 1;
+			const bool filtered = o.postFilter && (it == 1 || it == 2) && !work.empty();
+			if (!(filtered && o.postFilterInterleave)) { // (the interleaved mode runs on the main thread, one device)
+				for (size_t b = 0; b < batches.size(); ++b) {
+					if (batches[b].dev != d) continue;
+					{ std::lock_guard<std::mutex> g(runMu); if (!runError.empty()) return; }
+					if (it == 0 && !wait_prepared(b)) { fail_run("initialisation failed"); return; }
+					std::string err;
+					if (!estimate_images(d, batches[b].ids, pr, err)) { fail_run(err); return; }
+					if (last && !filterOnLast) saver_submit(batches[b].ids); // final maps of this batch: off to the host while the next batch runs
+				}
+			}
+			if (filtered) { // meet the others; the main thread filters
+				std::unique_lock<std::mutex> g(runMu);
+				++arrived;
+				runCv.notify_all();
+				runCv.wait(g, [&] { return released >= it || !runError.empty(); });
+				if (!runError.empty()) return;
+			}
+		}
+	};
+	std::vector<std::thread> workers;
+	for (int d = 0; d < nDev; ++d) workers.emplace_back(worker, d);
+	struct WorkersJoin { std::vector<std::thread>& w; std::mutex& mu; std::condition_variable& cv; std::string& err;
+		~WorkersJoin() { { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = "aborted"; } cv.notify_all(); for (auto& t : w) if (t.joinable()) t.join(); } } workersJoin{workers, runMu, runCv, runError};
 	for (int it = 0; it < o.estimationItersExternal; ++it) {
-		prm.it_external = it;
 		const bool last = it == o.estimationItersExternal - 1;
 		// SceneDensify.cpp:3916, 3939-3958: with --n-nOptimize's REMOVE_SPECKLES | FILL_GAPS bits, after the estimates of outer
 		// iterations 1 and 2 every image goes through RemoveSmallSegments (in the fork: a whole fusion pass over the current maps of all
 		// images) and GapInterpolation
 		const bool filtered = o.postFilter && (it == 1 || it == 2) && !work.empty();
-		if (filtered && o.postFilterInterleave) {
+		if (!filtered) continue;
+		{ // every device has finished the estimates of this outer iteration (or, interleaved mode, is waiting for the main thread to run it)
+			std::unique_lock<std::mutex> g(runMu);
+			runCv.wait(g, [&] { return arrived == nDev || !runError.empty(); });
+			if (!runError.empty()) { fprintf(stderr, "error: %s\n", runError.c_str()); return EXIT_FAILURE; }
+			arrived = 0;
+		}
+		const double tp = now_s();
+		if (!exchange_maps(true)) { fprintf(stderr, "error: gathering the depth maps on device %d failed\n", devs[0].ordinal); return EXIT_FAILURE; }
+		if (!register_maps()) return EXIT_FAILURE;
+		uint64_t filledAll = 0;
+		if (o.postFilterInterleave) {
 			// the reference's order, exactly (single-thread event loop, SceneDensify.cpp:3889-3965: EVTEstimateDepthMap(k) queues
 			// EVTOptimizeDepthMap(k) FIRST): image k is filtered right after its own estimate, so its fusion sees the images > k as the
 			// previous outer iteration left them and zeroes depths in them before they are estimated again.  One image per launch: the
 			// exact mode, not the fast one
-			const double tp = now_s();
-			if (!register_maps()) return EXIT_FAILURE;
-			uint64_t filledAll = 0;
+			hcmvs_params pr = prm;
+			pr.it_external = it;
 			double tf = 0;
 			for (uint32_t id : work) {
-				if (!estimate_images(std::vector<uint32_t>(1, id), it)) return EXIT_FAILURE;
+				std::string err;
+				if (!estimate_images(0, std::vector<uint32_t>(1, id), pr, err)) { fprintf(stderr, "error: %s\n", err.c_str()); return EXIT_FAILURE; }
 				const double t0 = now_s();
 				uint64_t filled = 0;
 				CHK(hcmvs_postfilter(ctx, id, filterOrder.data(), (int32_t)filterOrder.size(), nMinViewsFuse, 0.01f, 25.f, 7, &filled));
@@ -1071,39 +1252,28 @@ int main(int argc, char** argv) {
 			tPostfilter += tf;
 			if (o.verbosity > 1) printf("Depth-maps estimated and filtered image after image in outer iteration %d (the reference's order): %llu pixels filled "
 			                            "(%.2f s, %.2f s of it post-filters)\n", it, (unsigned long long)filledAll, now_s() - tp, tf);
-			if (last) saver_submit(work);
-			continue;
-		}
-		for (size_t b = 0; b < batches.size(); ++b) {
-			if (it == 0) { // the batch's initial maps must have arrived
-				std::unique_lock<std::mutex> g(prepMu);
-				prepCv.wait(g, [&] { return prepared[b].ready || !prepError.empty(); });
-				if (!prepError.empty()) { fprintf(stderr, "error: %s\n", prepError.c_str()); return EXIT_FAILURE; }
-				const Prepared& pr = prepared[b];
-				if (pr.failed == 2) { fprintf(stderr, "error: can not read the previous level's maps of image %u ('%s/depthmap/depth%04u.dmap' + normalmap, or '%s/depth%04u.dmap')\n", pr.failedId, o.workdir.c_str(), pr.failedId, o.workdir.c_str(), pr.failedId); return EXIT_FAILURE; }
-				if (pr.failed == 3) { fprintf(stderr, "error: the previous level's depth map of image %u holds no valid depth\n", pr.failedId); return EXIT_FAILURE; }
-				if (pr.failed) { fprintf(stderr, "error: initialisation of image %u failed (%s)\n", pr.failedId, pr.failed == 4 ? "device memory" : hcmvs_last_error(ctx)); return EXIT_FAILURE; }
-			}
-			if (!estimate_images(batches[b], it)) return EXIT_FAILURE;
-			if (last && !filterOnLast) saver_submit(batches[b]); // final maps of this batch: off to the host while the next batch runs
-		}
-		// the batch schedule of the post-filters: every image of the outer iteration has been estimated, now
-		// they are filtered one image after the other (hcmvs_postfilter_sequence keeps the whole chain on the device)
-		if (filtered) {
-			const double tp = now_s();
-			if (!register_maps()) return EXIT_FAILURE;
-			uint64_t filledAll = 0;
+		} else {
+			// the batch schedule of the post-filters: every image of the outer iteration has been estimated, now
+			// they are filtered one image after the other (hcmvs_postfilter_sequence keeps the whole chain on the device)
 			CHK(hcmvs_postfilter_sequence(ctx, work.data(), (int32_t)work.size(), filterOrder.data(), (int32_t)filterOrder.size(), nMinViewsFuse, 0.01f, 25.f, 7, &filledAll));
 			tPostfilter += now_s() - tp;
 			if (o.verbosity > 1) printf("Depth-maps filtered after outer iteration %d: fuse-consistency mask + gap interpolation, %llu pixels filled (%.2f s)\n", it,
 			                            (unsigned long long)filledAll, now_s() - tp);
-			if (last) saver_submit(work);
 		}
+		if (!exchange_maps(false)) { fprintf(stderr, "error: handing the filtered depth maps back to their devices failed\n"); return EXIT_FAILURE; }
+		if (last) saver_submit(work);
+		{ std::lock_guard<std::mutex> g(runMu); released = it; }
+		runCv.notify_all();
+	}
+	for (auto& t : workers) t.join();
+	{
+		std::lock_guard<std::mutex> g(runMu);
+		if (!runError.empty()) { fprintf(stderr, "error: %s\n", runError.c_str()); return EXIT_FAILURE; }
 	}
 	loaderThread.join();
 	double pixels = 0;
 	for (uint32_t id : work) pixels += (double)images[id].w * images[id].h;
-	CHK(hcmvs_synchronize(ctx));
+	for (auto& d : devs) if (hcmvs_synchronize(d.ctx) != HCMVS_OK) { fprintf(stderr, "error: %s\n", hcmvs_last_error(d.ctx)); return EXIT_FAILURE; }
 	const double tEstimated = now_s();
 	if (o.verbosity > 1)
 		printf("Depth-maps estimated: %zu images (%zu resumed), %d outer x %d inner sweeps in %.2f s (%.2f Mpix/s per outer iteration; post-filters %.2f s of it); "
@@ -1118,6 +1288,14 @@ int main(int argc, char** argv) {
 		if (!sv.error.empty()) { fprintf(stderr, "error: %s\n", sv.error.c_str()); return EXIT_FAILURE; }
 	}
 	const double tCopied = now_s();
+	auto release_all = [&]() {
+		for (auto& im : images) {
+			(void)hipSetDevice(devs[(size_t)im.dev].ordinal);
+			for (float* q : {im.dDepth, im.dNormal, im.dConf, im.dHintDepth, im.dHintNormal}) if (q) (void)hipFree(q);
+			if (im.dev != 0) { (void)hipSetDevice(devs[0].ordinal); for (float* q : {im.gDepth, im.gNormal, im.gConf}) if (q) (void)hipFree(q); }
+		}
+		for (auto& d : devs) hcmvs_destroy(d.ctx);
+	};
 	auto wait_files = [&]() -> bool {
 		std::unique_lock<std::mutex> g(sv.mu);
 		sv.cv.wait(g, [&] { return sv.written == sv.submitted || !sv.error.empty(); });
@@ -1127,25 +1305,19 @@ int main(int argc, char** argv) {
 	if (o.fusionMode == 1 || todo.empty()) {
 		if (!wait_files()) return EXIT_FAILURE;
 		if (o.verbosity > 1) printf("Depth-maps saved (%.2f s after the last estimate)\n", now_s() - tEstimated);
-		for (auto& im : images) for (float* p : {im.dDepth, im.dNormal, im.dConf, im.dHintDepth, im.dHintNormal}) if (p) (void)hipFree(p);
-		hcmvs_destroy(ctx);
+		release_all();
 		return EXIT_SUCCESS;
 	}
-	// register the maps for fusion
+	// the maps of every image on the first device (the exchange before fusion), registered for the fusion
+	if (!exchange_maps(true)) { fprintf(stderr, "error: gathering the depth maps on device %d failed\n", devs[0].ordinal); return EXIT_FAILURE; }
+	if (!register_maps()) return EXIT_FAILURE;
 	uint64_t capacity = 0;
 	for (uint32_t id : todo) {
-		ImageData& im = images[id];
-		const size_t n = (size_t)im.w * im.h;
-		CHK(hcmvs_set_depthmap_device(ctx, id, im.dDepth, im.dNormal, im.dConf, im.dMin, im.dMax));
-		std::vector<uint32_t> nb;
-		for (const auto& x : im.neighbors) if (std::find(todo.begin(), todo.end(), x.id) != todo.end()) nb.push_back(x.id);
-		if (nb.size() > 31) nb.resize(31);
-		CHK(hcmvs_set_neighbors(ctx, id, nb.data(), (int32_t)nb.size()));
+		const size_t n = (size_t)images[id].w * images[id].h;
 		capacity += (uint64_t)(o.numberViewsFuse >= 2 ? n / 2 : n); // a fused point claims at least number-views-fuse pixels
 	}
 	// fuse: best connected images first (SceneDensify.cpp:3285-3302)
-	std::vector<uint32_t> order(todo);
-	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return images[a].neighbors.size() > images[b].neighbors.size(); });
+	const std::vector<uint32_t>& order = fuseOrder;
 	// the complete PointCloud: points, view lists + weights (PointCloud::pointViews / pointWeights), colours, normals
 	uint64_t viewCapacity = 0;
 	for (uint32_t id : todo) viewCapacity += (uint64_t)images[id].w * images[id].h; // a point merges at most one depth per image
@@ -1188,7 +1360,6 @@ int main(int argc, char** argv) {
 	if (!okMvs || !okPly) { fprintf(stderr, "error: can not write the output files\n"); return EXIT_FAILURE; }
 	if (!wait_files()) return EXIT_FAILURE;
 	if (o.verbosity > 1) printf("Scene, point cloud and depth-maps saved (%.2f s after the fusion); total %.2f s\n", now_s() - tFused, now_s() - tStart);
-	for (auto& im : images) for (float* p : {im.dDepth, im.dNormal, im.dConf, im.dHintDepth, im.dHintNormal}) if (p) (void)hipFree(p);
-	hcmvs_destroy(ctx);
+	release_all();
 	return EXIT_SUCCESS;
 }

@@ -423,3 +423,41 @@ def test_hc_five_stage_schedule(tmp_path):
         assert b >= a - 0.02, acc
     ply = mvsio.read_ply(os.path.join(prev, "scene_dense.ply"))
     assert len(ply["x"]) > 50000
+
+
+@pytest.mark.gpu
+def test_densify_driver_several_device_contexts(tmp_path):
+    """`--devices a,b,...` -- one context and host thread per entry, the reference images dealt to them by
+    their position in the fusion order, the maps gathered on the first device (hipMemcpyPeerAsync; device-to-device copies when an
+    ordinal repeats) for the post-filters and the fusion.  On a one-GPU box `--devices 0,0` and `0,0,0` run two / three contexts on
+    the one device: depth maps, cloud and scene file must equal the single-context run byte for byte (three outer iterations, the
+    post-filters after the second and third, so the gather -> filter -> hand-back path runs twice)."""
+    outs = {}
+    for name, devices in (("one", None), ("two", "0,0"), ("three", "0,0,0")):
+        tmp = str(tmp_path / name)
+        os.makedirs(tmp)
+        scene, views = make_scene(tmp, n_views=6)
+        out = os.path.join(tmp, "dense.mvs")
+        cmd = [EXE, "-i", scene, "-o", out, "--resolution-level", "0", "--number-views", "3", "--n-EstimationIters", "2", "--n-EstimationIters-external", "3",
+               "--n-propagatehalfwin", "5", "--n-photometric_flow", "0", "--batch", "2", "-v", "3"]
+        if devices:
+            cmd += ["--devices", devices]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.count("Depth-maps filtered after outer iteration") == 2
+        if devices:
+            assert "device context %d" % (len(devices.split(",")) - 1) in r.stdout      # every context estimated something
+        files = ["dense.mvs", "dense.ply"] + ["depth%04d.dmap" % i for i in range(6)]
+        outs[name] = {f: open(os.path.join(tmp, f), "rb").read() for f in files}
+        assert len(outs[name]["dense.ply"]) > 100000
+    for name in ("two", "three"):
+        for f, b in outs["one"].items():
+            assert outs[name][f] == b, "%s differs between one context and %s" % (f, name)
+    # a scene that can not fit is refused with a message before anything is uploaded: not testable without filling the HBM; the
+    # unusable device ordinal is
+    tmp = str(tmp_path / "bad"); os.makedirs(tmp)
+    scene, _ = make_scene(tmp, n_views=5)
+    r = subprocess.run([EXE, "-i", scene, "--devices", "0,99"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "device 99" in r.stderr
+    r = subprocess.run([EXE, "-i", scene, "--devices", "0,x"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "--devices" in r.stderr
