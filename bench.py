@@ -167,9 +167,9 @@ def fuse_throughput(ctx, views, pts, dev):
             alg = ndep * (20.0 + (n - 1) * 8.0) + nmerged * 19.0
             cloud_bytes = npts * 31                                # xyz 12 + normal 12 + colour 3 + view count 4
             probe = torch.empty(max(cloud_bytes, 1), dtype=torch.uint8, device=dev)
-            host = np.empty(max(cloud_bytes, 1), np.uint8)         # pageable, like the caller's arrays
-            torch.cuda.synchronize()
-            t0 = time.perf_counter(); host[...] = probe.cpu().numpy(); d2h = time.perf_counter() - t0
+            host = torch.empty(max(cloud_bytes, 1), dtype=torch.uint8)   # pageable, like the caller's arrays
+            host.copy_(probe); torch.cuda.synchronize()                  # (first touch of the host pages outside the timing)
+            t0 = time.perf_counter(); host.copy_(probe); torch.cuda.synchronize(); d2h = time.perf_counter() - t0
             out["roofline"] = {"kernel": "FuseDepthMaps (fuse_begin / settle / apply / points / compaction kernels, %d images)" % n, "bound": "latency",
                                "achieved": round(alg / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4),
                                "algorithmic_bytes": int(alg), "ms": round(dt * 1e3, 2),
