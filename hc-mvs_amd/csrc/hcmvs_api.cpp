@@ -9,6 +9,7 @@
 #include "../../include/hcmvs_hip.h"
 #include "pm_common.h"
 #include "fuse_common.h"
+#include "pf_chain.h"
 #include "tri_init.h"
 #include "cloud_kernels.h"
 
@@ -82,6 +83,7 @@ struct hcmvs_ctx {
 	unsigned long long* counters = nullptr;
 	void* fuseScratch = nullptr; size_t capFuseScratch = 0;
 	char* passScratch = nullptr; size_t capPass = 0; // per-pass tables of the fusion (hcmvs_fuse_cloud, hcmvs_postfilter_sequence)
+	char* pfState = nullptr; size_t capPf = 0;       // the post-filter chain's state kept from fusion to fusion (pf_kernels.hip)
 	bool errPending = false; // an estimate was enqueued since the error word was last read
 	int nCU = 0;          // compute units of the device (fusion worker count)
 	hipEvent_t upEv[2] = {nullptr, nullptr};
@@ -221,6 +223,7 @@ void hcmvs_destroy(hcmvs_ctx* c) {
 	                (void*)c->evals, (void*)c->dMaps, (void*)c->counters, c->fuseScratch})
 		if (p) (void)hipFree(p);
 	if (c->passScratch) (void)hipFree(c->passScratch);
+	if (c->pfState) (void)hipFree(c->pfState);
 	for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->pinned) (void)hipHostFree(c->pinned);
 	for (auto& e : c->upEv) if (e) (void)hipEventDestroy(e);
@@ -992,6 +995,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	             oVoff = carve(viewCapacity ? maxArea * 4 : 0);
 	if (c->capPass < off) {
 		if (c->passScratch) (void)hipFree(c->passScratch);
+	if (c->pfState) (void)hipFree(c->pfState);
 		c->passScratch = nullptr; c->capPass = 0;
 		HIPCHK(c, hipMalloc(&c->passScratch, off));
 		c->capPass = off;
@@ -1093,6 +1097,109 @@ int hcmvs_fuse(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32_t n_m
 	return rc;
 }
 
+// The post-filter chain with its fusions computed incrementally (pf_kernels.hip): the first fusion of the chain evaluates every pixel,
+// each later one only what depends on the estimates that changed since (the pixels the previous image's gap interpolation filled, the
+// estimates the previous fusion zeroed).  Same decisions as a fusion from scratch, fusion after fusion.  Returns -1 when the chain can
+// not run this way (state does not fit the device, an image occurs twice, too many images) -- the caller then fuses from scratch.
+static int postfilter_chain_incremental(hcmvs_ctx* c, const std::vector<DevMap>& host, const uint32_t* ids, int32_t n_ids, const uint32_t* order, int32_t n_order,
+                                        int32_t n_min_views_fuse, float depth_diff_threshold, float normal_diff_deg, int32_t gap_size, uint64_t* n_filled) {
+	if (n_ids < 2 || n_ids > 2000 || n_order > 60000) return -1;
+	{ // an image is filled once per chain (a pair of estimates is linked into a bidder list at most twice)
+		std::vector<uint32_t> u(ids, ids + n_ids);
+		std::sort(u.begin(), u.end());
+		if (std::adjacent_find(u.begin(), u.end()) != u.end()) return -1;
+	}
+	std::vector<int> orderIndex(host.size(), -1);
+	for (int i = 0; i < n_order; ++i) { if (orderIndex[order[i]] >= 0) return -1; orderIndex[order[i]] = i; }
+	// layout of the state
+	size_t off = 0, maxArea = 0, maxIdArea = 0;
+	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+	struct Lay { size_t own, chg, val, tgt, head, next, acc, mm, fm, stamp, touch, stride; };
+	std::vector<Lay> lay(host.size());
+	for (size_t id = 0; id < host.size(); ++id) {
+		const DevMap& m = host[id];
+		if (!m.depth) continue;
+		const size_t n = (size_t)m.w * m.h;
+		if (n >= ((size_t)1 << 26) - 1) return -1;
+		Lay& L = lay[id];
+		L.own = carve(n * 2); L.chg = carve(n); L.val = carve(n);
+		if (orderIndex[id] < 0) continue;
+		size_t stride = 1;
+		for (int q = 0; q < m.nNeighbors; ++q) {
+			const uint32_t nb = c->views.find((uint32_t)id)->second.neighbors[(size_t)q];
+			if (nb < host.size() && host[nb].depth) stride = std::max(stride, (size_t)host[nb].w * host[nb].h);
+		}
+		const size_t nNb = (size_t)std::max(m.nNeighbors, 1);
+		if (2 * nNb * n >= 0xFFFFFFFFull || nNb * stride >= 0xFFFFFFFFull) return -1;
+		L.stride = stride;
+		L.tgt = carve(n * nNb * 4); L.head = carve(nNb * stride * 4); L.next = carve(2 * nNb * n * 4);
+		L.acc = carve(n); L.mm = carve(n * 4); L.fm = carve(n * 4); L.stamp = carve(n * 4); L.touch = carve(n * 4);
+		maxArea = std::max(maxArea, n);
+	}
+	for (int k = 0; k < n_ids; ++k) { const View& v = c->views.find(ids[k])->second; maxIdArea = std::max(maxIdArea, (size_t)v.w * v.h); }
+	const size_t oAny = carve(host.size() * 4);
+	const size_t oTable = carve(host.size() * sizeof(PfImage)), oScratch = carve(pf_pass_scratch_bytes(maxArea)), oCtl = carve(kCtlBytes), oCounters = carve(64),
+	             oStatus = carve(64), oDF = carve(maxIdArea * 4), oDF2 = carve(maxIdArea * 4), oNF = carve(maxIdArea * 12);
+	if (c->capPf < off) {
+		size_t freeB = 0, totalB = 0;
+		if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return -1;
+		if (off > freeB + c->capPf || off > (freeB + c->capPf) / 10 * 9) { (void)hipGetLastError(); return -1; } // does not fit (with a margin): fuse from scratch
+		if (c->pfState) (void)hipFree(c->pfState);
+		c->pfState = nullptr; c->capPf = 0;
+		if (hipMalloc(&c->pfState, off) != hipSuccess) { (void)hipGetLastError(); return -1; }
+		c->capPf = off;
+	}
+	if (getenv("HCMVS_FUSE_DEBUG")) fprintf(stderr, "postfilter: chain of %d images, fusions computed incrementally (%.1f MB of state kept between them)\n", n_ids, off / 1048576.0);
+	char* b = c->pfState;
+	hipStream_t s = c->stream;
+	std::vector<PfImage> pf(host.size());
+	memset(pf.data(), 0, pf.size() * sizeof(PfImage));
+	for (size_t id = 0; id < host.size(); ++id) {
+		const DevMap& m = host[id];
+		if (!m.depth) continue;
+		const size_t n = (size_t)m.w * m.h;
+		const Lay& L = lay[id];
+		PfImage& P = pf[id];
+		P.own = (uint16_t*)(b + L.own); P.chgNow = (uint8_t*)(b + L.chg); P.valNext = (uint8_t*)(b + L.val); P.anyChg = (uint32_t*)(b + oAny) + id;
+		HIPCHK(c, hipMemsetAsync(P.own, 0xFF, n * 2, s));
+		HIPCHK(c, hipMemsetAsync(P.chgNow, 0, n, s));
+		HIPCHK(c, hipMemsetAsync(P.valNext, 0, n, s));
+		if (orderIndex[id] < 0) continue;
+		const size_t nNb = (size_t)std::max(m.nNeighbors, 1);
+		P.tgt = (uint32_t*)(b + L.tgt); P.head = (uint32_t*)(b + L.head); P.next = (uint32_t*)(b + L.next); P.acc = (uint8_t*)(b + L.acc);
+		P.mm = (uint32_t*)(b + L.mm); P.fm = (uint32_t*)(b + L.fm); P.stamp = (uint32_t*)(b + L.stamp); P.touch = (uint32_t*)(b + L.touch); P.stride = L.stride;
+		launch_fill_u32(P.tgt, 0x03FFFFFFu, n * nNb, s); // "projects nowhere", never linked
+		HIPCHK(c, hipMemsetAsync(P.head, 0xFF, nNb * L.stride * 4, s));
+		HIPCHK(c, hipMemsetAsync(P.acc, 0, n, s));
+		HIPCHK(c, hipMemsetAsync(P.mm, 0, n * 4, s)); HIPCHK(c, hipMemsetAsync(P.fm, 0, n * 4, s));
+		HIPCHK(c, hipMemsetAsync(P.stamp, 0, n * 4, s)); HIPCHK(c, hipMemsetAsync(P.touch, 0, n * 4, s));
+	}
+	HIPCHK(c, hipMemsetAsync(b + oAny, 0, host.size() * 4, s));
+	PfImage* dPf = (PfImage*)(b + oTable);
+	HIPCHK(c, hipMemcpyAsync(dPf, pf.data(), pf.size() * sizeof(PfImage), hipMemcpyHostToDevice, s));
+	uint32_t* ctl = (uint32_t*)(b + oCtl); unsigned long long* counters = (unsigned long long*)(b + oCounters); uint32_t* status = (uint32_t*)(b + oStatus);
+	float* dF = (float*)(b + oDF); float* dF2 = (float*)(b + oDF2); float* nF = (float*)(b + oNF);
+	HIPCHK(c, hipMemsetAsync(status, 0, 64, s));
+	HIPCHK(c, hipMemsetAsync(counters, 0, 64, s));
+	const float normalError = cosf(normal_diff_deg * (3.14159274101257324f / 180.f)); // plain thresholds (SceneDensify.cpp:2083, 2177)
+	for (int k = 0; k < n_ids; ++k) {
+		if (k > 0) launch_pf_roll(c->dMaps, dPf, (int)host.size(), (uint32_t*)(b + oAny), s);
+		for (int oi = 0; oi < n_order; ++oi)
+			launch_pf_pass(host[order[oi]], oi, c->dMaps, dPf, pf[order[oi]], k == 0, depth_diff_threshold, normalError, n_min_views_fuse, (uint32_t)k, b + oScratch, ctl, status, s);
+		View& v = c->views.find(ids[k])->second;
+		launch_pf_filter(v.w, v.h, v.mDepth, v.mNormal, v.mConf, pf[ids[k]], v.gra, dF, dF2, nF, gap_size, depth_diff_threshold * 2.5f, counters + 5, s);
+	}
+	HIPCHK(c, hipGetLastError());
+	uint32_t st[4] = {0, 0, 0, 0};
+	unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};
+	HIPCHK(c, hipMemcpyAsync(st, status, 16, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipMemcpyAsync(cnt, counters, 48, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipStreamSynchronize(s));
+	if (st[0] != 0) return fail(c, HCMVS_ERR_TIMEOUT, "postfilter: the settle iteration of a fusion pass gave up; the registered depth maps are left partially fused");
+	if (n_filled) *n_filled = cnt[5];
+	return HCMVS_OK;
+}
+
 // The post-filters of one outer iteration, image after image.  Every image costs a complete fusion over all maps (that IS the
 // fork's RemoveSmallSegments, SceneDensify.cpp:2048-2275), so the fusion here is the one thing that must be cheap: it produces no
 // cloud, and all its passes are enqueued on the context's stream WITHOUT host synchronisation -- stream order is the image order
@@ -1123,6 +1230,13 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 	for (int k = 0; k < n_ids; ++k) { View& v = c->views.find(ids[k])->second; maxIdArea = std::max(maxIdArea, (size_t)v.w * v.h); rc = ensure_gradient(c, v); if (rc) return rc; }
 	const size_t tblElems = stride * (size_t)maxNb;
 	if (stride >= ((size_t)1 << 29) || tblElems > 0x7FFFFFFFull) return fail(c, HCMVS_ERR_CAPACITY, "postfilter: %d neighbours of %zu pixels exceed the per-pass tables", maxNb, stride);
+	// a chain of two or more images: every fusion after the first is computed incrementally when the state fits the device
+	// (HCMVS_PF_FULL=1: every fusion from scratch, the path of rounds 1-3, kept as the fall-back and for comparison)
+	if (n_ids >= 2 && !getenv("HCMVS_PF_FULL")) {
+		launch_unclaim(c->dMaps, (int)host.size(), c->stream); // no claim mark may be left over from a fusion that failed half way
+		rc = postfilter_chain_incremental(c, host, ids, n_ids, order, n_order, n_min_views_fuse, depth_diff_threshold, normal_diff_deg, gap_size, n_filled);
+		if (rc >= 0) return rc;
+	}
 	size_t off = 0;
 	auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
 	const size_t oPending = carve(maxArea * 4), oSettle = carve(fuse_settle_bytes(maxArea)), oTgt = carve(maxArea * 4 * (size_t)maxNb),
@@ -1130,6 +1244,7 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 	             oMerged = carve(maxArea * 4), oFlag = carve(maxArea), oNv = carve(maxArea * 4), oDF = carve(maxIdArea * 4), oDF2 = carve(maxIdArea * 4), oNF = carve(maxIdArea * 12);
 	if (c->capPass < off) {
 		if (c->passScratch) (void)hipFree(c->passScratch);
+	if (c->pfState) (void)hipFree(c->pfState);
 		c->passScratch = nullptr; c->capPass = 0;
 		HIPCHK(c, hipMalloc(&c->passScratch, off));
 		c->capPass = off;

@@ -253,7 +253,7 @@ def test_postfilter_gradient_ratio_literal(ctx, pairs):
         assert ((d[y, x0 + 1:x1] > 0).all() if pairs == [(20, 21)] else (d[y, x0 + 1:x1] == 0).all())
 
 
-def test_postfilter_sequence_equals_image_after_image(ctx):
+def test_postfilter_sequence_equals_image_after_image(ctx, capfd, monkeypatch):
     """hcmvs_postfilter_sequence (all passes of a fusion enqueued without host synchronisation, one synchronisation per image)
     against the oracle run image after image, as the reference does over an outer iteration (SceneDensify.cpp:3939-3958): every
     image's fusion sees the maps the images before it left.  Depth, normal, confidence of every image: bit for bit."""
@@ -270,7 +270,21 @@ def test_postfilter_sequence_equals_image_after_image(ctx):
         for i in range(len(cur)):
             cur[i]["depth"] = dd[i]
         cur[vid]["normal"] = nd; cur[vid]["conf"] = cd
+    # the chain computes every fusion after the first INCREMENTALLY (pf_kernels.hip: only what depends on the pixels the previous image's
+    # gap interpolation filled and on the estimates the previous fusion zeroed is evaluated again) ...
+    monkeypatch.setenv("HCMVS_FUSE_DEBUG", "1")
+    capfd.readouterr()
     assert ctx.postfilter_sequence(seq, order) == total > 500
+    assert "fusions computed incrementally" in capfd.readouterr().err
+    monkeypatch.delenv("HCMVS_FUSE_DEBUG")
+    for i in range(len(maps)):
+        d, n, c = ctx.get_depthmap(i, with_normal=True)
+        assert np.array_equal(d, cur[i]["depth"]) and np.array_equal(n, cur[i]["normal"]) and np.array_equal(c, cur[i]["conf"]), i
+    # ... and with every fusion from scratch (HCMVS_PF_FULL: the path of rounds 1-3, the fall-back when the state does not fit)
+    upload(ctx, maps)
+    monkeypatch.setenv("HCMVS_PF_FULL", "1")
+    assert ctx.postfilter_sequence(seq, order) == total
+    monkeypatch.delenv("HCMVS_PF_FULL")
     for i in range(len(maps)):
         d, n, c = ctx.get_depthmap(i, with_normal=True)
         assert np.array_equal(d, cur[i]["depth"]) and np.array_equal(n, cur[i]["normal"]) and np.array_equal(c, cur[i]["conf"]), i
