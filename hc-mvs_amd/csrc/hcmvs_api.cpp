@@ -70,7 +70,8 @@ struct hcmvs_ctx {
 	std::vector<DevView> hViews;          // host copy handed to hipMemcpyAsync (must outlive the call)
 	EstConst* dItems = nullptr;           // [kMaxBatch]
 	std::vector<EstConst> hItems;
-	int32_t* sync = nullptr;              // [0] unused, [1] error word, [16 .. 16 + kMaxBatch) row tickets of the batch items
+	int32_t* sync = nullptr;              // [0] unused, [1] error word, [16 .. 16 + kMaxBatch) row tickets of the batch items, then kMaxBatch rows-done counters
+	int sweepPerLaunch = 0;               // HCMVS_SWEEP_LAUNCHES: 0 automatic (one launch for all sweeps from 16 images on), 1 per-sweep, 2 one
 	unsigned long long* evals = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	int lastSweeps = 0;
@@ -186,7 +187,7 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 		if (hipEventCreate(&e) != hipSuccess) { delete c; return HCMVS_ERR_NO_DEVICE; }
 	c->hViews.resize((size_t)kMaxBatch * kMaxViews); c->hItems.resize(kMaxBatch);
 	if (hipMalloc(&c->dViews, sizeof(DevView) * kMaxViews * kMaxBatch) != hipSuccess || hipMalloc(&c->evals, 32) != hipSuccess ||
-	    hipMalloc(&c->dItems, sizeof(EstConst) * kMaxBatch) != hipSuccess || hipMalloc(&c->sync, 64 + sizeof(int32_t) * kMaxBatch) != hipSuccess) {
+	    hipMalloc(&c->dItems, sizeof(EstConst) * kMaxBatch) != hipSuccess || hipMalloc(&c->sync, 64 + sizeof(int32_t) * 2 * kMaxBatch) != hipSuccess) {
 		delete c;
 		return HCMVS_ERR_NO_DEVICE;
 	}
@@ -194,6 +195,9 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 	if (lag && atoi(lag) >= 1) c->sweepLag = atoi(lag);
 	const char* aff = getenv("HCMVS_XCD_AFFINITY");
 	if (aff) c->xcdAffinity = atoi(aff) != 0;
+	const char* spl = getenv("HCMVS_SWEEP_LAUNCHES");
+	if (spl && strcmp(spl, "per-sweep") == 0) c->sweepPerLaunch = 1;
+	if (spl && strcmp(spl, "one") == 0) c->sweepPerLaunch = 2;
 	const char* wpr = getenv("HCMVS_WAVES_PER_ROW"); // tuning knob: 1, 2, 3 or 4 waves cooperate on one image row
 	if (wpr && (atoi(wpr) == 1 || atoi(wpr) == 2 || atoi(wpr) == 3 || atoi(wpr) == 4)) c->wavesPerRow = atoi(wpr);
 	*out = c;
@@ -583,7 +587,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 	HIPCHK(c, hipMemcpyAsync(c->dViews, c->hViews.data(), sizeof(DevView) * kMaxViews * n_items, hipMemcpyHostToDevice, s));
 	HIPCHK(c, hipMemcpyAsync(c->dItems, c->hItems.data(), sizeof(EstConst) * n_items, hipMemcpyHostToDevice, s));
 	HIPCHK(c, hipMemsetAsync(c->evals, 0, 32, s));
-	HIPCHK(c, hipMemsetAsync(c->sync, 0, 64 + sizeof(int32_t) * kMaxBatch, s));
+	HIPCHK(c, hipMemsetAsync(c->sync, 0, 64 + sizeof(int32_t) * 2 * kMaxBatch, s));
 
 	HIPCHK(c, hipEventRecord(c->ev[0], s));
 	for (int i = 0; i < n_items; ++i) {
@@ -597,20 +601,33 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 	}
 	HIPCHK(c, hipEventRecord(c->ev[1], s));
 	SweepSync sy;
-	sy.ticket = c->sync + 16; sy.error = c->sync + 1; sy.evals = c->evals;
-	for (int iter = 0; iter < p->n_estimation_iters; ++iter) {
-		HIPCHK(c, hipMemsetAsync(c->sync + 16, 0, sizeof(int32_t) * kMaxBatch, s)); // the tickets; the error word stays sticky
-		for (int i = 0; i < n_items; ++i)
-			HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * c->hItems[i].border) * kProgressStride * sizeof(int32_t), s));
+	sy.ticket = c->sync + 16; sy.rowsDone = c->sync + 16 + kMaxBatch; sy.error = c->sync + 1; sy.evals = c->evals;
+	// A batch that fills the chip several times over (16 images or more) runs all its sweeps in ONE launch (round 4): the images go
+	// through their sweeps independently of each other, without a chip-wide drain and refill between two sweeps (+5.4 % at 16 images,
+	// +2.6 ... 3.5 % at 32; profiles/r04_launch_modes.txt).  Fewer images are bound by the latency of their row wavefronts, not by the
+	// chip, and gain nothing from it (measured: 4 -> 8 % slower), so they keep one launch per sweep.  HCMVS_SWEEP_LAUNCHES=one | per-sweep
+	// overrides.  The `restore` variant's extra hypothesis belongs to the last sweep of the last outer iteration: that sweep then
+	// gets a launch of its own, with the kernel instance that knows the hint.
+	{
+		const int nSweeps = p->n_estimation_iters;
+		bool hintLast = false;
+		for (int i = 0; i < n_items; ++i) hintLast = hintLast || (c->hItems[i].hintDepth && c->hItems[i].hintIter == nSweeps - 1);
 		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : 2); // measured: profiles/r03_small_batches.txt
-		{
-			// the launcher picks the kernel variant by view count: an item whose count leaves two or more view groups idle wants the
-			// pair-packing variant, which is correct for the other items of its layout class too
-			int vSel = items[0].n_src;
-			for (int i = 0; i < n_items; ++i) if (items[i].n_src % 8 != 0 && items[i].n_src % 8 != 7) vSel = items[i].n_src;
-			bool hint = false; // the `restore` variant's extra hypothesis is offered in this sweep by some item: the kernel instance that knows it
-			for (int i = 0; i < n_items; ++i) hint = hint || (c->hItems[i].hintDepth && c->hItems[i].hintIter == iter);
-			launch_sweep(c->dItems, n_items, maxRows, totalRows, vSel, p->adapthalfwin > kHalfWindow, hint, sy, iter, c->sweepLag, nw, c->xcdAffinity, s);
+		// the launcher picks the kernel variant by view count: an item whose count leaves two or more view groups idle wants the
+		// pair-packing variant, which is correct for the other items of its layout class too
+		int vSel = items[0].n_src;
+		for (int i = 0; i < n_items; ++i) if (items[i].n_src % 8 != 0 && items[i].n_src % 8 != 7) vSel = items[i].n_src;
+		int first = 0;
+		while (first < nSweeps) {
+			const bool perSweep = c->sweepPerLaunch == 1 || (c->sweepPerLaunch == 0 && n_items < 16);
+			int count = perSweep ? 1 : nSweeps - first;
+			bool hint = false;
+			if (hintLast) { if (first == nSweeps - 1) hint = true; else if (first + count == nSweeps) --count; } // the hint sweep runs alone
+			HIPCHK(c, hipMemsetAsync(c->sync + 16, 0, sizeof(int32_t) * 2 * kMaxBatch, s)); // tickets + rowsDone; the error word stays sticky
+			for (int i = 0; i < n_items; ++i)
+				HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * c->hItems[i].border) * kProgressStride * sizeof(int32_t), s));
+			launch_sweep(c->dItems, n_items, maxRows, totalRows, vSel, p->adapthalfwin > kHalfWindow, hint, sy, first, count, c->sweepLag, nw, c->xcdAffinity, s);
+			first += count;
 		}
 	}
 	HIPCHK(c, hipEventRecord(c->ev[2], s));

@@ -57,7 +57,8 @@ struct EstConst {
 };
 
 struct SweepSync {
-	int32_t* ticket;   // [kMaxBatch] next row of every image of the batch
+	int32_t* ticket;   // [kMaxBatch] next row of every image of the batch, counted through the sweeps of the launch (row + sweep * rows)
+	int32_t* rowsDone; // [kMaxBatch] rows every image has finished, counted through the sweeps of the launch
 	int32_t* error;    // set non-zero when a worker times out
 	unsigned long long* evals;  // [0] ScorePixel calls of the sequential algorithm, [1] evaluations issued (incl. speculative), [2] patch taps of [0]
 };
@@ -74,8 +75,8 @@ void launch_median3(const float* in, float* out, int W, int H, hipStream_t s);
 void launch_quads(const float* gray, float4* out, int W, int H, hipStream_t s); // 2 x 2 footprint layout of a source view
 void launch_score_pass(const EstConst& c, const float* depthIn, const float* normalIn, unsigned long long* evals,
                        hipStream_t s);
-void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, bool hint, const SweepSync& sync, int iter, int lag,
-                  int wavesPerRow, int affinity, hipStream_t s);
+void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, bool hint, const SweepSync& sync, int iter, int nSweeps,
+                  int lag, int wavesPerRow, int affinity, hipStream_t s);
 void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s);
 
 } // namespace hcmvs

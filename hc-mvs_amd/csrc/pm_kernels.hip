@@ -982,16 +982,21 @@ struct RowShared {
 	int row, item;
 };
 
-__device__ __forceinline__ int wait_progress(HC_GLOBAL int32_t* word, int need, HC_GLOBAL int32_t* err) {
+// started: the value the awaited word reaches once its owner is AT WORK on what I wait for (a row stores its sweep tag in its progress
+// word when it begins; the rows-done counter of an image is two rows short of the end of its sweep).  Below it the waiter sleeps long
+// between polls (thousands of row workers wait for their turn while a wavefront builds up; polling every 64 cycles
+// they take issue slots from the rows that are running on the same SIMDs and load the L2 for nothing) -- only the next in line polls fast.
+__device__ __forceinline__ int wait_progress(HC_GLOBAL int32_t* word, int need, HC_GLOBAL int32_t* err, int started = -0x7fffffff) {
 #if defined(HCMVS_ABL) && HCMVS_ABL == 3 /* diagnostic ablation: rows do not wait for each other (results are wrong) */
 	return need;
 #endif
 	int v;
 	unsigned spins = 0;
 	while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, HC_SCOPE)) < need) {
-		__builtin_amdgcn_s_sleep(1);
+		if (v < started) { __builtin_amdgcn_s_sleep(32); spins += 8u; } // ~2000 cycles
+		else __builtin_amdgcn_s_sleep(1);
 		++spins;
-		if ((spins & 255u) == 0u) {
+		if ((spins & 255u) < 9u) {
 			if (__hip_atomic_load(err, __ATOMIC_RELAXED, HC_SCOPE) != 0) return -1;
 			if (spins > (1u << 22)) { // bounded: give up instead of hanging the device
 				__hip_atomic_store(err, 1, __ATOMIC_RELAXED, HC_SCOPE);
@@ -1013,6 +1018,7 @@ struct RowPipe {
 	int poll;         // progress value of an in-flight poll
 	int pendingPub;   // > 0: results up to this column are stored but not yet published
 	HC_GLOBAL int32_t *upWord, *myWord, *err;
+	int base;         // progress words count columns of sweep k of the launch as (k << 16) + columns: the words are not reset between the sweeps
 	int r, y, ncols;
 	bool rev, fail;
 };
@@ -1184,10 +1190,10 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 				STAMP(5)
 				if (pp.pendingPub > 0) { // NW == 1 only (see the end of process_pixel)
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-					if (lane == 0) __hip_atomic_store(pp.myWord, pp.pendingPub, __ATOMIC_RELAXED, HC_SCOPE);
+					if (lane == 0) __hip_atomic_store(pp.myWord, pp.base + pp.pendingPub, __ATOMIC_RELAXED, HC_SCOPE);
 					pp.pendingPub = 0;
 				}
-				if (pp.r > 0) pp.poll = __hip_atomic_load(pp.upWord, __ATOMIC_RELAXED, HC_SCOPE);
+				if (pp.r > 0) pp.poll = __hip_atomic_load(pp.upWord, __ATOMIC_RELAXED, HC_SCOPE) - pp.base;
 				STAMP(6)
 			}
 			if (conf <= c.thConfSmall) idxScaleRange = 2;
@@ -1359,7 +1365,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		// published at once.  The last wave has no share of the next pixel's propagation round when there are at most NW - 1
 		// candidates (it_external 0: two), so the drain of its stores delays nobody there.
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		if (lane == 0) __hip_atomic_store(pp.myWord, q + 1, __ATOMIC_RELAXED, HC_SCOPE);
+		if (lane == 0) __hip_atomic_store(pp.myWord, pp.base + q + 1, __ATOMIC_RELAXED, HC_SCOPE);
 	}
 	STAMP(9)
 
@@ -1375,55 +1381,64 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 #endif
 template <int S, int NW, bool BIG, bool TWO = false, bool PACK = false, bool HINT = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? HCMVS_OCC : 1, !BIG ? HCMVS_OCC : 2))) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
-                                                        int iter, int lag, int affinity) {
+                                                        int iter0, int nSweeps, int lag, int affinity) {
 	__shared__ RowShared<NW> sh;
 	__shared__ WavePark<S> park[NW];
 	__shared__ float bigTab[BIG ? NW : 1][4][BIG ? kBigSlots : 1]; // big-patch kernels: per-tap tables of fill_patch_big
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, and the compiler should know it
-	const bool rev = (iter & 1) != 0; // dir = RB2LT on odd iterations, DepthMap.cpp:418
 	unsigned evals = 0, issued = 0;
 	unsigned long long taps = 0; // patch taps of the sequential algorithm's evaluations (per source view)
 	int par = 0, rot = (int)blockIdx.x;
 	STAMP_DECL
 	RowPipe<S> pp;
-	pp.err = as_global(sy.error); pp.rev = rev;
+	pp.err = as_global(sy.error);
 	for (;;) {
 		// Rows are handed out per image in dependence order (one counter per image): whoever holds row r-1 of an image
 		// is already running, so a waiting worker always waits on a running one.  Which image a worker serves is a
 		// matter of speed only: with affinity on, a workgroup prefers the images whose index is congruent to the id of
 		// its XCD (the rows of one image then share one L2, which holds the source lines the row above has just
 		// fetched) and only takes rows of the other images when its own are used up.
+		// ONE launch runs all nSweeps sweeps (round 4): an image's counter goes on through its sweeps (ticket t = row t % rows of sweep
+		// t / rows), so there is no chip-wide drain and refill between two sweeps -- an image that has finished a sweep starts its next one
+		// while the others are still in theirs.  The first row of a sweep waits until every row of the image's previous sweep is done (a
+		// sweep begins at the pixel the one before it ended with, DepthMap.cpp:418); a worker looks for a row that can run first.
 		if (NW > 1) __syncthreads(); // everyone is done with the previous row's shared state
 		if (threadIdx.x == 0) {
 			int item = -1, row = 0;
 			const int G = nItems < 8 ? nItems : 8;
 			const int home = affinity ? (int)(__builtin_amdgcn_s_getreg(6164) & 7u) % G : 0; // HW_REG_XCC_ID[3:0]
 			const int nHome = affinity ? (nItems - home + G - 1) / G : nItems;
-			for (int k = 0; k < nItems && item < 0; ++k) {
-				int cand;
-				if (!affinity) cand = (rot + k) % nItems;
-				else if (k < nHome) cand = home + ((rot + k) % nHome) * G;
-				else { // the other images, in index order
-					cand = k - nHome;
-					cand += cand / (G - 1) + (cand % (G - 1) >= home ? 1 : 0); // skip the indices congruent to home
+			for (int pass = 0; pass < 2 && item < 0; ++pass) // pass 0: only rows that need not wait for a sweep to end
+				for (int k = 0; k < nItems && item < 0; ++k) {
+					int cand;
+					if (!affinity) cand = (rot + k) % nItems;
+					else if (k < nHome) cand = home + ((rot + k) % nHome) * G;
+					else { // the other images, in index order
+						cand = k - nHome;
+						cand += cand / (G - 1) + (cand % (G - 1) >= home ? 1 : 0); // skip the indices congruent to home
+					}
+					const int nrows_ = items[cand].H - 2 * items[cand].border;
+					HC_GLOBAL int32_t* tk = as_global(sy.ticket) + cand;
+					const int t_ = __hip_atomic_load(tk, __ATOMIC_RELAXED, HC_SCOPE);
+					if (t_ >= nrows_ * nSweeps) continue;
+					if (pass == 0 && t_ > 0 && t_ % nrows_ == 0 && __hip_atomic_load(as_global(sy.rowsDone) + cand, __ATOMIC_RELAXED, HC_SCOPE) < t_) continue;
+					const int r_ = atomicAdd(sy.ticket + cand, 1);
+					if (r_ < nrows_ * nSweeps) { item = cand; row = r_; }
 				}
-				const int nrows_ = items[cand].H - 2 * items[cand].border;
-				HC_GLOBAL int32_t* tk = as_global(sy.ticket) + cand;
-				if (__hip_atomic_load(tk, __ATOMIC_RELAXED, HC_SCOPE) >= nrows_) continue;
-				const int r_ = atomicAdd(sy.ticket + cand, 1);
-				if (r_ < nrows_) { item = cand; row = r_; }
-			}
 			++rot;
 			sh.row = row; sh.item = item;
 		}
 		__syncthreads();
 		const int itemIdx = __builtin_amdgcn_readfirstlane(sh.item);
 		if (itemIdx < 0) break;
-		const int r = __builtin_amdgcn_readfirstlane(sh.row);
+		const int ticket = __builtin_amdgcn_readfirstlane(sh.row);
 		const EstConst& c = items[itemIdx];
 		const int bd = c.border;
 		const int nrows = c.H - 2 * bd, ncols = c.W - 2 * bd;
-		(void)nrows;
+		const int sweep = ticket / nrows, r = ticket - sweep * nrows;
+		const int iter = iter0 + sweep;
+		const bool rev = (iter & 1) != 0; // dir = RB2LT on odd iterations, DepthMap.cpp:418
+		pp.rev = rev; pp.base = sweep << 16;
 		LaneCtx<S> L;
 		lane_init<S>(c, L);
 		LdsStore<S> st;
@@ -1446,9 +1461,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 		pp.poll = 0; pp.pendingPub = 0; pp.fail = false;
 		if (r > 0) {
 			const int need = lag < ncols ? lag : ncols;
-			pp.known = wait_progress(pp.upWord, need, pp.err);
+			pp.known = wait_progress(pp.upWord, pp.base + need, pp.err, pp.base); // (the row above stores pp.base when it begins)
 			pp.fail = pp.known < 0;
+			pp.known -= pp.base;
+		} else if (sweep > 0) { // the image's previous sweep must be over, every row of it (fast polling for its last few rows only)
+			pp.fail = wait_progress(as_global(sy.rowsDone) + itemIdx, sweep * nrows, pp.err, sweep * nrows - 2) < 0;
 		}
+		if (!pp.fail && (threadIdx.x == 0) && ncols > 0) __hip_atomic_store(pp.myWord, pp.base, __ATOMIC_RELAXED, HC_SCOPE); // "this row is at work"
+
 		const int x0 = rev ? c.W - 1 - bd : bd;
 		const int dx = rev ? -1 : 1;
 		pp.tx1 = uniform_byte(c.gra, y * c.W + x0);
@@ -1481,8 +1501,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			fill_patch<S, BIG>(c, L, x, y, in, P, st);
 			STAMP(1)
 			if (pp.known < q + 1) { // the previous row must have finished this column
-				pp.known = wait_progress(pp.upWord, q + 1, pp.err);
+				pp.known = wait_progress(pp.upWord, pp.base + q + 1, pp.err);
 				if (pp.known < 0) { pp.fail = true; break; }
+				pp.known -= pp.base;
 				prefetch_up<S>(c, in);
 			}
 			STAMP(0)
@@ -1493,9 +1514,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 		if (pp.fail) break;
 		if (pp.pendingPub > 0) { // last column of the row (NW == 1)
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if ((threadIdx.x & 63) == 0) __hip_atomic_store(pp.myWord, pp.pendingPub, __ATOMIC_RELAXED, HC_SCOPE);
+			if ((threadIdx.x & 63) == 0) __hip_atomic_store(pp.myWord, pp.base + pp.pendingPub, __ATOMIC_RELAXED, HC_SCOPE);
 			pp.pendingPub = 0;
 		}
+		// the row is done and published (with several waves per row: by its last wave, whose stores were drained before it published):
+		// one more row of this sweep of the image
+		if (NW > 1) __syncthreads();
+		if (threadIdx.x == 0) __hip_atomic_fetch_add(as_global(sy.rowsDone) + itemIdx, 1, __ATOMIC_RELAXED, HC_SCOPE);
 	}
 	STAMP(10)
 	STAMP_FLUSH
@@ -1750,7 +1775,7 @@ void launch_score_pass(const EstConst& c, const float* depthIn, const float* nor
 }
 
 template <int NW, bool BIG, bool HINT>
-static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int lag,
+static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int nSweeps, int lag,
                             int affinity, hipStream_t s) {
 	// one workgroup per row; rows beyond the resident set are picked up through the ticket
 	int grid = totalRows < 8192 ? totalRows : 8192;
@@ -1760,39 +1785,41 @@ static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int
 	// (hypothesis, view) pairs of their own (score_chunk PACK; with one idle group it costs more than it saves)
 	const bool pack = V % 8 != 0 && V % 8 != 7;
 	if (V <= 8) {
-		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, false, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
-		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, true, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
+		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, false, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, nSweeps, lag, affinity);
+		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, true, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, nSweeps, lag, affinity);
 	} else {
-		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, false, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
-		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, true, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, lag, affinity);
+		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, false, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, nSweeps, lag, affinity);
+		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, true, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, nSweeps, lag, affinity);
 	}
 
 }
 template <bool HINT>
-static void launch_sweep_hint(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int lag,
+static void launch_sweep_hint(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int nSweeps, int lag,
                               int wavesPerRow, int affinity, hipStream_t s) {
 	if (bigPatch) { // patches beyond 64 taps: one or two waves per row
-		if (wavesPerRow >= 2) launch_sweep_nw<2, true, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s);
-		else launch_sweep_nw<1, true, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s);
+		if (wavesPerRow >= 2) launch_sweep_nw<2, true, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s);
+		else launch_sweep_nw<1, true, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s);
 		return;
 	}
 	if constexpr (HINT) { // the one sweep of a run that carries the hint: one or two waves per row
-		if (wavesPerRow >= 2) launch_sweep_nw<2, false, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s);
-		else launch_sweep_nw<1, false, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s);
+		if (wavesPerRow >= 2) launch_sweep_nw<2, false, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s);
+		else launch_sweep_nw<1, false, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s);
 		return;
 	}
 	switch (wavesPerRow) {
-	case 1: launch_sweep_nw<1, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
-	case 3: launch_sweep_nw<3, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
-	case 4: launch_sweep_nw<4, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
-	default: launch_sweep_nw<2, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, lag, affinity, s); break;
+	case 1: launch_sweep_nw<1, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s); break;
+	case 3: launch_sweep_nw<3, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s); break;
+	case 4: launch_sweep_nw<4, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s); break;
+	default: launch_sweep_nw<2, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s); break;
 	}
 }
-// hint: some item of the batch offers the `restore` variant's extra hypothesis in THIS sweep (EstConst::hintDepth, hintIter == iter)
-void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, bool hint, const SweepSync& sync, int iter, int lag,
-                  int wavesPerRow, int affinity, hipStream_t s) {
-	if (hint) launch_sweep_hint<true>(dItems, nItems, maxRows, totalRows, V, bigPatch, sync, iter, lag, wavesPerRow, affinity, s);
-	else launch_sweep_hint<false>(dItems, nItems, maxRows, totalRows, V, bigPatch, sync, iter, lag, wavesPerRow, affinity, s);
+// One launch for the sweeps iter .. iter + nSweeps - 1 of every item (tickets, rowsDone and the progress words of the items must be
+// zero).  hint: some item of the batch offers the `restore` variant's extra hypothesis in one of these sweeps (EstConst::hintDepth,
+// hintIter): the instance that knows the hint.
+void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, bool hint, const SweepSync& sync, int iter, int nSweeps,
+                  int lag, int wavesPerRow, int affinity, hipStream_t s) {
+	if (hint) launch_sweep_hint<true>(dItems, nItems, maxRows, totalRows, V, bigPatch, sync, iter, nSweeps, lag, wavesPerRow, affinity, s);
+	else launch_sweep_hint<false>(dItems, nItems, maxRows, totalRows, V, bigPatch, sync, iter, nSweeps, lag, wavesPerRow, affinity, s);
 }
 
 void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s) {
