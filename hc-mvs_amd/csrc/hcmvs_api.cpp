@@ -86,7 +86,7 @@ struct hcmvs_ctx {
 	char* passScratch = nullptr; size_t capPass = 0; // per-pass tables of the fusion (hcmvs_fuse_cloud, hcmvs_postfilter_sequence)
 	char* pfState = nullptr; size_t capPf = 0;       // the post-filter chain's state kept from fusion to fusion (pf_kernels.hip)
 	bool errPending = false; // an estimate was enqueued since the error word was last read
-	int nCU = 0;          // compute units of the device (fusion worker count)
+	int nCU = 0;          // compute units of the device: 4 SIMDs x 3 sweep workers each (the waves-per-row policy)
 	hipEvent_t upEv[2] = {nullptr, nullptr};
 	char* pinned = nullptr; size_t capPinned = 0; // page-locked staging of the host-buffer uploads (a pageable hipMemcpy crawls at ~1.3 GB/s here)
 	int wavesPerRow = 0; // 0 = automatic: 3 waves per row for one image, 2 for two (latency), 1 when >= 3 images fill the chip
@@ -181,6 +181,7 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return HCMVS_ERR_NO_DEVICE; // kernels are built for gfx950 only
 	hcmvs_ctx* c = new hcmvs_ctx();
 	c->device = device;
+	c->nCU = prop.multiProcessorCount;
 	if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { delete c; return HCMVS_ERR_NO_DEVICE; }
 	c->stream = c->ownStream;
 	for (auto& e : c->ev)
@@ -612,7 +613,11 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 		const int nSweeps = p->n_estimation_iters;
 		bool hintLast = false;
 		for (int i = 0; i < n_items; ++i) hintLast = hintLast || (c->hItems[i].hintDepth && c->hItems[i].hintIter == nSweeps - 1);
-		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 ? 1 : 2); // measured: profiles/r03_small_batches.txt
+		// waves per row: two for one or two images alone on the chip (latency of the row wavefront; measured: profiles/r03_small_batches.txt)
+		// -- but only while every row of the batch can be resident at once (12 workers per CU): a row that has to wait for a free slot
+		// delays the whole wavefront behind it (a lone 3840x2160 image has 2146 rows: one wave each)
+		const int slots = (c->nCU > 0 ? c->nCU : 256) * 12;
+		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 || 2 * totalRows > slots ? 1 : 2);
 		// the launcher picks the kernel variant by view count: an item whose count leaves two or more view groups idle wants the
 		// pair-packing variant, which is correct for the other items of its layout class too
 		int vSel = items[0].n_src;
