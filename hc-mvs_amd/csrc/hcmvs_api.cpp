@@ -617,7 +617,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 		// -- but only while every row of the batch can be resident at once (12 workers per CU): a row that has to wait for a free slot
 		// delays the whole wavefront behind it (a lone 3840x2160 image has 2146 rows: one wave each)
 		const int slots = (c->nCU > 0 ? c->nCU : 256) * 12;
-		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 || 2 * totalRows > slots ? 1 : 2);
+		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 || (n_items == 1 && 2 * totalRows > slots) ? 1 : 2);
 		// the launcher picks the kernel variant by view count: an item whose count leaves two or more view groups idle wants the
 		// pair-packing variant, which is correct for the other items of its layout class too
 		int vSel = items[0].n_src;
