@@ -229,18 +229,21 @@ def authors_config(ctx, dev, pmc=True):
         if best is None or st.ms_sweep_avg < best[0]:
             best = (st.ms_sweep_avg, dt, st.ms_total, st.evals, st.evals_issued)
     ms_sweep, dt, ms_total, evals, issued = best
+    launches = max(1, ctx.stats().n_sweep_launches)
+    spl = A["sweeps"] // launches
     P = (W - 14) * (H - 14)
     out = {"workload": "batch of %d reference images x %d source views, 1920x1080, 8x8 taps (adapthalfwin 7), outer iteration 1 of 4 (cross pattern %d / %d), "
                        "%d sweeps, photometric_flow %.2f" % (B, V, A["prop_halfwin"], A["prop_step"], A["sweeps"], A["photometric_flow"]),
-           "kernel": "sweep_kernel<8,1,false,TWO,PACK>", "sweep_launch_ms": round(ms_sweep, 3), "Mpix_s_per_sweep": round(B * W * H / ms_sweep / 1e3, 2),
+           "kernel": "sweep_kernel<8,1,false,TWO,PACK>", "sweep_ms": round(ms_sweep, 3), "sweeps_per_launch": spl, "sweep_launch_ms": round(ms_sweep * spl, 3),
+           "Mpix_s_per_sweep": round(B * W * H / ms_sweep / 1e3, 2),
            "estimate_ms": round(ms_total, 2), "Mpix_s_outer_iteration": round(B * W * H / dt / 1e6, 3),
            "evals_per_pixel_sweep": round((evals / (B * P) - 1) / A["sweeps"], 3), "evals_issued_per_pixel_sweep": round((issued / (B * P) - 1) / A["sweeps"], 3)}
     if pmc:
         live = live_pmc(B, kernel="sweep_kernel<8, 1, false, true, true", extra=["--authors-only"], sets=(("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"),),
                         need=("SQ_INSTS_VALU",))
         if live:
-            t = ms_sweep * 1e-3
-            out["valu"] = {"insts_per_launch": int(live["SQ_INSTS_VALU"]), "insts_per_pixel_sweep": round(live["SQ_INSTS_VALU"] / (B * P), 1),
+            t = ms_sweep * spl * 1e-3
+            out["valu"] = {"insts_per_launch": int(live["SQ_INSTS_VALU"]), "insts_per_pixel_sweep": round(live["SQ_INSTS_VALU"] / (B * P * spl), 1),
                            "frac": round(live["SQ_INSTS_VALU"] / t / VALU_PEAK_INSTS, 4),
                            "busy_frac_rocprof_4_cycles": round(live.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (N_SIMD * CLOCK_HZ * t), 4),
                            "counter_source": "rocprofv3 --pmc child run of `bench.py --authors-only`, now"}
@@ -267,7 +270,7 @@ def copy_bandwidth(dev):
 PMC_FILE = "r03_pmc.json"
 
 
-def pmc_value(batch, what):
+def pmc_value(batch, what, spl=1):
     """Per-launch counter totals of the sweep kernel from the committed rocprofv3 --pmc passes of this same command
     (profiles/r02_pmc.json, made by tools/prof_bench.sh + profiles/summarize_pmc.py): `hbm_bytes` = FETCH_SIZE + WRITE_SIZE,
     `valu_insts` = SQ_INSTS_VALU, `valu_busy_quadcycles` = SQ_ACTIVE_INST_VALU.  PMC counters cannot be collected from inside the
@@ -275,7 +278,9 @@ def pmc_value(batch, what):
     other batch size."""
     try:
         with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
-            return json.load(f).get("sweep_kernel_batch%d_%s_per_launch" % (batch, what))
+            j = json.load(f)
+        v = j.get("sweep_kernel_batch%d_%s_per_launch" % (batch, what))
+        return None if v is None else int(v * spl / max(1, int(j.get("sweeps_per_launch", 1))))   # a launch of the file may hold another number of sweeps
     except OSError:
         return None
 
@@ -443,8 +448,11 @@ def main():
         tap_evals_sweeps = int(st.tap_evals) - taps_a
         # algorithmic bytes of ONE sweep launch (SURVEY.md 8d tap-gather convention): every bilinear sample
         # counts its 4 texels (16 B) per source view, plus the 24 B of per-pixel state read and 20 B written
-        bytes_sweep = tap_evals_sweeps / SWEEPS * N_SRC * 16.0 + B * P * (24.0 + 20.0)
-        achieved = bytes_sweep / (st.ms_sweep_avg * 1e-3) / 1e9
+        # a batch of 16 or more images runs all its sweeps in ONE kernel launch (hcmvs_api.cpp): "per launch" is then per 8 sweeps
+        spl = SWEEPS // max(1, st.n_sweep_launches)                # sweeps per sweep-kernel launch
+        ms_launch = st.ms_sweeps / max(1, st.n_sweep_launches)      # average duration of a sweep-kernel launch (HIP events on its stream)
+        bytes_sweep = (tap_evals_sweeps / SWEEPS * N_SRC * 16.0 + B * P * (24.0 + 20.0)) * spl
+        achieved = bytes_sweep / (ms_launch * 1e-3) / 1e9
         out = {
             "metric": "PatchMatch Mpix/s (1080p, 8 views, 7x7, 8 iter)",
             "value": round(world * B * W * H * args.steps / dt / 1e6, 4),
@@ -461,17 +469,17 @@ def main():
                        "evals_per_pixel_sweep": round((st.evals / (B * P) - 1) / SWEEPS, 3)},
             "per_gpu": round(B * W * H * args.steps / dt / 1e6, 4),
             "single_unit": {"ms": round(single_ms, 2), "Mpix/s": round(W * H / single_ms / 1e3, 3)},
-            "kernel_ms": {"score_pass": round(st.ms_score, 3), "sweep_avg": round(st.ms_sweep_avg, 3),
-                          "sweeps_total": round(st.ms_sweeps, 3), "end": round(st.ms_end, 3),
+            "kernel_ms": {"score_pass": round(st.ms_score, 3), "sweep_avg": round(st.ms_sweep_avg, 3), "sweep_launches": int(st.n_sweep_launches),
+                          "sweep_launch_avg": round(ms_launch, 3), "sweeps_total": round(st.ms_sweeps, 3), "end": round(st.ms_end, 3),
                           "estimate_total": round(st.ms_total, 3)},
             # SURVEY.md 8d convention, kept for continuity: tap-gather ALGORITHMIC bytes (every bilinear sample counts its 4 texels)
             # over the HBM peak.  The gather is served by L2, so the fraction can pass 1: it says how many taps per second are
             # sampled, not what limits the kernel -- that is `roofline` below (the vector ALU).
             "roofline_convention": {"kernel": "sweep_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                                    "compulsory_bytes_per_launch": int(B * P * (4 * N_SRC + 4 + 40)),
-                                    "algorithmic_bytes_per_launch": int(bytes_sweep),
-                                    "avg_launch_ms": round(st.ms_sweep_avg, 3),
+                                    "compulsory_bytes_per_launch": int(B * P * (4 * N_SRC + 4 + 40)) * spl,
+                                    "algorithmic_bytes_per_launch": int(bytes_sweep), "sweeps_per_launch": spl,
+                                    "avg_launch_ms": round(ms_launch, 3),
                                     "convention": "SURVEY.md 8d: algorithmic tap-gather bytes (4 texels per bilinear sample) over the HBM peak"},
         }
         # the counters of the sweep kernel: measured now in rocprofv3 --pmc child runs of this command (FETCH_SIZE / WRITE_SIZE are
@@ -482,17 +490,17 @@ def main():
             vi, vb = int(live["SQ_INSTS_VALU"]), int(live.get("SQ_ACTIVE_INST_VALU", 0)) or None
             source = "rocprofv3 --pmc child runs of this command, now (SQ_INSTS_VALU + SQ_ACTIVE_INST_VALU, FETCH_SIZE, WRITE_SIZE: one pass per set)"
         else:
-            traffic, vi, vb = pmc_value(B, "hbm_bytes"), pmc_value(B, "valu_insts"), pmc_value(B, "valu_busy_quadcycles")
+            traffic, vi, vb = pmc_value(B, "hbm_bytes", spl), pmc_value(B, "valu_insts", spl), pmc_value(B, "valu_busy_quadcycles", spl)
             source = "profiles/%s (committed rocprofv3 --pmc measurement of this command)" % PMC_FILE
-        t_launch = st.ms_sweep_avg * 1e-3
-        evals_launch = (st.evals - B * P) / SWEEPS                   # ScorePixel evaluations of one sweep launch (each covers all views)
+        t_launch = ms_launch * 1e-3
+        evals_launch = (st.evals - B * P) / SWEEPS * spl             # ScorePixel evaluations of one sweep-kernel launch (each covers all views)
         useful_flops = evals_launch * N_SRC * FLOP_PER_EVAL_VIEW
-        roof = {"kernel": "sweep_kernel<8,1> (batched row worker)", "bound": "valu",
+        roof = {"kernel": "sweep_kernel<8,1> (batched row worker; %d sweeps per launch)" % spl, "bound": "valu",
                 "achieved": round(vi / t_launch, 1) if vi else None, "peak": VALU_PEAK_INSTS, "unit": "wave64 VALU instructions/s",
                 "frac": round(vi / t_launch / VALU_PEAK_INSTS, 4) if vi else None,
                 "useful_flop_frac": round(useful_flops / t_launch / FP32_VECTOR_PEAK, 4),
                 "useful_TFLOPs": round(useful_flops / t_launch / 1e12, 2),
-                "traffic": traffic, "avg_launch_ms": round(st.ms_sweep_avg, 3), "counter_source": source,
+                "traffic": traffic, "avg_launch_ms": round(ms_launch, 3), "sweeps_per_launch": spl, "counter_source": source,
                 "peak_definition": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (plain f32 rate, MI355X_MICROARCH.md); useful flops = "
                                    "evaluations x views x 1.6 kflop (SURVEY.md 8d) over the 157.3 TFLOP/s vector fp32 peak"}
         if traffic:
@@ -500,7 +508,7 @@ def main():
         if vi:
             simd_cycles = N_SIMD * CLOCK_HZ * t_launch
             roof["insts_per_launch"] = vi
-            roof["insts_per_pixel_sweep"] = round(vi / (B * P), 1)
+            roof["insts_per_pixel_sweep"] = round(vi / (B * P * spl), 1)
             # the same instruction count priced at what this mix costs: measured on this chip (profiles/r02_valu_issue_bench.jsonl)
             # fma/mul 2.3-2.8 cycles, logic 3.0, DPP / cvt / mul24 / readlane / f64 4.2-4.7, rcp 8.2 -> about 3 cycles per
             # instruction; and rocprof's own busy counter (SQ_ACTIVE_INST_VALU, 4-cycle units)

@@ -28,7 +28,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("evals", C.c_uint64), ("evals_issued", C.c_uint64), ("tap_evals", C.c_uint64), ("ms_score", C.c_float), ("ms_sweeps", C.c_float),
                 ("ms_sweep_avg", C.c_float), ("ms_end", C.c_float), ("ms_total", C.c_float),
-                ("n_sweeps", C.c_int32)]
+                ("n_sweeps", C.c_int32), ("n_sweep_launches", C.c_int32)]
 
 
 class BatchItem(C.Structure):

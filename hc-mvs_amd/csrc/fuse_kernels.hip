@@ -14,7 +14,7 @@
  *     parallel.  HBM-bound integer/float work, one thread per pixel, coalesced over the reference map.
  *   - Fuse: a pixel of image A interacts with other pixels of A only through the neighbour pixels it
  *     projects onto (its targets).  The pixels that project onto one neighbour pixel are listed per target
- *     (CSR, built once per image pass).  Whether a pixel becomes a point depends on which of its targets the
+ *     (a linked list of "bidders", pushed with one atomicExch as fuse_begin_kernel classifies the pair).  Whether a pixel becomes a point depends on which of its targets the
  *     pixels BEFORE it (raster order) have left available -- a well-founded recursion with exactly one
  *     solution, which is found by iteration: every pixel evaluated in parallel under the assumption that all
  *     the others become points, then only the pixels whose inputs changed, until nothing changes (the settle

@@ -74,7 +74,7 @@ struct hcmvs_ctx {
 	int sweepPerLaunch = 0;               // HCMVS_SWEEP_LAUNCHES: 0 automatic (one launch for all sweeps from 16 images on), 1 per-sweep, 2 one
 	unsigned long long* evals = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-	int lastSweeps = 0;
+	int lastSweeps = 0, lastSweepLaunches = 0;
 	bool haveStats = false;
 	int sweepLag = 1;
 	int fuseOrder = 0; // hcmvs_set_fuse_order
@@ -622,7 +622,8 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 		// pair-packing variant, which is correct for the other items of its layout class too
 		int vSel = items[0].n_src;
 		for (int i = 0; i < n_items; ++i) if (items[i].n_src % 8 != 0 && items[i].n_src % 8 != 7) vSel = items[i].n_src;
-		int first = 0;
+		int first = 0, nLaunches = 0;
+		c->lastSweepLaunches = 0;
 		while (first < nSweeps) {
 			const bool perSweep = c->sweepPerLaunch == 1 || (c->sweepPerLaunch == 0 && n_items < 16);
 			int count = perSweep ? 1 : nSweeps - first;
@@ -632,8 +633,9 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 			for (int i = 0; i < n_items; ++i)
 				HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * c->hItems[i].border) * kProgressStride * sizeof(int32_t), s));
 			launch_sweep(c->dItems, n_items, maxRows, totalRows, vSel, p->adapthalfwin > kHalfWindow, hint, sy, first, count, c->sweepLag, nw, c->xcdAffinity, s);
-			first += count;
+			first += count; ++nLaunches;
 		}
+		c->lastSweepLaunches = nLaunches;
 	}
 	HIPCHK(c, hipEventRecord(c->ev[2], s));
 	for (int i = 0; i < n_items; ++i)
@@ -671,6 +673,7 @@ int hcmvs_get_stats(hcmvs_ctx* c, hcmvs_stats* out) {
 	HIPCHK(c, hipEventElapsedTime(&out->ms_end, c->ev[2], c->ev[3]));
 	HIPCHK(c, hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[3]));
 	out->n_sweeps = c->lastSweeps;
+	out->n_sweep_launches = c->lastSweepLaunches;
 	out->ms_sweep_avg = c->lastSweeps > 0 ? out->ms_sweeps / (float)c->lastSweeps : 0.f;
 	c->errPending = true;
 	return check_sweep_error(c);

@@ -77,10 +77,11 @@ typedef struct {
 	uint64_t tap_evals;   /* sum over `evals` of the patch taps each one samples per source view (36/49/64) */
 	float ms_score;       /* device time of the init-score pass (HIP events on the context's stream) */
 	float ms_sweeps;      /* device time of all propagate/refine sweeps */
-	float ms_sweep_avg;   /* average duration of one sweep kernel launch */
+	float ms_sweep_avg;   /* ms_sweeps / n_sweeps: average duration of one sweep */
 	float ms_end;         /* device time of median/end/export kernels */
 	float ms_total;
 	int32_t n_sweeps;
+	int32_t n_sweep_launches; /* kernel launches the n_sweeps sweeps ran in: a batch of 16 or more images runs all its sweeps in one launch */
 } hcmvs_stats;
 
 void hcmvs_default_params(hcmvs_params* p);
@@ -230,14 +231,21 @@ int hcmvs_fuse(hcmvs_ctx* ctx, const uint32_t* order, int32_t n_order, int32_t n
  *   differ by at most 10 % -- are filled by linear interpolation of depth and normal direction; finally the maps take the
  *   fused-and-filled values where those are valid.
  * RemoveSmallSegments compares with the plain thresholds (SceneDensify.cpp:2083, 2177): --depthweight / --normalweight only scale the
- * thresholds of FuseDepthMaps (SceneDensify.cpp:3310, 3400), so this entry takes no weights.
+ * thresholds of FuseDepthMaps (SceneDensify.cpp:3310, 3400), so this entry takes no weights; and it visits the pixels of an image in
+ * raster order (SceneDensify.cpp:2130-2131) whatever hcmvs_set_fuse_order says about FuseDepthMaps.
  * The reference's third, per-pixel pass (SceneDensify.cpp:2790-2983) reads uninitialised variables and is not reproduced.
  * n_filled: pixels the two interpolation passes wrote. */
 int hcmvs_postfilter(hcmvs_ctx* ctx, uint32_t id, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
                      float normal_diff_deg, int32_t gap_size, uint64_t* n_filled);
-/* The same for the images ids[0 .. n_ids) one after the other -- what the reference does over all images of an outer iteration
- * (SceneDensify.cpp:3939-3958); identical in effect to n_ids calls of hcmvs_postfilter in that order (every image's fusion sees the
- * maps the images before it left), with the per-call set-up paid once.  n_filled: total over the images. */
+/* The same for the images ids[0 .. n_ids) one after the other: identical in effect to n_ids calls of hcmvs_postfilter in that order
+ * (every image's fusion sees the maps the images before it left), with the per-call set-up paid once and every fusion after the first
+ * computed INCREMENTALLY -- only what depends on the estimates that changed since the previous fusion (the pixels the previous image's
+ * gap interpolation filled, the estimates that fusion zeroed) is evaluated again; same decisions, fusion after fusion (the state kept
+ * between the fusions is about 360 B per pixel of the scene; when it does not fit the device, or an image occurs twice in ids, every
+ * fusion runs from scratch).  n_filled: total over the images.
+ * NOTE on the order: the reference filters image k right after image k's own estimate (single-thread event order,
+ * SceneDensify.cpp:3889-3965), i.e. hcmvs_estimate(k), hcmvs_postfilter(k), hcmvs_estimate(k + 1), ...  Calling this entry AFTER all
+ * estimates of an outer iteration is the batch schedule of this repo's driver -- a documented departure. */
 int hcmvs_postfilter_sequence(hcmvs_ctx* ctx, const uint32_t* ids, int32_t n_ids, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse,
                               float depth_diff_threshold, float normal_diff_deg, int32_t gap_size, uint64_t* n_filled);
 

@@ -14,6 +14,7 @@ from collections import defaultdict
 
 src, tag = sys.argv[1], sys.argv[2]
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32  # units per step of the profiled bench run
+spl = int(sys.argv[4]) if len(sys.argv) > 4 else (8 if batch >= 16 else 1)  # sweeps per sweep-kernel launch (round 4: a batch of 16+ runs its 8 sweeps in one launch)
 stats = glob.glob(src + "/trace/*/*_kernel_stats.csv")[0]
 shutil.copy(stats, "profiles/%s_bench_kernel_stats.csv" % tag)
 acc = defaultdict(lambda: defaultdict(list))
@@ -36,6 +37,7 @@ for k, cs in out["counters"].items():
     if "sweep_kernel<8, 1" in k and "SQ_INSTS_VALU" in cs:
         out["sweep_kernel_batch%d_valu_insts_per_launch" % batch] = int(cs["SQ_INSTS_VALU"]["mean_per_launch"])
         out["sweep_kernel_batch%d_valu_busy_quadcycles_per_launch" % batch] = int(cs["SQ_ACTIVE_INST_VALU"]["mean_per_launch"])
+out["sweeps_per_launch"] = spl
 json.dump(out, open("profiles/%s_pmc.json" % tag, "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k not in ("counters",)}, indent=1))
 for k, cs in out["counters"].items():
