@@ -267,7 +267,7 @@ def copy_bandwidth(dev):
     return round(best, 1)
 
 
-PMC_FILE = "r03_pmc.json"
+PMC_FILE = "r04_pmc.json"
 
 
 def pmc_value(batch, what, spl=1):

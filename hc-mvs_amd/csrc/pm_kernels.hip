@@ -992,13 +992,17 @@ __device__ __forceinline__ int wait_progress(HC_GLOBAL int32_t* word, int need, 
 #endif
 	int v;
 	unsigned spins = 0;
+	unsigned long long t0 = 0;
 	while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, HC_SCOPE)) < need) {
-		if (v < started) { __builtin_amdgcn_s_sleep(32); spins += 8u; } // ~2000 cycles
+		if (v < started) __builtin_amdgcn_s_sleep(32); // ~2000 cycles
 		else __builtin_amdgcn_s_sleep(1);
-		++spins;
-		if ((spins & 255u) < 9u) {
+		if ((++spins & 127u) == 0u) {
 			if (__hip_atomic_load(err, __ATOMIC_RELAXED, HC_SCOPE) != 0) return -1;
-			if (spins > (1u << 22)) { // bounded: give up instead of hanging the device
+			// bounded in TIME (the 100 MHz constant clock), not in polls: give up after 20 s instead of hanging the device -- long enough
+			// for a device shared with other processes, whose kernels may hold the chip for whole sweeps
+			const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+			if (t0 == 0) t0 = now;
+			else if (now - t0 > 2000000000ull) {
 				__hip_atomic_store(err, 1, __ATOMIC_RELAXED, HC_SCOPE);
 				return -1;
 			}
