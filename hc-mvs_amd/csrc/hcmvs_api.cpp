@@ -1104,7 +1104,7 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	}
 	*n_points = total;
 	if (n_depths) *n_depths = tot[2];
-	cloud->n_view_entries = viewTotal;
+	cloud->n_view_entries = wantCloud ? viewTotal : tot[1]; // a counting call (no xyz) reports what the cloud's view lists would hold
 	return HCMVS_OK;
 }
 

@@ -320,11 +320,14 @@ void launch_pf_pass(const DevMap& A, int i, const DevMap* maps, const PfImage* d
 	S.tag = fusionIndex + 1u;                      // `touch` is per image, an image has one pass per fusion
 	S.stampBase = fusionIndex << 21;               // steps stay below 2^20 (pf_settle_rest_kernel gives up there)
 	(void)hipMemsetAsync(ctl, 0, kCtlBytes, s);
-	hipLaunchKernelGGL(pf_delta_kernel, kPfGrid, kPfBlock, 0, s, A, i, maps, dPf, first ? 1 : 0, thDepth, normalError, delta, ctl);
-	for (int step = 0; step <= kSettleSteps; ++step) hipLaunchKernelGGL(pf_settle_step_kernel, kPfGrid, kPfBlock, 0, s, S, delta, (uint32_t)step);
+	// (smaller grids for the later fusions of a chain were tried -- 512 / 128 workgroups: 1.09 instead of 0.88 s per filtered iteration on
+	// 64 x 1080p; a pass re-evaluates some 10^5 pixels, it is not launch-bound)
+	const dim3 gridScan = kPfGrid, gridList = kPfGrid;
+	hipLaunchKernelGGL(pf_delta_kernel, gridScan, kPfBlock, 0, s, A, i, maps, dPf, first ? 1 : 0, thDepth, normalError, delta, ctl);
+	for (int step = 0; step <= kSettleSteps; ++step) hipLaunchKernelGGL(pf_settle_step_kernel, gridList, kPfBlock, 0, s, S, delta, (uint32_t)step);
 	hipLaunchKernelGGL(pf_settle_rest_kernel, dim3(1), dim3(1024), 0, s, S, status);
-	hipLaunchKernelGGL(pf_apply_kernel, kPfGrid, kPfBlock, 0, s, A, S, 0);
-	hipLaunchKernelGGL(pf_apply_kernel, kPfGrid, kPfBlock, 0, s, A, S, 1);
+	hipLaunchKernelGGL(pf_apply_kernel, gridList, kPfBlock, 0, s, A, S, 0);
+	hipLaunchKernelGGL(pf_apply_kernel, gridList, kPfBlock, 0, s, A, S, 1);
 }
 // mask -> gap interpolation along rows, then columns -> merge, for the image whose turn it is (launch_postfilter of fuse_kernels.hip with
 // the owner map in place of the claim marks)

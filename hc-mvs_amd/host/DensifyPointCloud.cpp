@@ -57,6 +57,8 @@ struct Options { // DensifyPointCloud.cpp:139-198 (defaults from there)
 	float photometricFlow = 0.5f, depthweight = 1.f, normalweight = 1.f;
 	int initTriangulate = 1;      // 1: Delaunay init from the sparse points, 0: read the previous level's maps (SceneDensify.cpp:522-553)
 	int minViewsTrustPoint = 2;   // < 2: splat the sparse points instead (SceneDensify.cpp:783-808)
+	int fuseCount = -1;           // --fuse-count 0|1: fuse once with worst-case buffers / count first, then fuse with exact buffers (-1: count first when
+	                              // the worst case exceeds 4 GiB)
 	int fuseOrder = 0;            // hcmvs_set_fuse_order: 0 the reference's raster order (its cloud, point for point), 1 hashed order
 	                              // (shorter dependence chains; point count within 1 % of the reference's)
 	int estimateColors = 2, estimateNormals = 2;   // 2: during fusion, 1: after it (DepthMap.cpp:2125-2269), 0: none
@@ -588,7 +590,7 @@ int main(int argc, char** argv) {
 		"--n-usegeoconsistency", "--n-initTriangulate", "--n-viewspread", "--n-opticalflow", "--n-adapthalfwin",
 		"--n-propagatehalfwin", "--n-propagatestep",
 		// this driver's own
-		"--min-views-trust-point", "--fuse-order", "--device", "--devices", "--batch", "--seed", "--restore-hypothesis", "--n-postfilter", "--n-postfilter-interleave", "--resume"};
+		"--min-views-trust-point", "--fuse-order", "--fuse-count", "--device", "--devices", "--batch", "--seed", "--restore-hypothesis", "--n-postfilter", "--n-postfilter-interleave", "--resume"};
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i], val;
 		if (a == "-h" || a == "--help") { kv["--help"] = "1"; continue; }
@@ -616,7 +618,7 @@ int main(int argc, char** argv) {
 	geti("--n-propagatehalfwin", o.propagateHalfWin); geti("--n-propagatestep", o.propagateStep);
 	getf("--n-photometric_flow", o.photometricFlow); getf("--depthweight", o.depthweight); getf("--normalweight", o.normalweight);
 	geti("--n-initTriangulate", o.initTriangulate); geti("--min-views-trust-point", o.minViewsTrustPoint);
-	geti("--fuse-order", o.fuseOrder); geti("--restore-hypothesis", o.restoreHypothesis); geti("--n-postfilter", o.postFilter); geti("--n-postfilter-interleave", o.postFilterInterleave); geti("--n-nOptimize", o.nOptimize); geti("--resume", o.resume);
+	geti("--fuse-order", o.fuseOrder); geti("--fuse-count", o.fuseCount); geti("--restore-hypothesis", o.restoreHypothesis); geti("--n-postfilter", o.postFilter); geti("--n-postfilter-interleave", o.postFilterInterleave); geti("--n-nOptimize", o.nOptimize); geti("--resume", o.resume);
 	geti("--device", o.device); geti("--batch", o.batch);
 	if (kv.count("--devices")) { // comma-separated HIP ordinals
 		std::stringstream ss(kv["--devices"]);
@@ -808,7 +810,9 @@ int main(int argc, char** argv) {
 				size_t maxNb = 1;
 				for (uint32_t id : todo) maxNb = std::max(maxNb, std::min<size_t>(images[id].neighbors.size(), 31));
 				resident += allPx * 4 + (nDev > 1 ? allPx * 20 : 0) + maxPx * (12 * maxNb + 40);
-				if (o.fusionMode != 1) resident += allPx / 2 * 31 + allPx * 8;
+				// the cloud: counted first when large (see the fusion below), so what is reserved is what it holds -- taken here as 0.2
+				// points per pixel (the reference reserves 0.15, SceneDensify.cpp:3298) with 3 view entries each
+				if (o.fusionMode != 1) resident += (allPx * 39 > ((size_t)4 << 30) && o.fuseCount != 0) ? allPx / 5 * (31 + 3 * 8) : allPx / 2 * 31 + allPx * 8;
 			}
 			int batch = o.batch;
 			while (batch > 1 && resident + (size_t)batch * maxPx * 24 > freeB) batch /= 2;
@@ -1316,11 +1320,29 @@ int main(int argc, char** argv) {
 		const size_t n = (size_t)images[id].w * images[id].h;
 		capacity += (uint64_t)(o.numberViewsFuse >= 2 ? n / 2 : n); // a fused point claims at least number-views-fuse pixels
 	}
+	uint64_t viewCapacity = 0;
+	for (uint32_t id : todo) viewCapacity += (uint64_t)images[id].w * images[id].h; // a point merges at most one depth per image
+	// The worst case (half a point per pixel, one view entry per pixel) is 39 B per pixel of the scene on the device and as much on the
+	// host: 166 GB for 512 images of 3840x2160.  A large scene is therefore fused twice: a counting pass first (no cloud; a fusion
+	// repeated on the maps a fusion has left makes the same decisions, so the second pass produces the cloud the first one counted),
+	// then the real one with buffers of exactly the size needed.
+	uint64_t countedDepths = 0;
+	if ((capacity * 31 + viewCapacity * 8) > ((uint64_t)4 << 30) || o.fuseCount == 1) {
+		if (o.fuseCount != 0) {
+			hcmvs_cloud cnt;
+			memset(&cnt, 0, sizeof cnt);
+			CHK(hcmvs_set_fuse_order(ctx, o.fuseOrder));
+			CHK(hcmvs_fuse_cloud(ctx, fuseOrder.data(), (int32_t)fuseOrder.size(), std::min<int>(o.numberViewsFuse, (int)images.size()), 0.01f, 25.f, o.depthweight,
+			                     o.normalweight, &cnt));
+			if (o.verbosity > 2) printf("Fusion counted first: %llu points, %llu view entries (worst case reserved otherwise: %llu / %llu)\n", (unsigned long long)cnt.n_points,
+			                            (unsigned long long)cnt.n_view_entries, (unsigned long long)capacity, (unsigned long long)viewCapacity);
+			capacity = cnt.n_points + 1; viewCapacity = cnt.n_view_entries + 1;
+			countedDepths = cnt.n_depths; // the depths the fusion visited before it invalidated any (SceneDensify.cpp:3461 logs that number)
+		}
+	}
 	// fuse: best connected images first (SceneDensify.cpp:3285-3302)
 	const std::vector<uint32_t>& order = fuseOrder;
 	// the complete PointCloud: points, view lists + weights (PointCloud::pointViews / pointWeights), colours, normals
-	uint64_t viewCapacity = 0;
-	for (uint32_t id : todo) viewCapacity += (uint64_t)images[id].w * images[id].h; // a point merges at most one depth per image
 	RawArray<float> xyz(capacity * 3), nrm(capacity * 3); RawArray<uint8_t> bgr(capacity * 3); RawArray<uint32_t> nviews(capacity);
 	RawArray<uint32_t> viewIds(viewCapacity); RawArray<float> viewWeights(viewCapacity);
 	if (capacity && (!xyz.data() || !nrm.data() || !bgr.data() || !nviews.data() || !viewIds.data() || !viewWeights.data())) {
@@ -1335,7 +1357,7 @@ int main(int argc, char** argv) {
 	cl.views_capacity = viewCapacity; cl.view_ids = viewIds.data(); cl.view_weights = viewWeights.data();
 	CHK(hcmvs_fuse_cloud(ctx, order.data(), (int32_t)order.size(), std::min<int>(o.numberViewsFuse, (int)images.size()), 0.01f, 25.f, o.depthweight,
 	                     o.normalweight, &cl));
-	nPoints = cl.n_points; nDepths = cl.n_depths;
+	nPoints = cl.n_points; nDepths = countedDepths ? countedDepths : cl.n_depths;
 	xyz.shrink(nPoints * 3); nrm.shrink(nPoints * 3); bgr.shrink(nPoints * 3); nviews.shrink(nPoints);
 	viewIds.shrink(cl.n_view_entries); viewWeights.shrink(cl.n_view_entries);
 	// --estimate-colors / --estimate-normals: 2 = estimated during fusion (above), 1 = re-estimated on the final cloud

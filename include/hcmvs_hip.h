@@ -264,7 +264,11 @@ typedef struct {
 	float* view_weights;      /* views_capacity or NULL: Conf2Weight of the merged estimates (SceneDensify.cpp:154-156) */
 	uint64_t n_points, n_depths, n_view_entries; /* out */
 } hcmvs_cloud;
-/* hcmvs_fuse with the complete cloud */
+/* hcmvs_fuse with the complete cloud.  With cloud->xyz == NULL the call only COUNTS: the fusion runs (with its side effect, the
+ * invalidated depths) and n_points / n_depths / n_view_entries come back, no point is produced.  A fusion repeated on the maps a fusion
+ * has left makes the same decisions (what it invalidated is simply absent the second time), so a counting call followed by a call with
+ * buffers of exactly that size yields the cloud a single call with large enough buffers would have produced -- how a caller avoids
+ * reserving the worst case (half a point per pixel of the scene). */
 int hcmvs_fuse_cloud(hcmvs_ctx* ctx, const uint32_t* order, int32_t n_order, int32_t n_min_views_fuse, float depth_diff_threshold,
                      float normal_diff_deg, float depthweight, float normalweight, hcmvs_cloud* cloud);
 

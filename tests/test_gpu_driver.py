@@ -461,3 +461,26 @@ def test_densify_driver_several_device_contexts(tmp_path):
     assert r.returncode != 0 and "device 99" in r.stderr
     r = subprocess.run([EXE, "-i", scene, "--devices", "0,x"], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "--devices" in r.stderr
+
+
+@pytest.mark.gpu
+def test_densify_driver_counts_before_it_fuses(tmp_path):
+    """DESIGN.md section 4 (memory budget of configs[3]): a large scene is fused twice -- a counting pass (hcmvs_fuse_cloud without
+    buffers), then the real one with buffers of exactly the size counted -- instead of reserving half a point per pixel of the scene.  A
+    fusion repeated on the maps a fusion has left makes the same decisions, so cloud, scene file and the logged counts are those of the
+    single pass (`--fuse-count 1` forces the counting pass on a small scene; both pixel orders)."""
+    outs = {}
+    for order in ("0", "1"):
+        for count in ("0", "1"):
+            tmp = str(tmp_path / ("o%sc%s" % (order, count)))
+            os.makedirs(tmp)
+            scene, views = make_scene(tmp, n_views=5)
+            out = os.path.join(tmp, "dense.mvs")
+            r = subprocess.run([EXE, "-i", scene, "-o", out, "--resolution-level", "0", "--number-views", "4", "--n-EstimationIters", "3", "--n-EstimationIters-external", "1",
+                                "--fuse-order", order, "--fuse-count", count, "-v", "3"], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert ("Fusion counted first" in r.stdout) == (count == "1")
+            line = [l for l in r.stdout.splitlines() if "Depth-maps fused and filtered" in l][0]
+            outs[(order, count)] = (open(out, "rb").read(), open(out[:-4] + ".ply", "rb").read(), line.split(" in ")[0])
+        assert outs[(order, "0")] == outs[(order, "1")]
+    assert outs[("0", "0")][1] != outs[("1", "0")][1]          # (the two pixel orders do give different clouds)
