@@ -347,6 +347,16 @@ class Context:
         return dict(xyz=xyz[:k], normal=None if nrm is None else nrm[:k], bgr=None if bgr is None else bgr[:k],
                     n_views=nv[:k], n_points=k, n_depths=nd.value)
 
+    def fuse_count(self, order, n_min_views_fuse=2, depth_diff_threshold=0.01, normal_diff_deg=25.0, depthweight=1.0, normalweight=1.0):
+        """hcmvs_fuse_cloud without buffers: the fusion runs (with its side effect, the invalidated depths) and only counts.  A fusion
+        repeated on the maps it has left makes the same decisions, so buffers of exactly (n_points, n_view_entries) hold the cloud of the
+        fusion that follows.  Returns (n_points, n_depths, n_view_entries)."""
+        cl = Cloud()
+        ids = (C.c_uint32 * len(order))(*order)
+        self._chk(lib().hcmvs_fuse_cloud(self._h, ids, len(order), n_min_views_fuse, depth_diff_threshold, normal_diff_deg, depthweight, normalweight,
+                                         C.byref(cl)))
+        return cl.n_points, cl.n_depths, cl.n_view_entries
+
     def fuse_cloud(self, order, capacity, views_capacity, n_min_views_fuse=2, depth_diff_threshold=0.01, normal_diff_deg=25.0, depthweight=1.0,
                    normalweight=1.0):
         """hcmvs_fuse_cloud: the complete PointCloud (points, view lists + weights as CSR, colours, normals)"""

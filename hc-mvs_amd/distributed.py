@@ -218,8 +218,20 @@ def densify_scene(ctx, views, srcs, neighbors, order, init, params, group=None, 
     _device_sync(dev)
     register(allm)
     maps = {img: unpack_maps(allm[slab_index(k, world, n_local)], h, w) for k, img in enumerate(ids)}
-    cap = capacity if capacity is not None else hw * len(ids) // 2
+    # the cloud's buffers: as given, or counted -- a counting fusion first (no buffers), then the real one with exactly what it needs,
+    # instead of half a point per pixel of the scene on every rank (66 GB of device and of host memory each at BASELINE configs[3]); a
+    # fusion repeated on the maps a fusion has left makes the same decisions, so the cloud is the single pass's
+    if capacity is not None:
+        cap = capacity
+    elif hasattr(ctx, "fuse_count"):
+        kw = {k: v for k, v in (fuse_kw or {}).items() if k not in ("with_normals", "with_colors")}
+        counted = ctx.fuse_count(ids, **kw)
+        cap = counted[0] + 1
+    else:
+        cap = hw * len(ids) // 2
     cloud = ctx.fuse(ids, cap, **(fuse_kw or {}))          # replicated on every rank: identical clouds
+    if capacity is None and hasattr(ctx, "fuse_count"):
+        cloud["n_depths"] = counted[1]                     # the depths the fusion visited before it invalidated any (SceneDensify.cpp:3461 logs that number)
     cloud["maps"] = maps
     cloud["_keep"] = (allm, allr, slabs)                   # the registered device maps must outlive the context's use of them
     return cloud

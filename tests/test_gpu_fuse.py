@@ -367,3 +367,29 @@ def test_fuse_bit_exact_large_dirty_maps(ctx, kw, fk):
     assert np.array_equal(got["normal"], want["normal"]) and np.array_equal(got["bgr"], want["bgr"])
     for i, d in enumerate(want["depths"]):
         assert np.array_equal(ctx.get_depthmap(i)[0], d)
+
+
+def test_fuse_count_then_fuse_is_the_single_pass(ctx):
+    """hcmvs_fuse_cloud without buffers counts (and invalidates); the fusion that follows, with buffers of exactly the counted size, yields
+    the cloud of a single pass -- a fusion repeated on the maps a fusion has left makes the same decisions (what it invalidated is simply
+    absent the second time).  The property the driver's two-pass fusion and the incremental post-filter chain rest on."""
+    for kw, mode in ((dict(noise=0.003, outliers=0.05, holes=0.1), 0), (dict(w=144, h=112, f=130.0, n_views=7, noise=0.002, outliers=0.03), 0),
+                     (dict(noise=0.003, outliers=0.05, holes=0.1), 1)):
+        maps, order = make_maps(**kw)
+        ctx.set_fuse_order(mode)
+        upload(ctx, maps)
+        single = ctx.fuse_cloud(order, 200000, 800000)
+        after_single = [ctx.get_depthmap(i)[0] for i in range(len(maps))]
+        upload(ctx, maps)
+        n_points, n_depths, n_entries = ctx.fuse_count(order)
+        assert (n_points, n_depths, n_entries) == (single["n_points"], single["n_depths"], len(single["view_ids"]))
+        for i in range(len(maps)):
+            assert np.array_equal(ctx.get_depthmap(i)[0], after_single[i])       # the counting pass has invalidated what the single pass invalidates
+        again = ctx.fuse_cloud(order, n_points, n_entries)                       # exactly the counted sizes
+        assert again["n_points"] == n_points
+        for k in ("xyz", "normal", "bgr", "n_views", "view_ids", "view_weights"):
+            assert np.array_equal(again[k], single[k]), k
+        for i in range(len(maps)):
+            assert np.array_equal(ctx.get_depthmap(i)[0], after_single[i])       # ... and the second pass invalidates nothing more
+        assert ctx.fuse_count(order)[0] == n_points                              # nor a third
+    ctx.set_fuse_order(0)
