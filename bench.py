@@ -23,9 +23,12 @@ issue fraction, `useful_flop_frac` = the flops SURVEY.md 8d counts (1.6 kflop pe
 peak, `traffic` = HBM bytes per launch; the counters are measured NOW by rocprofv3 --pmc child runs of this same command, one pass per
 counter set (`counter_source` says so, or names the committed profile used when rocprofv3 is not usable).  `roofline_convention` keeps
 the SURVEY.md 8d tap-gather figure (algorithmic bytes over the HBM peak; it passes 1.0 because the gather is served by L2 -- printed,
-not capped).  Also `roofline_single_unit`, `fuse` (FuseDepthMaps points/s on estimated maps), `cpu_baseline` (the oracle on the host
-cores).
-The default run takes about three minutes.
+not capped).  A batch of 16 or more images runs all its sweeps in ONE kernel launch: "per launch" then means per 8 sweeps
+(`roofline.sweeps_per_launch`, `kernel_ms.sweep_launches`).  Also `roofline_single_unit`, `fuse` (FuseDepthMaps points/s on estimated maps,
+with `fuse.roofline`: the SURVEY.md 8d bytes over its wall time, bound "latency", the share of the cloud's copy to the host), `authors_config`
+(the reference authors' own settings -- 10 views, 8x8 taps, cross pattern 5 / 4 -- as a batch of 16: the TWO + PACK kernel instance, time per
+sweep and its VALU fractions from a rocprofv3 child run of `bench.py --authors-only`), `cpu_baseline` (the oracle on the host cores).
+The default run takes about three and a half minutes.
 """
 import argparse
 import ctypes
