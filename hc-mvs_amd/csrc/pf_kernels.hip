@@ -222,6 +222,13 @@ __global__ __launch_bounds__(1024) void pf_settle_rest_kernel(PfSettle S, uint32
 }
 
 // ---- what changed: releases first, then claims and invalidations (a released estimate may be claimed by another pixel of the pass) ----
+// Which changes later passes must hear of (chgNow + the image's flag).  An estimate that is FREE when a point takes it -- claims it,
+// zeroes it, or is itself the pixel that becomes a point -- was free at the end of the previous fusion too (or was released in this
+// one, which marked it): no point of a later pass can have had it as an available merge or in-front target, for that point would have
+// claimed or zeroed it then.  Its later bidders are pixels that failed to become points, and losing a target does not make a failing
+// pixel succeed; whoever of them is evaluated again for another reason reads the owner map as it stands.  So taking a free estimate
+// changes no later decision and is not announced.  What is: an estimate RELEASED (its later bidders may now merge it), one TAKEN FROM A
+// LATER PASS's point of the previous fusion (that point loses a view), and -- by pf_merge_kernel, for the next fusion -- a changed value.
 __global__ void pf_apply_kernel(DevMap A, PfSettle S, int phase) {
 	const uint32_t n = S.ctl[kCtlTouched];
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
@@ -242,7 +249,9 @@ __global__ void pf_apply_kernel(DevMap A, PfSettle S, int phase) {
 				const int q = __builtin_ctz(bits);
 				const uint32_t y = S.me.tgt[(size_t)p * S.nNb + q] & kPfIdxMask;
 				const PfImage& tb = S.pf[S.nbIds[q]];
-				tb.own[y] = me16; tb.chgNow[y] = 1; *tb.anyChg = 1u; // free until now, or taken from a later pass of the previous fusion
+				const uint16_t prev = tb.own[y];
+				tb.own[y] = me16;
+				if (prev != kPfNone && prev != me16) { tb.chgNow[y] = 1; *tb.anyChg = 1u; } // taken from a later pass of the previous fusion
 			}
 			for (uint32_t bits = newF; bits; bits &= bits - 1u) {
 				const int q = __builtin_ctz(bits);
@@ -252,11 +261,18 @@ __global__ void pf_apply_kernel(DevMap A, PfSettle S, int phase) {
 				if (dB[y] != 0.f) { // SceneDensify.cpp:3447-3449
 					dB[y] = 0.f;
 					const PfImage& tb = S.pf[B];
-					tb.chgNow[y] = 1; tb.valNext[y] = 1; *tb.anyChg = 1u;
-					if (tb.own[y] != kPfNone) tb.own[y] = kPfNone; // it belonged to a point of a later pass of the previous fusion
+					const uint16_t prev = tb.own[y];
+					if (prev != kPfNone) { // it belonged to a point of this pass (whose pixel the settle iteration has re-evaluated) or of a later one
+						tb.own[y] = kPfNone;
+						if (prev != me16) { tb.chgNow[y] = 1; *tb.anyChg = 1u; }
+					}
 				}
 			}
-			if (now && !was) { S.me.own[p] = me16; S.me.chgNow[p] = 1; *S.me.anyChg = 1u; }
+			if (now && !was) {
+				const uint16_t prev = S.me.own[p];
+				S.me.own[p] = me16;
+				if (prev != kPfNone && prev != me16) { S.me.chgNow[p] = 1; *S.me.anyChg = 1u; } // it was a merged view of a later pass's point
+			}
 		}
 	}
 	(void)A;
