@@ -904,11 +904,24 @@ static int build_map_table(hcmvs_ctx* c, std::vector<DevMap>& host) {
 	if (!c->counters) HIPCHK(c, hipMalloc(&c->counters, 8 * sizeof(unsigned long long)));
 	return HCMVS_OK;
 }
+// hipMalloc that gives the post-filter chain's state back to the device when memory is short (the chain allocates it again, or falls
+// back to fusions from scratch, the next time it runs)
+static hipError_t malloc_or_release_chain(hcmvs_ctx* c, void** p, size_t bytes) {
+	hipError_t e = hipMalloc(p, bytes);
+	if (e != hipSuccess && c->pfState) {
+		(void)hipGetLastError();
+		(void)hipStreamSynchronize(c->stream);
+		(void)hipFree(c->pfState);
+		c->pfState = nullptr; c->capPf = 0;
+		e = hipMalloc(p, bytes);
+	}
+	return e;
+}
 static int ensure_scratch(hcmvs_ctx* c, size_t bytes) {
 	if (bytes <= c->capFuseScratch) return HCMVS_OK;
 	if (c->fuseScratch) (void)hipFree(c->fuseScratch);
 	c->fuseScratch = nullptr; c->capFuseScratch = 0;
-	HIPCHK(c, hipMalloc(&c->fuseScratch, bytes));
+	HIPCHK(c, malloc_or_release_chain(c, &c->fuseScratch, bytes));
 	c->capFuseScratch = bytes;
 	return HCMVS_OK;
 }
@@ -1020,9 +1033,8 @@ int hcmvs_fuse_cloud(hcmvs_ctx* c, const uint32_t* order, int32_t n_order, int32
 	             oVoff = carve(viewCapacity ? maxArea * 4 : 0);
 	if (c->capPass < off) {
 		if (c->passScratch) (void)hipFree(c->passScratch);
-	if (c->pfState) (void)hipFree(c->pfState);
 		c->passScratch = nullptr; c->capPass = 0;
-		HIPCHK(c, hipMalloc(&c->passScratch, off));
+		HIPCHK(c, malloc_or_release_chain(c, (void**)&c->passScratch, off));
 		c->capPass = off;
 	}
 	const int vstride = maxNb + 1;
@@ -1269,9 +1281,8 @@ int hcmvs_postfilter_sequence(hcmvs_ctx* c, const uint32_t* ids, int32_t n_ids, 
 	             oMerged = carve(maxArea * 4), oFlag = carve(maxArea), oNv = carve(maxArea * 4), oDF = carve(maxIdArea * 4), oDF2 = carve(maxIdArea * 4), oNF = carve(maxIdArea * 12);
 	if (c->capPass < off) {
 		if (c->passScratch) (void)hipFree(c->passScratch);
-	if (c->pfState) (void)hipFree(c->pfState);
 		c->passScratch = nullptr; c->capPass = 0;
-		HIPCHK(c, hipMalloc(&c->passScratch, off));
+		HIPCHK(c, malloc_or_release_chain(c, (void**)&c->passScratch, off));
 		c->capPass = off;
 	}
 	char* b = c->passScratch;
