@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 	int cb = 0, t0 = 0;
 	unsigned idxScaleRange = 0;
 	float scaleRange = 1.f, depthRange = 0.f, p0 = 0.f, p1 = 0.f;
-	bool hooked = false;
+	bool hooked = false, pollTaken = false;
 	for (;;) {
 		if (phase == PH_PICK) { // the RefineIters label, DepthMap.cpp:1443-1448
 			BLOCK(blk_pick, 0)
@@ -1280,6 +1280,11 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		}
 		const float mine = two_best(c, best1, best2); // lanes without a scored hypothesis: two_best(inf, inf) = inf
 		STAMP(7)
+		// the poll of the row above, issued by the hook in front of this round's evaluations, has come back with their gathers (vector
+		// memory returns in order): taking it here costs no wait.  Taken at the end of the pixel it was a load in flight across the loop's
+		// back-edge, and the compiler guards such a value with a full `s_waitcnt vmcnt(0)` there -- which also drained the pixel's stores
+		// (NW = 1) on the spot, the very wait the deferred publication is there to avoid
+		if (hooked && !pollTaken) { pollTaken = true; if (pp.r > 0 && pp.poll > pp.known) pp.known = pp.poll; }
 		const float all = share_scores<NW>(sh, par, lane, lo, hi, mine);
 		STAMP(8)
 		// ---- every wave replays the sequential accept logic ----
@@ -1353,7 +1358,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			if (conf > nconf - 0.1f) { conf = nconf; depth = hd; n0 = h0; n1 = h1; n2 = h2; }
 		}
 	}
-	if (pp.r > 0 && pp.poll > pp.known) pp.known = pp.poll; // consume the poll issued after the propagation phase
+	if (hooked && !pollTaken && pp.r > 0 && pp.poll > pp.known) pp.known = pp.poll; // (a pixel whose last round scored nothing: rare)
 	if (lane == 0) {
 		float* hrec = sh.hist[q & (kHist - 1)];
 		hrec[0] = depth; hrec[1] = n0; hrec[2] = n1; hrec[3] = n2; hrec[4] = conf;
@@ -1366,8 +1371,9 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		pp.pendingPub = q + 1; // published by the hook of the next pixel, a scoring round later: the drain of the stores is then free
 	} else if (wv == NW - 1) {
 		// several waves per row (one or two images alone on the chip: the row wavefront's critical path is what counts): the column is
-		// published at once.  The last wave has no share of the next pixel's propagation round when there are at most NW - 1
-		// candidates (it_external 0: two), so the drain of its stores delays nobody there.
+		// published at once by the row's last wave.  Deferring it to the next pixel's hook as with one wave per row was measured again in
+		// round 4, without the compiler's own drain at the loop's back-edge in the way: 41.3 instead of 35.4 ms per sweep of a lone 1080p
+		// image -- every row then trails the one above by a scoring round more (profiles/r04_launch_modes.txt)
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		if (lane == 0) __hip_atomic_store(pp.myWord, pp.base + q + 1, __ATOMIC_RELAXED, HC_SCOPE);
 	}
@@ -1506,14 +1512,25 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			STAMP(1)
 			if (pp.known < q + 1) { // the previous row must have finished this column
 				pp.known = wait_progress(pp.upWord, pp.base + q + 1, pp.err);
-				if (pp.known < 0) { pp.fail = true; break; }
+				if (pp.known < 0) { // (the same hand-over as below, so that the two ways out of the pixel meet with nothing in flight)
+					pp.fail = true;
+					asm volatile("s_waitcnt vmcnt(0)" : "+v"(pp.nI), "+v"(pp.nC) :: "memory");
+					break;
+				}
 				pp.known -= pp.base;
 				prefetch_up<S>(c, in);
 			}
 			STAMP(0)
+			// The next pixel's patch inputs (issued above, a pixel ahead) and this pixel's own loads are all back before the pixel's first
+			// arithmetic needs the latter: wait for everything HERE, where it is free, and hand pp.nI / pp.nC on as plain registers -- a
+			// load still "in flight" at the loop's back-edge would make the compiler put a full `s_waitcnt vmcnt(0)` there (see the poll)
+			asm volatile("s_waitcnt vmcnt(0)" : "+v"(pp.nI), "+v"(pp.nC) :: "memory");
 			const unsigned e0 = evals;
 			process_pixel<S, NW, BIG, TWO, PACK, HINT>(c, L, L1, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
 			taps += (unsigned long long)(evals - e0) * (unsigned)((P.a + 1) * (P.a + 1));
+#ifdef HCMVS_STAMP_BACKEDGE
+			STAMP(5)
+#endif
 		}
 		if (pp.fail) break;
 		if (pp.pendingPub > 0) { // last column of the row (NW == 1)
