@@ -41,12 +41,12 @@ namespace hcmvs {
 
 // diagnostic build only (-DHCMVS_STAMPS): per-phase cycle accounting of wave 0 of every row worker
 #ifdef HCMVS_STAMPS
-__device__ unsigned long long g_stamps[32]; // [0, 14) cycles per phase, [16, 32) executions of the blocks of BLOCK()
-#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned st_cnt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__device__ unsigned long long g_stamps[32]; // [0, 16) cycles per phase, [16, 32) executions of the blocks of BLOCK()
+#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned st_cnt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; }
-#define STAMP_ARGS , unsigned long long& st_last, unsigned long long (&st_acc)[14], unsigned (&st_cnt)[16]
+#define STAMP_ARGS , unsigned long long& st_last, unsigned long long (&st_acc)[16], unsigned (&st_cnt)[16]
 #define STAMP_PASS , st_last, st_acc, st_cnt
-#define STAMP_FLUSH if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) { for (int i_ = 0; i_ < 14; ++i_) atomicAdd(&g_stamps[i_], st_acc[i_]); for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_stamps[16 + i_], (unsigned long long)st_cnt[i_]); }
+#define STAMP_FLUSH if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_stamps[i_], st_acc[i_]); for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_stamps[16 + i_], (unsigned long long)st_cnt[i_]); }
 #define SUBMARK(name)
 #define BLOCK(name, i) ++st_cnt[i];
 #define BLOCKN(name, i, n) st_cnt[i] += (unsigned)(n);
@@ -1367,6 +1367,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			store_f(&c.conf[idx], conf);
 		}
 	}
+	STAMP(15)
 	if constexpr (NW == 1) {
 		pp.pendingPub = q + 1; // published by the hook of the next pixel, a scoring round later: the drain of the stores is then free
 	} else if (wv == NW - 1) {
@@ -1489,6 +1490,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			pp.nI = first.I[0]; pp.nC = first.center;
 			pp.tx2 = ncols > 1 ? uniform_byte(c.gra, y * c.W + x0 + dx) : (uint8_t)0;
 		}
+		STAMP(10) // (ticket, and the wait until the row above has begun: the ramp of the row wavefront)
 		for (int q = 0; q < ncols && !pp.fail; ++q) {
 			const int x = rev ? c.W - 1 - bd - q : bd + q;
 			STAMP(13)
@@ -1496,6 +1498,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			PixIn<S> in;
 			in.tx = (float)pp.tx1;
 			prefetch_static<S>(c, L, x, y, q, rev, pp.known >= q + 1, in);
+			// the row above is not yet known to have passed this column (the hook's poll is a scoring round old): one more poll rides with
+			// the pixel's loads and is back with them, behind fill_patch -- a row that trails the one above by little more than a pixel then
+			// needs no synchronous poll (a full round trip to the progress word with nothing to hide it) at every pixel
+			const bool needUp = pp.known < q + 1;
+			int fresh = 0;
+			if (needUp) fresh = __hip_atomic_load(pp.upWord, __ATOMIC_RELAXED, HC_SCOPE) - pp.base;
 			in.I[0] = pp.nI; in.center = pp.nC;
 			if (q + 1 < ncols) { // next pixel's patch inputs (its gradient byte arrived a pixel ago)
 				PixIn<S> nxt;
@@ -1510,21 +1518,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			Patch<S> P;
 			fill_patch<S, BIG>(c, L, x, y, in, P, st);
 			STAMP(1)
-			if (pp.known < q + 1) { // the previous row must have finished this column
-				pp.known = wait_progress(pp.upWord, pp.base + q + 1, pp.err);
-				if (pp.known < 0) { // (the same hand-over as below, so that the two ways out of the pixel meet with nothing in flight)
-					pp.fail = true;
-					asm volatile("s_waitcnt vmcnt(0)" : "+v"(pp.nI), "+v"(pp.nC) :: "memory");
-					break;
+			// The next pixel's patch inputs (issued above, a pixel ahead), this pixel's own loads and the poll are all back before the pixel's
+			// first arithmetic needs them: wait for everything HERE, where it is free, and hand pp.nI / pp.nC on as plain registers -- a
+			// load still "in flight" at the loop's back-edge would make the compiler put a full `s_waitcnt vmcnt(0)` there (see the hook's poll)
+			asm volatile("s_waitcnt vmcnt(0)" : "+v"(pp.nI), "+v"(pp.nC), "+v"(fresh) :: "memory");
+			if (needUp) {
+				if (fresh > pp.known) pp.known = fresh;
+				if (pp.known < q + 1) { // the previous row must have finished this column
+					pp.known = wait_progress(pp.upWord, pp.base + q + 1, pp.err);
+					if (pp.known < 0) { pp.fail = true; break; }
+					pp.known -= pp.base;
 				}
-				pp.known -= pp.base;
 				prefetch_up<S>(c, in);
 			}
 			STAMP(0)
-			// The next pixel's patch inputs (issued above, a pixel ahead) and this pixel's own loads are all back before the pixel's first
-			// arithmetic needs the latter: wait for everything HERE, where it is free, and hand pp.nI / pp.nC on as plain registers -- a
-			// load still "in flight" at the loop's back-edge would make the compiler put a full `s_waitcnt vmcnt(0)` there (see the poll)
-			asm volatile("s_waitcnt vmcnt(0)" : "+v"(pp.nI), "+v"(pp.nC) :: "memory");
+			STAMP(14)
 			const unsigned e0 = evals;
 			process_pixel<S, NW, BIG, TWO, PACK, HINT>(c, L, L1, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
 			taps += (unsigned long long)(evals - e0) * (unsigned)((P.a + 1) * (P.a + 1));

@@ -35,11 +35,11 @@ for rep in range(2):
 st = ctx.stats()
 L.hcmvs_debug_stamps(ctx._h, out, 1)
 names = ["0 wait for the row above", "1 fill_patch (after 12)", "2 slots + interp + park", "3 hypothesis generation", "4 smooth_pass",
-         "5 (prop tail)", "6 publish hook", "7 score_chunk", "8 exchange", "9 store + ring", "10 row end/ticket", "11 accept scan", "12 loop top + loads issue", "13 loop back-edge (end of process_pixel -> loop top)"]
-tot = sum(out[i] for i in range(14))
+         "5 (prop tail)", "6 publish hook", "7 score_chunk", "8 exchange", "9 store + ring", "10 ticket + wait for the row above to BEGIN (ramp)", "11 accept scan", "12 loop top + loads issue", "13 loop back-edge (end of process_pixel -> loop top)", "14 wait for the pixel's own loads", "15 store + ring (9: drain + publish)"]
+tot = sum(out[i] for i in range(16))
 npx = (W - 14) * (H - 14) * I * B
 print("B", B, "ms_sweep_avg %.2f" % st.ms_sweep_avg, "s_memtime ticks/pixel (wave0) %.0f" % (tot / npx))
-for i in range(14):
+for i in range(16):
     print("%-32s %6.1f%%  %8.0f ticks/px" % (names[i], 100.0 * out[i] / tot, out[i] / npx))
 
 # executions of the blocks of the pixel state machine (BLOCK() in pm_kernels.hip), per pixel-sweep of wave 0's rows
