@@ -77,6 +77,7 @@ struct hcmvs_ctx {
 	int lastSweeps = 0, lastSweepLaunches = 0;
 	bool haveStats = false;
 	int sweepLag = 1;
+	int sweepSegment = -1; // columns per ticket of the sweep worker: -1 = automatic (see the launch of the sweeps), 0 = whole rows
 	int fuseOrder = 0; // hcmvs_set_fuse_order
 	int xcdAffinity = 1; // rows of an image prefer the workgroups of one XCD (HCMVS_XCD_AFFINITY=0 turns it off)
 	// filter / fuse scratch
@@ -199,6 +200,8 @@ int hcmvs_create(int device, hcmvs_ctx** out) {
 	const char* spl = getenv("HCMVS_SWEEP_LAUNCHES");
 	if (spl && strcmp(spl, "per-sweep") == 0) c->sweepPerLaunch = 1;
 	if (spl && strcmp(spl, "one") == 0) c->sweepPerLaunch = 2;
+	const char* sgl = getenv("HCMVS_SWEEP_SEGMENT"); // tuning knob: columns per ticket (0 = whole rows)
+	if (sgl && atoi(sgl) >= 0) c->sweepSegment = atoi(sgl);
 	const char* wpr = getenv("HCMVS_WAVES_PER_ROW"); // tuning knob: 1, 2, 3 or 4 waves cooperate on one image row
 	if (wpr && (atoi(wpr) == 1 || atoi(wpr) == 2 || atoi(wpr) == 3 || atoi(wpr) == 4)) c->wavesPerRow = atoi(wpr);
 	*out = c;
@@ -632,7 +635,22 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 			HIPCHK(c, hipMemsetAsync(c->sync + 16, 0, sizeof(int32_t) * 2 * kMaxBatch, s)); // tickets + rowsDone; the error word stays sticky
 			for (int i = 0; i < n_items; ++i)
 				HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * c->hItems[i].border) * kProgressStride * sizeof(int32_t), s));
-			launch_sweep(c->dItems, n_items, maxRows, totalRows, vSel, p->adapthalfwin > kHalfWindow, hint, sy, first, count, c->sweepLag, nw, c->xcdAffinity, s);
+			// A launch of ONE sweep with two to four times as many rows as the chip holds workers (6 .. 11 images of 1080p) hands out
+			// stretches of 256 columns instead of whole rows: with whole rows the last rows of every image begin when the chip is already
+			// draining and run on a third of it (8 images: 106.9 -> 100.0 ms per sweep, 6: 92.2 -> 90.2).  Fewer images are bound by the
+			// jitter of their row wavefronts, not by slots (3 or 4 images: 0 ... -3 %), more fill the tail with other images' rows anyway
+			// (12: the same) -- measured, profiles/r04_launch_modes.txt.  HCMVS_SWEEP_SEGMENT=N forces stretches of N columns, 0 whole rows.
+			int segLen = 0, tickets = totalRows;
+			if (count == 1 && (c->sweepSegment > 0 || (c->sweepSegment < 0 && nw == 1 && totalRows >= 2 * slots && totalRows < 4 * slots))) {
+				segLen = c->sweepSegment > 0 ? c->sweepSegment : 256;
+				if (segLen < 32) segLen = 32; // (the ring of a row's latest results is re-read from memory at the start of a stretch)
+				tickets = 0;
+				for (int i = 0; i < n_items; ++i) {
+					const int rows = c->hItems[i].H - 2 * c->hItems[i].border, cols = c->hItems[i].W - 2 * c->hItems[i].border;
+					tickets += rows * ((cols + segLen - 1) / segLen);
+				}
+			}
+			launch_sweep(c->dItems, n_items, maxRows, tickets, vSel, p->adapthalfwin > kHalfWindow, hint, sy, first, count, c->sweepLag, nw, c->xcdAffinity, segLen, s);
 			first += count; ++nLaunches;
 		}
 		c->lastSweepLaunches = nLaunches;

@@ -76,7 +76,7 @@ void launch_quads(const float* gray, float4* out, int W, int H, hipStream_t s); 
 void launch_score_pass(const EstConst& c, const float* depthIn, const float* normalIn, unsigned long long* evals,
                        hipStream_t s);
 void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, bool hint, const SweepSync& sync, int iter, int nSweeps,
-                  int lag, int wavesPerRow, int affinity, hipStream_t s);
+                  int lag, int wavesPerRow, int affinity, int segLen, hipStream_t s); // segLen > 0: tickets are stretches of segLen columns of a row
 void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s);
 
 } // namespace hcmvs

@@ -1392,7 +1392,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 #endif
 template <int S, int NW, bool BIG, bool TWO = false, bool PACK = false, bool HINT = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? HCMVS_OCC : 1, !BIG ? HCMVS_OCC : 2))) void sweep_kernel(const EstConst* __restrict__ items, int nItems, int maxRows, SweepSync sy,
-                                                        int iter0, int nSweeps, int lag, int affinity) {
+                                                        int iter0, int nSweeps, int lag, int affinity, int segLen) {
 	__shared__ RowShared<NW> sh;
 	__shared__ WavePark<S> park[NW];
 	__shared__ float bigTab[BIG ? NW : 1][4][BIG ? kBigSlots : 1]; // big-patch kernels: per-tap tables of fill_patch_big
@@ -1419,6 +1419,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			const int G = nItems < 8 ? nItems : 8;
 			const int home = affinity ? (int)(__builtin_amdgcn_s_getreg(6164) & 7u) % G : 0; // HW_REG_XCC_ID[3:0]
 			const int nHome = affinity ? (nItems - home + G - 1) / G : nItems;
+			// stretches: no image's tickets run out before the end of the sweep, so the preference for the home images would leave an image
+			// with fewer home XCDs than the others short of workers all sweep long -- a worker keeps to its home images only while they
+			// are not ahead of the image that is furthest behind (by more than 1 / 64 of a sweep)
+			float behind = 2.f;
+			if (segLen > 0 && affinity)
+				for (int k = 0; k < nItems; ++k) {
+					const int nrows_ = items[k].H - 2 * items[k].border;
+					const int per_ = nrows_ * ((items[k].W - 2 * items[k].border + segLen - 1) / segLen);
+					const int t_ = __hip_atomic_load(as_global(sy.ticket) + k, __ATOMIC_RELAXED, HC_SCOPE);
+					if (t_ < per_ * nSweeps) { const float f = (float)t_ / (float)per_; behind = f < behind ? f : behind; }
+				}
 			for (int pass = 0; pass < 2 && item < 0; ++pass) // pass 0: only rows that need not wait for a sweep to end
 				for (int k = 0; k < nItems && item < 0; ++k) {
 					int cand;
@@ -1429,12 +1440,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 						cand += cand / (G - 1) + (cand % (G - 1) >= home ? 1 : 0); // skip the indices congruent to home
 					}
 					const int nrows_ = items[cand].H - 2 * items[cand].border;
+					const int per_ = nrows_ * (segLen > 0 ? (items[cand].W - 2 * items[cand].border + segLen - 1) / segLen : 1); // tickets of a sweep
 					HC_GLOBAL int32_t* tk = as_global(sy.ticket) + cand;
 					const int t_ = __hip_atomic_load(tk, __ATOMIC_RELAXED, HC_SCOPE);
-					if (t_ >= nrows_ * nSweeps) continue;
-					if (pass == 0 && t_ > 0 && t_ % nrows_ == 0 && __hip_atomic_load(as_global(sy.rowsDone) + cand, __ATOMIC_RELAXED, HC_SCOPE) < t_) continue;
+					if (t_ >= per_ * nSweeps) continue;
+					if (pass == 0 && segLen > 0 && affinity && (float)t_ / (float)per_ > behind + 1.f / 64.f) continue;
+					if (pass == 0 && t_ > 0 && t_ % per_ == 0 &&
+					    __hip_atomic_load(as_global(sy.rowsDone) + cand, __ATOMIC_RELAXED, HC_SCOPE) < (t_ / per_) * nrows_) continue;
 					const int r_ = atomicAdd(sy.ticket + cand, 1);
-					if (r_ < nrows_ * nSweeps) { item = cand; row = r_; }
+					if (r_ < per_ * nSweeps) { item = cand; row = r_; }
 				}
 			++rot;
 			sh.row = row; sh.item = item;
@@ -1446,7 +1460,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 		const EstConst& c = items[itemIdx];
 		const int bd = c.border;
 		const int nrows = c.H - 2 * bd, ncols = c.W - 2 * bd;
-		const int sweep = ticket / nrows, r = ticket - sweep * nrows;
+		// SEGMENTS (segLen > 0; batches whose rows do not all fit the chip at once): a ticket is a stretch of segLen columns of a row, so
+		// that a worker's slot comes free after segLen pixels instead of a whole row -- with whole rows the rows beyond the resident set
+		// begin only when row 0 has reached its END, W - (resident rows per image) pixel periods late.  Tickets are numbered by the time
+		// r + seg * segLen at which a stretch can begin at the earliest (its upper neighbour is one pixel ahead, its left neighbour done):
+		// whatever a stretch waits for has a smaller ticket, i.e. is running or finished.
+		const int nseg = segLen > 0 ? (ncols + segLen - 1) / segLen : 1;
+		const int perSweep = nrows * nseg;
+		const int sweep = ticket / perSweep;
+		int r = ticket - sweep * perSweep, seg = 0;
+		if (nseg > 1) {
+			const int tt = r;
+			auto before = [&](int k) { // stretches that can begin before time k
+				int n = 0;
+				for (int g = 0; g < nseg; ++g) { const int v = k - g * segLen; n += v < 0 ? 0 : (v > nrows ? nrows : v); }
+				return n;
+			};
+			int lo = 0, hi = nrows + (nseg - 1) * segLen; // before(lo) <= tt < before(hi)
+			while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (before(mid) <= tt) lo = mid; else hi = mid; }
+			const int j = tt - before(lo);               // the j-th stretch of time lo, in the order of the segments
+			const int over = lo - nrows + 1;             // segments g with lo - g * segLen < nrows: g >= over / segLen, rounded up
+			const int g0 = over > 0 ? (over + segLen - 1) / segLen : 0;
+			seg = g0 + j;
+			r = lo - seg * segLen;
+		}
+		const int q0 = seg * segLen, q1 = nseg > 1 && q0 + segLen < ncols ? q0 + segLen : ncols;
 		const int iter = iter0 + sweep;
 		const bool rev = (iter & 1) != 0; // dir = RB2LT on odd iterations, DepthMap.cpp:418
 		pp.rev = rev; pp.base = sweep << 16;
@@ -1470,28 +1508,46 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 		pp.myWord = as_global(c.progress) + (size_t)r * kProgressStride;
 		pp.known = r > 0 ? 0 : 0x7fffffff; // columns the previous logical row has finished
 		pp.poll = 0; pp.pendingPub = 0; pp.fail = false;
-		if (r > 0) {
-			const int need = lag < ncols ? lag : ncols;
-			pp.known = wait_progress(pp.upWord, pp.base + need, pp.err, pp.base); // (the row above stores pp.base when it begins)
+		STAMP(10) // (ticket)
+		if (q0 > 0) { // the stretch to my left must be finished (and published: its results are in memory)
+			pp.fail = wait_progress(pp.myWord, pp.base + q0, pp.err, pp.base + q0 - 4) < 0;
+		}
+		STAMP(14) // (wait for the stretch to my left)
+		if (r > 0 && !pp.fail) {
+			const int need = q0 + lag < q1 ? q0 + lag : q1; // (never beyond my own stretch: the stretch above-right has a later ticket)
+			pp.known = wait_progress(pp.upWord, pp.base + need, pp.err, pp.base + q0); // (the row above stores pp.base when it begins)
 			pp.fail = pp.known < 0;
 			pp.known -= pp.base;
-		} else if (sweep > 0) { // the image's previous sweep must be over, every row of it (fast polling for its last few rows only)
+		} else if (sweep > 0 && q0 == 0) { // the image's previous sweep must be over, every row of it (fast polling for its last few rows only)
 			pp.fail = wait_progress(as_global(sy.rowsDone) + itemIdx, sweep * nrows, pp.err, sweep * nrows - 2) < 0;
 		}
-		if (!pp.fail && (threadIdx.x == 0) && ncols > 0) __hip_atomic_store(pp.myWord, pp.base, __ATOMIC_RELAXED, HC_SCOPE); // "this row is at work"
+		if (!pp.fail && (threadIdx.x == 0) && ncols > 0 && q0 == 0) __hip_atomic_store(pp.myWord, pp.base, __ATOMIC_RELAXED, HC_SCOPE); // "this row is at work"
+		if (q0 > 0 && !pp.fail) {
+			// the ring of the row's latest results (the neighbours behind me in my row) as the stretch to my left stored them
+			const int lane = (int)(threadIdx.x & 63);
+			const int col = q0 - 1 - lane;
+			if (lane < kHist && col >= 0) {
+				const int hx = rev ? c.W - 1 - bd - col : bd + col;
+				const float4 hdn = load_dn(&c.dn[y * c.W + hx]);
+				const float hcf = load_f(&c.conf[y * c.W + hx]);
+				float* hrec = sh.hist[col & (kHist - 1)];
+				hrec[0] = hdn.x; hrec[1] = hdn.y; hrec[2] = hdn.z; hrec[3] = hdn.w; hrec[4] = hcf; // (every wave of the row writes the same values)
+			}
+			if (NW > 1) __syncthreads();
+		}
 
-		const int x0 = rev ? c.W - 1 - bd : bd;
+		const int xs = rev ? c.W - 1 - bd - q0 : bd + q0;
 		const int dx = rev ? -1 : 1;
-		pp.tx1 = uniform_byte(c.gra, y * c.W + x0);
+		pp.tx1 = uniform_byte(c.gra, y * c.W + xs);
 		{ // the patch inputs travel one pixel ahead of the pixel being processed, the gradient byte two
 			PixIn<S> first;
 			first.tx = (float)pp.tx1;
-			load_patch_inputs<S>(c, L, x0, y, first);
+			load_patch_inputs<S>(c, L, xs, y, first);
 			pp.nI = first.I[0]; pp.nC = first.center;
-			pp.tx2 = ncols > 1 ? uniform_byte(c.gra, y * c.W + x0 + dx) : (uint8_t)0;
+			pp.tx2 = q0 + 1 < ncols ? uniform_byte(c.gra, y * c.W + xs + dx) : (uint8_t)0;
 		}
-		STAMP(10) // (ticket, and the wait until the row above has begun: the ramp of the row wavefront)
-		for (int q = 0; q < ncols && !pp.fail; ++q) {
+		STAMP(9) // (the wait until the row above has begun: the ramp of the row wavefront)
+		for (int q = q0; q < q1 && !pp.fail; ++q) {
 			const int x = rev ? c.W - 1 - bd - q : bd + q;
 			STAMP(13)
 			// all loads of this pixel that do not depend on other rows go out in one batch ...
@@ -1549,7 +1605,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 		// the row is done and published (with several waves per row: by its last wave, whose stores were drained before it published):
 		// one more row of this sweep of the image
 		if (NW > 1) __syncthreads();
-		if (threadIdx.x == 0) __hip_atomic_fetch_add(as_global(sy.rowsDone) + itemIdx, 1, __ATOMIC_RELAXED, HC_SCOPE);
+		if (threadIdx.x == 0 && q1 == ncols) __hip_atomic_fetch_add(as_global(sy.rowsDone) + itemIdx, 1, __ATOMIC_RELAXED, HC_SCOPE);
 	}
 	STAMP(10)
 	STAMP_FLUSH
@@ -1805,7 +1861,7 @@ void launch_score_pass(const EstConst& c, const float* depthIn, const float* nor
 
 template <int NW, bool BIG, bool HINT>
 static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, const SweepSync& sync, int iter, int nSweeps, int lag,
-                            int affinity, hipStream_t s) {
+                            int affinity, int segLen, hipStream_t s) {
 	// one workgroup per row; rows beyond the resident set are picked up through the ticket
 	int grid = totalRows < 8192 ? totalRows : 8192;
 	if (grid < 1) return;
@@ -1814,41 +1870,41 @@ static void launch_sweep_nw(const EstConst* dItems, int nItems, int maxRows, int
 	// (hypothesis, view) pairs of their own (score_chunk PACK; with one idle group it costs more than it saves)
 	const bool pack = V % 8 != 0 && V % 8 != 7;
 	if (V <= 8) {
-		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, false, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, nSweeps, lag, affinity);
-		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, true, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, nSweeps, lag, affinity);
+		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, false, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, nSweeps, lag, affinity, segLen);
+		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, false, true, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, nSweeps, lag, affinity, segLen);
 	} else {
-		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, false, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, nSweeps, lag, affinity);
-		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, true, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, nSweeps, lag, affinity);
+		if (!pack) hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, false, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, nSweeps, lag, affinity, segLen);
+		else hipLaunchKernelGGL((sweep_kernel<8, NW, BIG, true, true, HINT>), g, b, 0, s, dItems, nItems, maxRows, sync, iter, nSweeps, lag, affinity, segLen);
 	}
 
 }
 template <bool HINT>
 static void launch_sweep_hint(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, const SweepSync& sync, int iter, int nSweeps, int lag,
-                              int wavesPerRow, int affinity, hipStream_t s) {
+                              int wavesPerRow, int affinity, int segLen, hipStream_t s) {
 	if (bigPatch) { // patches beyond 64 taps: one or two waves per row
-		if (wavesPerRow >= 2) launch_sweep_nw<2, true, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s);
-		else launch_sweep_nw<1, true, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s);
+		if (wavesPerRow >= 2) launch_sweep_nw<2, true, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, segLen, s);
+		else launch_sweep_nw<1, true, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, segLen, s);
 		return;
 	}
 	if constexpr (HINT) { // the one sweep of a run that carries the hint: one or two waves per row
-		if (wavesPerRow >= 2) launch_sweep_nw<2, false, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s);
-		else launch_sweep_nw<1, false, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s);
+		if (wavesPerRow >= 2) launch_sweep_nw<2, false, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, segLen, s);
+		else launch_sweep_nw<1, false, true>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, segLen, s);
 		return;
 	}
 	switch (wavesPerRow) {
-	case 1: launch_sweep_nw<1, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s); break;
-	case 3: launch_sweep_nw<3, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s); break;
-	case 4: launch_sweep_nw<4, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s); break;
-	default: launch_sweep_nw<2, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, s); break;
+	case 1: launch_sweep_nw<1, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, segLen, s); break;
+	case 3: launch_sweep_nw<3, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, segLen, s); break;
+	case 4: launch_sweep_nw<4, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, segLen, s); break;
+	default: launch_sweep_nw<2, false, HINT>(dItems, nItems, maxRows, totalRows, V, sync, iter, nSweeps, lag, affinity, segLen, s); break;
 	}
 }
 // One launch for the sweeps iter .. iter + nSweeps - 1 of every item (tickets, rowsDone and the progress words of the items must be
 // zero).  hint: some item of the batch offers the `restore` variant's extra hypothesis in one of these sweeps (EstConst::hintDepth,
 // hintIter): the instance that knows the hint.
 void launch_sweep(const EstConst* dItems, int nItems, int maxRows, int totalRows, int V, bool bigPatch, bool hint, const SweepSync& sync, int iter, int nSweeps,
-                  int lag, int wavesPerRow, int affinity, hipStream_t s) {
-	if (hint) launch_sweep_hint<true>(dItems, nItems, maxRows, totalRows, V, bigPatch, sync, iter, nSweeps, lag, wavesPerRow, affinity, s);
-	else launch_sweep_hint<false>(dItems, nItems, maxRows, totalRows, V, bigPatch, sync, iter, nSweeps, lag, wavesPerRow, affinity, s);
+                  int lag, int wavesPerRow, int affinity, int segLen, hipStream_t s) {
+	if (hint) launch_sweep_hint<true>(dItems, nItems, maxRows, totalRows, V, bigPatch, sync, iter, nSweeps, lag, wavesPerRow, affinity, segLen, s);
+	else launch_sweep_hint<false>(dItems, nItems, maxRows, totalRows, V, bigPatch, sync, iter, nSweeps, lag, wavesPerRow, affinity, segLen, s);
 }
 
 void launch_end_pass(const EstConst& c, int finalPass, float* depth, float* normal, float* conf, hipStream_t s) {

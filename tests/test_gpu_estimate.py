@@ -258,6 +258,44 @@ def test_batch_more_than_eight_views_and_cross_pattern(ctx):
         _compare(g, want[:3])
 
 
+@pytest.mark.parametrize("seg,nw", [("32", "1"), ("40", "2"), ("32", "3")])
+def test_rows_handed_out_in_stretches(seg, nw):
+    """the sweep worker's tickets as stretches of a row (hcmvs_api.cpp: batches whose rows do not all fit the chip; here forced on small
+    images with HCMVS_SWEEP_SEGMENT): a stretch waits for the one to its left, re-reads the ring of the row's latest results from memory
+    and goes on where that one stopped -- every map equals the oracle bit for bit, with the plain and the cross propagation pattern,
+    8 and 10 source views, odd sweeps (right-to-left), one to three waves per row, stretches that do not divide the row"""
+    torch = pytest.importorskip("torch")
+    import os
+    os.environ["HCMVS_SWEEP_SEGMENT"] = seg
+    os.environ["HCMVS_WAVES_PER_ROW"] = nw
+    os.environ["HCMVS_SWEEP_LAUNCHES"] = "per-sweep"
+    try:
+        c = binding.Context(0)
+    finally:
+        for k in ("HCMVS_SWEEP_SEGMENT", "HCMVS_WAVES_PER_ROW", "HCMVS_SWEEP_LAUNCHES"):
+            os.environ.pop(k, None)
+    try:
+        scenes = [_scene(136, 72, 100.0, 8, seed=91), _scene(88, 104, 100.0, 3, seed=92), _scene(120, 80, 100.0, 8, seed=93)]
+        pg, po = _params(adapthalfwin=6, n_estimation_iters=3, seed=611)
+        got, keep = _batch_run(c, torch, scenes, pg, [0, 3, 4])
+        evals = 0
+        for si, ((views, pts), g, k) in enumerate(zip(scenes, got, keep)):
+            po.seed = 611 + [0, 3, 4][si]
+            want = O.estimate(views, po, k[5], k[6], k[3], k[4])
+            _compare(g, want[:3])
+            evals += want[3]
+        assert c.stats().evals == evals
+        # 10 source views (two sets of view groups), outer iteration 1: the cross pattern reaches 5 pixels back into the ring
+        scenes = [_scene(104, 72, 90.0, 10, seed=94), _scene(72, 104, 90.0, 10, seed=95)]
+        pg, po = _params(adapthalfwin=7, n_estimation_iters=3, seed=78, it_external=1, n_external_iters=3, propagate_halfwin=5, propagate_step=4)
+        got, keep = _batch_run(c, torch, scenes, pg, [0, 6])
+        for si, ((views, pts), g, k) in enumerate(zip(scenes, got, keep)):
+            po.seed = 78 + [0, 6][si]
+            _compare(g, O.estimate(views, po, k[5], k[6], k[3], k[4])[:3])
+    finally:
+        c.close()
+
+
 def test_ragged_and_minimum_sizes(ctx):
     """odd image sizes down to the smallest image that still has pixels inside the 7 px border"""
     with pytest.raises(binding.HcmvsError):   # nothing left inside the border

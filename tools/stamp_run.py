@@ -8,6 +8,8 @@ synth = importlib.import_module("hc-mvs_amd.synth")
 W, H, F, V = 1920, 1080, 1600.0, 8
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 I = int(sys.argv[2]) if len(sys.argv) > 2 else 4   # sweeps (bench.py: 8)
+AUTHORS = len(sys.argv) > 3 and sys.argv[3] == "authors"  # 10 source views, half window 7, outer iteration 1 with the cross pattern 5 / 4
+if AUTHORS: V = 10
 dev = torch.device("cuda:0")
 ctx = binding.Context(0)
 items, keep = [], []
@@ -24,6 +26,14 @@ for b in range(B):
                       d_normal=work.data_ptr() + 4 * HW, d_conf=work.data_ptr() + 16 * HW, seed_offset=b))
     keep.append((g, init, work))
 p = binding.default_params(adapthalfwin=6, n_estimation_iters=I)
+if AUTHORS:
+    kw = dict(adapthalfwin=7, n_estimation_iters=I, n_external_iters=4, propagate_halfwin=5, propagate_step=4, photometric_flow=0.26, seed=4321)
+    for g, init, work in keep: work.copy_(init)
+    torch.cuda.synchronize()
+    ctx.estimate_batch_device(items, binding.default_params(it_external=0, **kw))  # outer iteration 0 makes the input maps
+    torch.cuda.synchronize()
+    for k, (g, init, work) in enumerate(keep): init.copy_(work)
+    p = binding.default_params(it_external=1, **kw)
 L = binding.lib(); L.hcmvs_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
 out = (C.c_uint64 * 32)()
 for rep in range(2):
@@ -35,7 +45,7 @@ for rep in range(2):
 st = ctx.stats()
 L.hcmvs_debug_stamps(ctx._h, out, 1)
 names = ["0 wait for the row above", "1 fill_patch (after 12)", "2 slots + interp + park", "3 hypothesis generation", "4 smooth_pass",
-         "5 (prop tail)", "6 publish hook", "7 score_chunk", "8 exchange", "9 store + ring", "10 ticket + wait for the row above to BEGIN (ramp)", "11 accept scan", "12 loop top + loads issue", "13 loop back-edge (end of process_pixel -> loop top)", "14 wait for the pixel's own loads", "15 store + ring (9: drain + publish)"]
+         "5 (prop tail)", "6 publish hook", "7 score_chunk", "8 exchange", "9 wait for the row above to BEGIN (ramp)", "10 ticket", "11 accept scan", "12 loop top + loads issue", "13 loop back-edge (end of process_pixel -> loop top)", "14 wait for the stretch to my left", "15 store + ring (9: drain + publish)"]
 tot = sum(out[i] for i in range(16))
 npx = (W - 14) * (H - 14) * I * B
 print("B", B, "ms_sweep_avg %.2f" % st.ms_sweep_avg, "s_memtime ticks/pixel (wave0) %.0f" % (tot / npx))
