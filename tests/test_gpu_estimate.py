@@ -314,11 +314,17 @@ def test_ragged_and_minimum_sizes(ctx):
 def test_full_size_schedule_invariance():
     """BASELINE.json configs[1] at full size (1920x1080, 8 source views, 7x7, 8 sweeps): the oracle cannot run this in seconds, so
     parity is shown through properties that do not depend on the size -- the maps must not depend on how the rows are
-    scheduled (one image alone with two waves per row == the same image inside a batch with one wave per row and XCD
-    affinity), the evaluation count per pixel-sweep is the algorithm's (2 propagations + 6 refinements, fewer where a
-    neighbour is already good), and the result converges to the analytic ground truth."""
+    scheduled (one image alone with two waves per row and whole rows == the same image inside a batch with one wave per row, XCD
+    affinity and the rows handed out in stretches of 256 columns), the evaluation count per pixel-sweep is the algorithm's
+    (2 propagations + 6 refinements, fewer where a neighbour is already good), and the result converges to the analytic ground truth."""
     torch = pytest.importorskip("torch")
-    c = binding.Context(0)
+    import os
+    os.environ["HCMVS_SWEEP_SEGMENT"] = "256"     # (the automatic policy takes stretches for 6 .. 11 images of this size)
+    try:
+        c = binding.Context(0)
+    finally:
+        os.environ.pop("HCMVS_SWEEP_SEGMENT", None)
+    c1 = binding.Context(0)
     try:
         W, H = 1920, 1080
         scenes = [_scene(W, H, 1600.0, 8, seed=61, n_pts=2000), _scene(W, H, 1600.0, 8, seed=62, n_pts=2000),
@@ -327,13 +333,15 @@ def test_full_size_schedule_invariance():
         pg = binding.default_params(adapthalfwin=6, n_estimation_iters=SWEEPS, seed=4321)
         got3, keep = _batch_run(c, torch, scenes, pg, [0, 1, 2])
         evals3 = c.stats().evals
-        # item 1 alone (two waves per row, no interleaving)
+        # item 1 alone (two waves per row, whole rows, no interleaving), in a context of its own
         views, pts = scenes[1]
         k = keep[1]
         pg1 = binding.default_params(adapthalfwin=6, n_estimation_iters=SWEEPS, seed=4321 + 1)
         ids = list(range(1000 + 9, 1000 + 18))
-        alone = c.estimate(ids[0], ids[1:], pg1, k[5], k[6], k[3], k[4])
-        evals1 = c.stats().evals
+        for i, v in zip(ids, views):
+            c1.upload_view(i, v["gray"], v["K"], v["R"], v["C"])
+        alone = c1.estimate(ids[0], ids[1:], pg1, k[5], k[6], k[3], k[4])
+        evals1 = c1.stats().evals
         for g, a, n in zip(got3[1], alone, ("depth", "normal", "conf")):
             assert np.array_equal(g, a), n
         P = (W - 14) * (H - 14)
@@ -347,6 +355,7 @@ def test_full_size_schedule_invariance():
         assert (np.abs(d - gt)[valid] / gt[valid] < 0.01).mean() > 0.95
     finally:
         c.close()
+        c1.close()
 
 
 def test_batch_mixed_view_counts(ctx):
