@@ -1023,7 +1023,7 @@ struct RowPipe {
 	int pendingPub;   // > 0: results up to this column are stored but not yet published
 	HC_GLOBAL int32_t *upWord, *myWord, *err;
 	int base;         // progress words count columns of sweep k of the launch as (k << 16) + columns: the words are not reset between the sweeps
-	int r, y, ncols;
+	int r, y;
 	bool rev, fail;
 };
 
@@ -1501,7 +1501,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			s1.view = L1.view;
 			s1.put_view(as_global(c.views) + (L1.vact ? L1.view : 0), L1.seg);
 		}
-		pp.ncols = ncols;
 		const int y = rev ? c.H - 1 - bd - r : bd + r;
 		pp.r = r; pp.y = y;
 		pp.upWord = as_global(c.progress) + (size_t)(r > 0 ? r - 1 : 0) * kProgressStride;
@@ -1544,7 +1543,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			first.tx = (float)pp.tx1;
 			load_patch_inputs<S>(c, L, xs, y, first);
 			pp.nI = first.I[0]; pp.nC = first.center;
-			pp.tx2 = q0 + 1 < ncols ? uniform_byte(c.gra, y * c.W + xs + dx) : (uint8_t)0;
+			pp.tx2 = q0 + 1 < q1 ? uniform_byte(c.gra, y * c.W + xs + dx) : (uint8_t)0;
 		}
 		STAMP(9) // (the wait until the row above has begun: the ramp of the row wavefront)
 		for (int q = q0; q < q1 && !pp.fail; ++q) {
@@ -1561,14 +1560,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			int fresh = 0;
 			if (needUp) fresh = __hip_atomic_load(pp.upWord, __ATOMIC_RELAXED, HC_SCOPE) - pp.base;
 			in.I[0] = pp.nI; in.center = pp.nC;
-			if (q + 1 < ncols) { // next pixel's patch inputs (its gradient byte arrived a pixel ago)
+			if (q + 1 < q1) { // next pixel's patch inputs (its gradient byte arrived a pixel ago)
 				PixIn<S> nxt;
 				nxt.tx = (float)pp.tx2;
 				load_patch_inputs<S>(c, L, x + dx, y, nxt);
 				pp.nI = nxt.I[0]; pp.nC = nxt.center;
 			}
 			pp.tx1 = pp.tx2;
-			if (q + 2 < ncols) pp.tx2 = uniform_byte(c.gra, y * c.W + x + 2 * dx);
+			if (q + 2 < q1) pp.tx2 = uniform_byte(c.gra, y * c.W + x + 2 * dx);
 			STAMP(12)
 			// ... and the patch weights are computed while they (and the previous row) arrive
 			Patch<S> P;
@@ -1605,7 +1604,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 		// the row is done and published (with several waves per row: by its last wave, whose stores were drained before it published):
 		// one more row of this sweep of the image
 		if (NW > 1) __syncthreads();
-		if (threadIdx.x == 0 && q1 == ncols) __hip_atomic_fetch_add(as_global(sy.rowsDone) + itemIdx, 1, __ATOMIC_RELAXED, HC_SCOPE);
+		if (threadIdx.x == 0 && q1 == c.W - 2 * bd) __hip_atomic_fetch_add(as_global(sy.rowsDone) + itemIdx, 1, __ATOMIC_RELAXED, HC_SCOPE);
 	}
 	STAMP(10)
 	STAMP_FLUSH

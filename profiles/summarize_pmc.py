@@ -32,9 +32,9 @@ out = {"command": "rocprofv3 --pmc <counter> --output-format csv -- python3 benc
 for k, cs in sorted(acc.items()):
     out["counters"][k] = {c: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for c, v in sorted(cs.items())}
 for k, cs in out["counters"].items():
-    if "sweep_kernel<8, 1" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+    if "sweep_kernel<8, 1, false, false, false" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         out["sweep_kernel_batch%d_hbm_bytes_per_launch" % batch] = int((cs["FETCH_SIZE"]["mean_per_launch"] + cs["WRITE_SIZE"]["mean_per_launch"]) * 1024)
-    if "sweep_kernel<8, 1" in k and "SQ_INSTS_VALU" in cs:
+    if "sweep_kernel<8, 1, false, false, false" in k and "SQ_INSTS_VALU" in cs:
         out["sweep_kernel_batch%d_valu_insts_per_launch" % batch] = int(cs["SQ_INSTS_VALU"]["mean_per_launch"])
         out["sweep_kernel_batch%d_valu_busy_quadcycles_per_launch" % batch] = int(cs["SQ_ACTIVE_INST_VALU"]["mean_per_launch"])
 out["sweeps_per_launch"] = spl
