@@ -606,8 +606,8 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 	HIPCHK(c, hipEventRecord(c->ev[1], s));
 	SweepSync sy;
 	sy.ticket = c->sync + 16; sy.rowsDone = c->sync + 16 + kMaxBatch; sy.error = c->sync + 1; sy.evals = c->evals;
-	// A batch that fills the chip several times over (16 images or more) runs all its sweeps in ONE launch (round 4): the images go
-	// through their sweeps independently of each other, without a chip-wide drain and refill between two sweeps (+5.4 % at 16 images,
+	// A batch whose rows fill the chip four times over (12 images of 1080p or more) runs all its sweeps in ONE launch (round 4): the images go
+	// through their sweeps independently of each other, without a chip-wide drain and refill between two sweeps (+5 % at 12, +7 % at 16 images,
 	// +2.6 ... 3.5 % at 32; profiles/r04_launch_modes.txt).  Fewer images are bound by the latency of their row wavefronts, not by the
 	// chip, and gain nothing from it (measured: 4 -> 8 % slower), so they keep one launch per sweep.  HCMVS_SWEEP_LAUNCHES=one | per-sweep
 	// overrides.  The `restore` variant's extra hypothesis belongs to the last sweep of the last outer iteration: that sweep then
@@ -628,7 +628,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 		int first = 0, nLaunches = 0;
 		c->lastSweepLaunches = 0;
 		while (first < nSweeps) {
-			const bool perSweep = c->sweepPerLaunch == 1 || (c->sweepPerLaunch == 0 && n_items < 16);
+			const bool perSweep = c->sweepPerLaunch == 1 || (c->sweepPerLaunch == 0 && totalRows < 4 * slots);
 			int count = perSweep ? 1 : nSweeps - first;
 			bool hint = false;
 			if (hintLast) { if (first == nSweeps - 1) hint = true; else if (first + count == nSweeps) --count; } // the hint sweep runs alone
@@ -641,7 +641,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 			// jitter of their row wavefronts, not by slots (3 or 4 images: 0 ... -3 %), more fill the tail with other images' rows anyway
 			// (12: the same) -- measured, profiles/r04_launch_modes.txt.  HCMVS_SWEEP_SEGMENT=N forces stretches of N columns, 0 whole rows.
 			int segLen = 0, tickets = totalRows;
-			if (count == 1 && (c->sweepSegment > 0 || (c->sweepSegment < 0 && nw == 1 && totalRows >= 2 * slots && totalRows < 4 * slots))) {
+			if (c->sweepSegment > 0 || (c->sweepSegment < 0 && count == 1 && nw == 1 && totalRows >= 2 * slots && totalRows < 4 * slots)) {
 				segLen = c->sweepSegment > 0 ? c->sweepSegment : 256;
 				if (segLen < 32) segLen = 32; // (the ring of a row's latest results is re-read from memory at the start of a stretch)
 				tickets = 0;

@@ -81,7 +81,7 @@ typedef struct {
 	float ms_end;         /* device time of median/end/export kernels */
 	float ms_total;
 	int32_t n_sweeps;
-	int32_t n_sweep_launches; /* kernel launches the n_sweeps sweeps ran in: a batch of 16 or more images runs all its sweeps in one launch */
+	int32_t n_sweep_launches; /* kernel launches the n_sweeps sweeps ran in: a batch whose rows fill the chip four times over (12 or more images of 1080p) runs all its sweeps in one launch */
 } hcmvs_stats;
 
 void hcmvs_default_params(hcmvs_params* p);

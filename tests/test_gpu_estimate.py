@@ -292,6 +292,13 @@ def test_rows_handed_out_in_stretches(seg, nw):
         for si, ((views, pts), g, k) in enumerate(zip(scenes, got, keep)):
             po.seed = 78 + [0, 6][si]
             _compare(g, O.estimate(views, po, k[5], k[6], k[3], k[4])[:3])
+        # patches beyond 64 taps (11 x 11: the big-patch worker, border 10)
+        scenes = [_scene(120, 88, 100.0, 3, seed=96), _scene(96, 104, 100.0, 4, seed=97)]
+        pg, po = _params(adapthalfwin=10, n_estimation_iters=2, seed=35)
+        got, keep = _batch_run(c, torch, scenes, pg, [0, 2])
+        for si, ((views, pts), g, k) in enumerate(zip(scenes, got, keep)):
+            po.seed = 35 + [0, 2][si]
+            _compare(g, O.estimate(views, po, k[5], k[6], k[3], k[4])[:3])
     finally:
         c.close()
 
