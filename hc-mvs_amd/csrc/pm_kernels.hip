@@ -1553,12 +1553,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			PixIn<S> in;
 			in.tx = (float)pp.tx1;
 			prefetch_static<S>(c, L, x, y, q, rev, pp.known >= q + 1, in);
-			// the row above is not yet known to have passed this column (the hook's poll is a scoring round old): one more poll rides with
-			// the pixel's loads and is back with them, behind fill_patch -- a row that trails the one above by little more than a pixel then
-			// needs no synchronous poll (a full round trip to the progress word with nothing to hide it) at every pixel
-			const bool needUp = pp.known < q + 1;
-			int fresh = 0;
-			if (needUp) fresh = __hip_atomic_load(pp.upWord, __ATOMIC_RELAXED, HC_SCOPE) - pp.base;
 			in.I[0] = pp.nI; in.center = pp.nC;
 			if (q + 1 < q1) { // next pixel's patch inputs (its gradient byte arrived a pixel ago)
 				PixIn<S> nxt;
@@ -1573,21 +1567,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			Patch<S> P;
 			fill_patch<S, BIG>(c, L, x, y, in, P, st);
 			STAMP(1)
-			// The next pixel's patch inputs (issued above, a pixel ahead), this pixel's own loads and the poll are all back before the pixel's
-			// first arithmetic needs them: wait for everything HERE, where it is free, and hand pp.nI / pp.nC on as plain registers -- a
-			// load still "in flight" at the loop's back-edge would make the compiler put a full `s_waitcnt vmcnt(0)` there (see the hook's poll)
-			asm volatile("s_waitcnt vmcnt(0)" : "+v"(pp.nI), "+v"(pp.nC), "+v"(fresh) :: "memory");
-			if (needUp) {
-				if (fresh > pp.known) pp.known = fresh;
-				if (pp.known < q + 1) { // the previous row must have finished this column
-					pp.known = wait_progress(pp.upWord, pp.base + q + 1, pp.err);
-					if (pp.known < 0) { pp.fail = true; break; }
-					pp.known -= pp.base;
+			if (pp.known < q + 1) { // the previous row must have finished this column
+				pp.known = wait_progress(pp.upWord, pp.base + q + 1, pp.err);
+				if (pp.known < 0) { // (the same hand-over as below, so that the two ways out of the pixel meet with nothing in flight)
+					pp.fail = true;
+					asm volatile("s_waitcnt vmcnt(0)" : "+v"(pp.nI), "+v"(pp.nC) :: "memory");
+					break;
 				}
+				pp.known -= pp.base;
 				prefetch_up<S>(c, in);
 			}
+			// The next pixel's patch inputs (issued above, a pixel ahead) and this pixel's own loads are all back before the pixel's first
+			// arithmetic needs the latter: wait for everything HERE, where it is free, and hand pp.nI / pp.nC on as plain registers -- a
+			// load still "in flight" at the loop's back-edge would make the compiler put a full `s_waitcnt vmcnt(0)` there (see the hook's poll)
+			asm volatile("s_waitcnt vmcnt(0)" : "+v"(pp.nI), "+v"(pp.nC) :: "memory");
 			STAMP(0)
-			STAMP(14)
 			const unsigned e0 = evals;
 			process_pixel<S, NW, BIG, TWO, PACK, HINT>(c, L, L1, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
 			taps += (unsigned long long)(evals - e0) * (unsigned)((P.a + 1) * (P.a + 1));
