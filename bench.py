@@ -302,7 +302,7 @@ def live_pmc(batch, timeout_s=150, kernel=None, extra=(), sets=(("FETCH_SIZE",),
         return None
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["TMPDIR"] = "/tmp"
-    kernel = kernel or "sweep_kernel<8, %d" % (1 if batch >= 3 else 2)   # waves per row the library picks
+    kernel = kernel or "sweep_kernel<8, %d" % (3 if batch == 1 else (2 if batch <= 3 else 1))   # waves per row the library picks for 1080p images
     tmp = tempfile.mkdtemp(prefix="hcmvs_pmc_", dir="/tmp")
     res = {}
     try:
@@ -523,7 +523,7 @@ def main():
         # the (W + H) x T_pixel critical path of its row wavefront
         taps_a1 = int(np.where(ctx.gradient_map(0)[7:H - 7, 7:W - 7] > 100, 36, (AHW + 1) ** 2).astype(np.int64).sum())
         bytes_1 = (int(st1.tap_evals) - taps_a1) / SWEEPS * N_SRC * 16.0 + P * 44.0
-        out["roofline_single_unit"] = {"kernel": "sweep_kernel<8,2> (one image alone: 2 waves per row, hcmvs_api.cpp waves-per-row policy)",
+        out["roofline_single_unit"] = {"kernel": "sweep_kernel<8,3> (one image alone: 3 waves per row, the rows handed out in stretches of 256 columns; hcmvs_api.cpp waves-per-row policy)",
                                        "bound": "latency of the row wavefront; the figure is in the SURVEY.md 8d convention (hbm)",
                                        "achieved": round(bytes_1 / (st1.ms_sweep_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(bytes_1 / (st1.ms_sweep_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -616,11 +616,14 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 		const int nSweeps = p->n_estimation_iters;
 		bool hintLast = false;
 		for (int i = 0; i < n_items; ++i) hintLast = hintLast || (c->hItems[i].hintDepth && c->hItems[i].hintIter == nSweeps - 1);
-		// waves per row: two for one or two images alone on the chip (latency of the row wavefront; measured: profiles/r03_small_batches.txt)
-		// -- but only while every row of the batch can be resident at once (12 workers per CU): a row that has to wait for a free slot
-		// delays the whole wavefront behind it (a lone 3840x2160 image has 2146 rows: one wave each)
+		// Waves per row, by how the batch's rows compare with the workers the chip holds at once (12 per CU; measured on 1080p images,
+		// profiles/r04_launch_modes.txt): a batch of few rows is bound by the latency of one pixel along the (W + H) critical path of its row
+		// wavefronts, and the scoring of a pixel's hypotheses divides among the waves of a row -- three waves for one image (1066 rows), two
+		// for two or three (a lone 3840x2160 image has 2146 rows: two), one from there on, where the chip's throughput counts.  More waves
+		// than workers are fine since the rows are handed out in stretches (below): a row no longer needs a worker of its own from its
+		// first to its last column.
 		const int slots = (c->nCU > 0 ? c->nCU : 256) * 12;
-		const int nw = c->wavesPerRow ? c->wavesPerRow : (n_items >= 3 || (n_items == 1 && 2 * totalRows > slots) ? 1 : 2);
+		const int nw = c->wavesPerRow ? c->wavesPerRow : (10 * totalRows <= 4 * slots ? 3 : (10 * totalRows <= 11 * slots ? 2 : 1));
 		// the launcher picks the kernel variant by view count: an item whose count leaves two or more view groups idle wants the
 		// pair-packing variant, which is correct for the other items of its layout class too
 		int vSel = items[0].n_src;
@@ -635,13 +638,14 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 			HIPCHK(c, hipMemsetAsync(c->sync + 16, 0, sizeof(int32_t) * 2 * kMaxBatch, s)); // tickets + rowsDone; the error word stays sticky
 			for (int i = 0; i < n_items; ++i)
 				HIPCHK(c, hipMemsetAsync(c->slots[i].progress, 0, (size_t)(c->hItems[i].H - 2 * c->hItems[i].border) * kProgressStride * sizeof(int32_t), s));
-			// A launch of ONE sweep with two to four times as many rows as the chip holds workers (6 .. 11 images of 1080p) hands out
-			// stretches of 256 columns instead of whole rows: with whole rows the last rows of every image begin when the chip is already
-			// draining and run on a third of it (8 images: 106.9 -> 100.0 ms per sweep, 6: 92.2 -> 90.2).  Fewer images are bound by the
-			// jitter of their row wavefronts, not by slots (3 or 4 images: 0 ... -3 %), more fill the tail with other images' rows anyway
-			// (12: the same) -- measured, profiles/r04_launch_modes.txt.  HCMVS_SWEEP_SEGMENT=N forces stretches of N columns, 0 whole rows.
+			// A launch of ONE sweep with more waves than the chip holds workers (and less than four times as many rows: from there on all
+			// sweeps run in one launch) hands out stretches of 256 columns instead of whole rows: a worker's slot comes free after 256 pixels.
+			// With whole rows the rows beyond the resident set begin only when row 0 has reached its end -- 8 images: 107.2 -> 100.3 ms per
+			// sweep; it is also what lets one to three images have two or three waves per row (1: 35.6 -> 33.7 ms, 2: 46.1 -> 42.0,
+			// 3: 59.9 -> 55.4); 4 and 5 images: 0 ... +2 % (profiles/r04_launch_modes.txt).  HCMVS_SWEEP_SEGMENT=N forces stretches of N
+			// columns, 0 whole rows.
 			int segLen = 0, tickets = totalRows;
-			if (c->sweepSegment > 0 || (c->sweepSegment < 0 && count == 1 && nw == 1 && totalRows >= 2 * slots && totalRows < 4 * slots)) {
+			if (c->sweepSegment > 0 || (c->sweepSegment < 0 && count == 1 && nw * totalRows > slots && totalRows < 4 * slots)) {
 				segLen = c->sweepSegment > 0 ? c->sweepSegment : 256;
 				if (segLen < 32) segLen = 32; // (the ring of a row's latest results is re-read from memory at the start of a stretch)
 				tickets = 0;
