@@ -622,7 +622,7 @@ int hcmvs_estimate_batch_device(hcmvs_ctx* c, const hcmvs_batch_item* items, int
 		// for two or three (a lone 3840x2160 image has 2146 rows: two), one from there on, where the chip's throughput counts.  More waves
 		// than workers are fine since the rows are handed out in stretches (below): a row no longer needs a worker of its own from its
 		// first to its last column.
-		const int slots = (c->nCU > 0 ? c->nCU : 256) * 12;
+		const int slots = (c->nCU > 0 ? c->nCU : 256) * (p->adapthalfwin > kHalfWindow ? 8 : 12); // (the big-patch worker: two waves per SIMD)
 		const int nw = c->wavesPerRow ? c->wavesPerRow : (10 * totalRows <= 4 * slots ? 3 : (10 * totalRows <= 11 * slots ? 2 : 1));
 		// the launcher picks the kernel variant by view count: an item whose count leaves two or more view groups idle wants the
 		// pair-packing variant, which is correct for the other items of its layout class too

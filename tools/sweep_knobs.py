@@ -7,6 +7,8 @@ import numpy as np, torch
 binding = importlib.import_module("hc-mvs_amd.binding")
 synth = importlib.import_module("hc-mvs_amd.synth")
 W, H, F, V = 1920, 1080, 1600.0, int(os.environ.get("HCMVS_KNOB_VIEWS", "8"))  # source views per reference image
+if os.environ.get("HCMVS_KNOB_SIZE"):  # e.g. 3840x2160
+    W, H = (int(v) for v in os.environ["HCMVS_KNOB_SIZE"].split("x")); F = 1600.0 * W / 1920
 B, I = int(sys.argv[1]), int(sys.argv[2])
 configs = sys.argv[3:] or [":1"]
 dev = torch.device("cuda:0")
