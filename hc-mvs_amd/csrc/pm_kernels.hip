@@ -1367,7 +1367,6 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 			store_f(&c.conf[idx], conf);
 		}
 	}
-	STAMP(15)
 	if constexpr (NW == 1) {
 		pp.pendingPub = q + 1; // published by the hook of the next pixel, a scoring round later: the drain of the stores is then free
 	} else if (wv == NW - 1) {
@@ -1378,7 +1377,7 @@ __device__ __forceinline__ void process_pixel(const EstConst& c, const LaneCtx<S
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		if (lane == 0) __hip_atomic_store(pp.myWord, pp.base + q + 1, __ATOMIC_RELAXED, HC_SCOPE);
 	}
-	STAMP(9)
+	STAMP(15)
 
 }
 
@@ -1585,9 +1584,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(!BIG ? 
 			const unsigned e0 = evals;
 			process_pixel<S, NW, BIG, TWO, PACK, HINT>(c, L, L1, sh, par, wv, x, y, q, iter, in, P, st, pp, evals, issued STAMP_PASS);
 			taps += (unsigned long long)(evals - e0) * (unsigned)((P.a + 1) * (P.a + 1));
-#ifdef HCMVS_STAMP_BACKEDGE
-			STAMP(5)
-#endif
+			STAMP(5) // (the pixel loop's back-edge is stamp 13's alone)
 		}
 		if (pp.fail) break;
 		if (pp.pendingPub > 0) { // last column of the row (NW == 1)

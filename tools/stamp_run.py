@@ -45,7 +45,7 @@ for rep in range(2):
 st = ctx.stats()
 L.hcmvs_debug_stamps(ctx._h, out, 1)
 names = ["0 wait for the row above", "1 fill_patch (after 12)", "2 slots + interp + park", "3 hypothesis generation", "4 smooth_pass",
-         "5 (prop tail)", "6 publish hook", "7 score_chunk", "8 exchange", "9 wait for the row above to BEGIN (ramp)", "10 ticket", "11 accept scan", "12 loop top + loads issue", "13 loop back-edge (end of process_pixel -> loop top)", "14 wait for the stretch to my left", "15 store + ring (9: drain + publish)"]
+         "5 (prop tail)", "6 publish hook", "7 score_chunk", "8 exchange", "9 wait for the row above to BEGIN (ramp)", "10 ticket", "11 accept scan", "12 loop top + loads issue", "13 loop back-edge (end of process_pixel -> loop top)", "14 wait for the stretch to my left", "15 store + ring + publish"]
 tot = sum(out[i] for i in range(16))
 npx = (W - 14) * (H - 14) * I * B
 print("B", B, "ms_sweep_avg %.2f" % st.ms_sweep_avg, "s_memtime ticks/pixel (wave0) %.0f" % (tot / npx))
